@@ -1,0 +1,243 @@
+/*
+ * parametron_hip.h — C ABI of libparametron_hip.so: the MI355X (gfx950) implementation of
+ * Parametron.jl's parameter-update / coefficient re-evaluation hot path.
+ *
+ * The reference (tkoolen/Parametron.jl v0.9.1, pure Julia) has no FFI of its own; the de-facto
+ * operator interface of the path is
+ *   (1) the in-place builders of Parametron.Functions that the `optimize` rewrite rules splice
+ *       into the lazy-expression DAG           (src/lazyexpression.jl:200-302, src/functions.jl)
+ *   (2) update!(moi_f, f, varmap) x3            (src/moi_interop.jl:35-81)
+ *   (3) the per-node call ABI FunctionWrapper{T,Tuple{}} (src/FunctionWrappersQuickFix.jl:108-126)
+ *       driven by update!(m::Model)             (src/model.jl:132-143).
+ * Each entry point below names the reference function(s) it replaces.  A Julia host binds them
+ * with `ccall((:pmt_xxx, libparametron_hip), Cint, (...), ...)` — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no HIP/torch types: `void *stream` is a hipStream_t (NULL = default stream);
+ *     every `const double *`, term pointer etc. is a DEVICE pointer unless named host_*.
+ *   - all calls are asynchronous on `stream`; nothing allocates or synchronises unless stated
+ *     (the reference's `@allocated solve!(model) == 0` contract, test/model.jl:116-124).
+ *   - matrices are column-major with leading dimension `lda` (Julia Matrix{Float64},
+ *     src/functions.jl:790-796); variable indices are 1-based Int64 (Variable.index).
+ *   - `varmap` is model_var_to_optimizer (src/model.jl:8,100-107): varmap[k-1] is the optimizer
+ *     index of Variable k; NULL = IdentityVarMap (src/moi_interop.jl:32-33).
+ *   - return value: PMT_OK or an error code; pmt_last_error() gives the message.  The Julia/Python
+ *     host maps PMT_DIMENSION_MISMATCH -> DimensionMismatch, PMT_INVALID_ARGUMENT -> ArgumentError,
+ *     PMT_STATE_ERROR -> ErrorException (src/functions.jl:780-781, src/model.jl:50,61,69).
+ *   - threading: calls on one stream/plan must be externally serialised (the reference is
+ *     single-threaded and shares `dest` buffers, src/lazyexpression.jl:202-203).
+ */
+#ifndef PARAMETRON_HIP_H
+#define PARAMETRON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMT_OK 0
+#define PMT_DIMENSION_MISMATCH 1
+#define PMT_INVALID_ARGUMENT 2
+#define PMT_HIP_ERROR 3
+#define PMT_STATE_ERROR 4
+#define PMT_OUT_OF_MEMORY 5
+
+/* Term layouts = the Julia isbits structs. */
+typedef struct { double coeff; int64_t var; } pmt_linear_term;                 /* LinearTerm{Float64} src/functions.jl:110-113 == MOI.ScalarAffineTerm (moi_interop.jl:40) */
+typedef struct { double coeff; int64_t row; int64_t col; } pmt_quadratic_term; /* QuadraticTerm{Float64} src/functions.jl:136-140 == MOI.ScalarQuadraticTerm (moi_interop.jl:59) */
+typedef struct { int64_t output_index; double coeff; int64_t var; } pmt_vector_affine_term; /* MOI.VectorAffineTerm (moi_interop.jl:75) */
+
+const char *pmt_last_error(void);
+int pmt_version(void);
+/* number of visible HIP devices (<= 0: none); used by hosts to fail loudly without a GPU */
+int pmt_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense affine nodes
+ * ------------------------------------------------------------------------------------- */
+
+/* y = A*x (+|-) b as Vector{AffineFunction}: out_terms[row*cols + col] = (A[row,col], xvar[col]),
+ * out_consts[row] = 0.0 (+|-) b[row].   sign: +1 vecadd!, -1 vecsubtract!, 0 no vector (b ignored).
+ * Replaces matvecmul!(y, A, x::Vector{Variable}) src/functions.jl:775-798 fused with
+ * vecadd!/vecsubtract!(dest, y, b) :751-764 (copyto! :422-427, add!/subtract! Number :452,:474). */
+int pmt_affine_assemble_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                            const int64_t *xvar, const double *b, int sign,
+                            pmt_linear_term *out_terms, double *out_consts, void *stream);
+
+/* Same node written straight into MOI.VectorAffineFunction buffers:
+ * out_terms[row*cols + col] = (row_offset + row + 1, A[row,col], varmap[xvar[col]]), out_consts as above.
+ * Replaces the chain above + update!(::MOI.VectorAffineFunction, fs, varmap) src/moi_interop.jl:64-81. */
+int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                               const int64_t *xvar, const double *b, int sign,
+                               const int64_t *varmap, int64_t row_offset,
+                               pmt_vector_affine_term *out_terms, double *out_consts, void *stream);
+
+/* dest[i] = x[i] (+|-) v[i] for x::Vector{Variable}: one term (1.0, xvar[i]) per row, constant 0.0 (+|-) v[i]
+ * (`x - l` bounds, test/model.jl:162-163).  vecadd!/vecsubtract! with copyto!(f, ::Variable)
+ * src/functions.jl:421.  Native output (out_terms_lt) and/or MOI output (out_terms_vat) may be NULL. */
+int pmt_vars_addsub_f64(const int64_t *xvar, int64_t n, const double *v, int sign,
+                        const int64_t *varmap, int64_t row_offset,
+                        pmt_linear_term *out_terms_lt, pmt_vector_affine_term *out_terms_vat,
+                        double *out_consts, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Generic term-list nodes (materialised Vector{AffineFunction} = flat LT buffer + row_ptr + consts).
+ * row_ptr has rows+1 entries (device); NULL means uniform rows of `row_len` terms.
+ * ------------------------------------------------------------------------------------- */
+
+/* dst row i = [ xa[i].linear ; sb * xb[i].linear ],  constant  ca[i] (+ sb*cb[i])  with sb = +1 or -1 (exact):
+ *   copyto! (:422-427)  then  add!(f, ::AffineFunction) :455  /  subtract!(f, ::AffineFunction) :477-485,
+ * i.e. vecadd!/vecsubtract! :751-764 on any mix of Vector{AffineFunction}, Vector{Variable} (pre-materialised
+ * by the host as one (1.0, var) term per row, consts NULL: copyto!(f, ::Variable) :421 leaves the constant 0)
+ * and number vectors (terms NULL, consts = the numbers: copyto!(f, ::Number) :419, add!/subtract! :452,:474).
+ * A part with consts == NULL contributes no constant; part b may be absent altogether (plain copyto!, vcat!
+ * pieces :969-994).  If part a has no constants the row constant is 0.0 (+ sb*cb[i]). */
+int pmt_affvec_combine_f64(int64_t rows,
+                           const pmt_linear_term *xa_terms, const int64_t *xa_row_ptr, int64_t xa_row_len, const double *xa_consts,
+                           const pmt_linear_term *xb_terms, const int64_t *xb_row_ptr, int64_t xb_row_len, const double *xb_consts, int sb,
+                           pmt_linear_term *out_terms, const int64_t *out_row_ptr, int64_t out_row_len, double *out_consts,
+                           void *stream);
+
+/* dest[i] = s * y[i] where s is a device scalar (Parameter{Float64}) or host constant:
+ * scale!(dest, x::Number, y::Vector{AffineFunction}) src/functions.jl:895-915 -> mul! :578 -> muladd! :515-523.
+ * coeff = s*coeff, const = 0 + y.c*s.  s_dev == NULL uses s_host. */
+int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_linear_term *y_terms, const double *y_consts,
+                         const double *s_dev, double s_host,
+                         pmt_linear_term *out_terms, double *out_consts, void *stream);
+
+/* y = A * X with X::Vector{AffineFunction} of uniform length L:
+ * row `row` = concat over col of A[row,col]*X[col].linear ; const = sum_col X.c[col]*A[row,col] (in col order).
+ * matvecmul!(y, A, x::Vector{AffineFunction}) src/functions.jl:800-822 (muladd! :524 -> :515-523). */
+int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                           const pmt_linear_term *x_terms, int64_t x_row_len, const double *x_consts,
+                           pmt_linear_term *out_terms, double *out_consts, void *stream);
+
+/* dot(v, x) family producing an AffineFunction (src/functions.jl:665-687):
+ *   Number[] . Variable[]        -> out_terms[i] = (v[i], xvar[i]), const 0            (:676-687)
+ *   Number[] . AffineFunction[]  -> concat_i v[i]*X[i].linear, const = sum_i X.c[i]*v[i] (:665-674, uniform L) */
+int pmt_vecdot_numbers_vars_f64(const double *v, const int64_t *xvar, int64_t n,
+                                pmt_linear_term *out_terms, double *out_const, void *stream);
+int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n,
+                                const pmt_linear_term *x_terms, int64_t x_row_len, const double *x_consts,
+                                pmt_linear_term *out_terms, double *out_const, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Quadratic nodes
+ * ------------------------------------------------------------------------------------- */
+
+/* dest = x . y for x, y ::Vector{AffineFunction} with uniform row lengths nx, ny (LITERAL expansion):
+ *   quad[(i*nx + a)*ny + b] = (x[i].lin[a].coeff * y[i].lin[b].coeff, x[i].lin[a].var, y[i].lin[b].var)
+ *   lin[i*(nx+ny) + a]      = (y.c[i] * x[i].lin[a].coeff, var)        a < nx
+ *   lin[i*(nx+ny) + nx + b] = (x.c[i] * y[i].lin[b].coeff, var)        b < ny
+ *   const = sum_i x.c[i]*y.c[i]  accumulated left to right
+ * = _vecdot!(dest::QuadraticFunction, x, y) src/functions.jl:702-709 over muladd! :548-576.
+ * moi != 0 fuses update!(::MOI.ScalarQuadraticFunction, f, varmap) src/moi_interop.jl:45-62:
+ * indices go through varmap and coefficients with rowvar == colvar are doubled (:58). */
+int pmt_quad_expand_f64(int64_t rows,
+                        const pmt_linear_term *x_terms, int64_t nx, const double *x_consts,
+                        const pmt_linear_term *y_terms, int64_t ny, const double *y_consts,
+                        int moi, const int64_t *varmap,
+                        pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
+                        void *stream);
+
+/* Canonical least-squares objective for residual = A*x (+|-) b:  canonicalize!(residual . residual)
+ * (src/functions.jl:381-386 applied to the literal result above), then the MOI copy:
+ *   out_quad[tri(j,k)] = (2 * sum_i A[i,j]*A[i,k], vm[xvar[j]], vm[xvar[k]])  for j <= k, row-major upper triangle
+ *   out_lin[j]         = (2 * sum_i c_i*A[i,j], vm[xvar[j]])   with c_i = 0.0 (+|-) b[i]
+ *   out_const          = sum_i c_i^2 left to right.
+ * Requires xvar strictly increasing (distinct variables in sorted order — what Variable(model) yields);
+ * moi == 0 keeps native indices (no varmap) but the same coefficients as the MOI form are NOT produced:
+ *   native canonical form has diagonal coefficient (A'A)[j,j] and off-diagonal 2*(A'A)[j,k].
+ * f64 MFMA contraction; `workspace` (device, pmt_quad_gram_workspace_bytes) holds split-K partial tiles. */
+size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
+int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                      const int64_t *xvar, const double *b, int sign,
+                      int moi, const int64_t *varmap,
+                      pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
+                      void *workspace, void *stream);
+
+/* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
+ * bilinearmul! src/functions.jl:840-858 (the Q' pairing quirk is reproduced).
+ * Q must be contiguous (lda == rows).  moi as above. */
+int pmt_bilinear_f64(const double *Q, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar,
+                     int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream);
+
+/* x . y for Variable/LinearTerm vectors: quad[i] = (xc[i]*yc[i], xvar[i], yvar[i]); xc/yc NULL = Variables (coeff 1)
+ * _vecdot! src/functions.jl:689-700. */
+int pmt_vecdot_terms_f64(int64_t n, const double *xc, const int64_t *xvar, const double *yc, const int64_t *yvar,
+                         int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream);
+
+/* AffineFunction[] . Variable[] (uniform row length L):
+ *   quad[i*L + a] = (x[i].lin[a].coeff, x[i].lin[a].var, yvar[i]) ; lin[i] = (x.c[i], yvar[i])
+ * _vecdot! :702-709 over muladd!(dest, ::AffineFunction, ::Variable) src/functions.jl:537-546. */
+int pmt_vecdot_affs_vars_f64(int64_t rows, const pmt_linear_term *x_terms, int64_t L, const double *x_consts,
+                             const int64_t *yvar, int moi, const int64_t *varmap,
+                             pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MOI copies of materialised native functions — update!(moi_f, f, varmap) src/moi_interop.jl:35-81
+ * ------------------------------------------------------------------------------------- */
+int pmt_pack_scalar_affine_f64(const pmt_linear_term *terms, int64_t n, const int64_t *varmap,
+                               pmt_linear_term *out_terms, void *stream);                       /* :35-43 */
+int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int64_t nq, const int64_t *varmap,
+                                  pmt_quadratic_term *out_quad, void *stream);                  /* :53-60 (diag x2) */
+int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const int64_t *row_ptr, int64_t rows, int64_t row_len,
+                               const int64_t *varmap, int64_t row_offset,
+                               pmt_vector_affine_term *out_terms, void *stream);                /* :64-81 */
+
+/* ---------------------------------------------------------------------------------------
+ * Sparse constraint matrix (BASELINE config 5): C given in CSC (Julia SparseMatrixCSC: colptr/rowval
+ * 1-based Int64, nzval).  pmt_sparse_plan_* computes ONCE the row-major order of the structural non-zeros;
+ * per re-evaluation pmt_sparse_pack_vector_f64 gathers nzval through it into MOI.VectorAffineTerms
+ * (row-major, columns ascending within a row = the reference's matvecmul! order restricted to structural nz).
+ * ------------------------------------------------------------------------------------- */
+/* host-side helper: perm[t] = index into nzval of the t-th term in row-major order, rows_out[t], cols_out[t] (1-based) */
+int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *host_colptr, const int64_t *host_rowval,
+                              int64_t *host_perm, int64_t *host_rows, int64_t *host_cols, int64_t *host_row_ptr);
+int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *perm, const int64_t *term_row, const int64_t *term_var,
+                               int64_t nnz, const int64_t *varmap, int64_t row_offset,
+                               pmt_vector_affine_term *out_terms, void *stream);
+/* constants: out[i] = 0.0 (+|-) d[i] */
+int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Device-side Parameter update callbacks for synthetic inputs (counter-based):
+ * dst[i] = scale * U[0,1)(seed, i)   — the analogue of `Parameter(rand!, zeros(n, n), model)` README.md:36-43
+ * ------------------------------------------------------------------------------------- */
+int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Plan = a recorded re-evaluation: device buffers + a tape of the launches above.
+ * Built once by the host from the lazy-expression DAG (↔ `dest = deepcopy(expr())` pre-allocation,
+ * src/lazyexpression.jl:202,230,243), replayed by every update!(model) (src/model.jl:132-143) with no
+ * allocation and no host logic (↔ FunctionWrapper hop per node, FunctionWrappersQuickFix.jl:108-126).
+ * ------------------------------------------------------------------------------------- */
+typedef struct pmt_plan pmt_plan;
+
+int pmt_plan_create(int device, void *stream /* NULL: plan creates its own stream */, pmt_plan **out);
+int pmt_plan_destroy(pmt_plan *plan);
+void *pmt_plan_stream(pmt_plan *plan);
+/* device allocation owned by the plan (zero-filled); freed by pmt_plan_destroy */
+int pmt_plan_alloc(pmt_plan *plan, size_t bytes, void **out_device_ptr);
+size_t pmt_plan_bytes_allocated(const pmt_plan *plan);
+/* asynchronous copies on the plan's stream */
+int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
+int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
+int pmt_plan_synchronize(pmt_plan *plan);
+
+/* recording: between begin_record and end_record every pmt_*_f64 call issued with stream ==
+ * pmt_plan_recording_stream(plan) is appended to the plan's tape instead of being launched */
+int pmt_plan_begin_record(pmt_plan *plan);
+int pmt_plan_end_record(pmt_plan *plan);
+void *pmt_plan_recording_stream(pmt_plan *plan);
+int64_t pmt_plan_tape_length(const pmt_plan *plan);
+/* replay the tape on the plan's stream: one update!(model).  use_graph != 0 replays a captured hipGraph */
+int pmt_plan_update(pmt_plan *plan);
+int pmt_plan_instantiate_graph(pmt_plan *plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

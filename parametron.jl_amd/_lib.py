@@ -1,0 +1,125 @@
+"""ctypes binding of libparametron_hip.so (the C ABI declared in include/parametron_hip.h).
+
+This is the product path: there is NO CPU fallback.  If the shared library is missing or no
+MI355X is visible, the calls raise — loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libparametron_hip.so")
+
+# Julia isbits layouts as numpy structured dtypes
+LT = np.dtype([("coeff", "<f8"), ("var", "<i8")])
+QT = np.dtype([("coeff", "<f8"), ("row", "<i8"), ("col", "<i8")])
+VAT = np.dtype([("out", "<i8"), ("coeff", "<f8"), ("var", "<i8")])
+
+PMT_OK, PMT_DIMENSION_MISMATCH, PMT_INVALID_ARGUMENT, PMT_HIP_ERROR, PMT_STATE_ERROR, PMT_OUT_OF_MEMORY = range(6)
+
+
+class DimensionMismatch(Exception):
+    """Julia's DimensionMismatch (src/functions.jl:780-781 and the other @boundscheck sites)."""
+
+
+class ArgumentError(ValueError):
+    """Julia's ArgumentError (src/lazyexpression.jl:175,185; src/model.jl:226,243,246)."""
+
+
+class ErrorException(RuntimeError):
+    """Julia's ErrorException — error(...) (src/model.jl:50,61,69,139)."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_vp, _i64, _f64, _ci, _u64, _sz = C.c_void_p, C.c_int64, C.c_double, C.c_int, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/parametron_hip.h declares
+SIGNATURES = {
+    "pmt_last_error": (C.c_char_p, []),
+    "pmt_version": (_ci, []),
+    "pmt_device_count": (_ci, []),
+    "pmt_affine_assemble_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_affine_pack_vector_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _i64, _vp, _vp, _vp]),
+    "pmt_vars_addsub_f64": (_ci, [_vp, _i64, _vp, _ci, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pmt_affvec_combine_f64": (_ci, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _i64, _vp, _vp]),
+    "pmt_affvec_scale_f64": (_ci, [_i64, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _vp]),
+    "pmt_matvecmul_affs_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pmt_vecdot_numbers_vars_f64": (_ci, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "pmt_vecdot_numbers_affs_f64": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "pmt_quad_expand_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_quad_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_vecdot_terms_f64": (_ci, [_i64, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_vecdot_affs_vars_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
+    "pmt_pack_scalar_affine_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),
+    "pmt_pack_scalar_quadratic_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),
+    "pmt_pack_vector_affine_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "pmt_consts_f64": (_ci, [_vp, _i64, _ci, _vp, _vp]),
+    "pmt_fill_uniform_f64": (_ci, [_vp, _i64, _u64, _f64, _vp]),
+    "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),
+    "pmt_plan_destroy": (_ci, [_vp]),
+    "pmt_plan_stream": (_vp, [_vp]),
+    "pmt_plan_alloc": (_ci, [_vp, _sz, C.POINTER(_vp)]),
+    "pmt_plan_bytes_allocated": (_sz, [_vp]),
+    "pmt_plan_upload": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_synchronize": (_ci, [_vp]),
+    "pmt_plan_begin_record": (_ci, [_vp]),
+    "pmt_plan_end_record": (_ci, [_vp]),
+    "pmt_plan_recording_stream": (_vp, [_vp]),
+    "pmt_plan_tape_length": (_i64, [_vp]),
+    "pmt_plan_update": (_ci, [_vp]),
+    "pmt_plan_instantiate_graph": (_ci, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ErrorException(
+                "libparametron_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def require_gpu():
+    n = load().pmt_device_count()
+    if n <= 0:
+        raise ErrorException("no MI355X / HIP device visible: the Parametron hot path has no CPU fallback")
+    return n
+
+
+def check(rc):
+    if rc == PMT_OK:
+        return
+    msg = load().pmt_last_error().decode("utf-8", "replace")
+    if rc == PMT_DIMENSION_MISMATCH:
+        raise DimensionMismatch(msg)
+    if rc == PMT_INVALID_ARGUMENT:
+        raise ArgumentError(msg)
+    if rc == PMT_STATE_ERROR:
+        raise ErrorException(msg)
+    if rc == PMT_OUT_OF_MEMORY:
+        raise MemoryError(msg)
+    raise HipError(msg)
+
+
+def call(name, *args):
+    """Call a status-returning entry point and raise the reference's exception type on failure."""
+    check(getattr(load(), name)(*args))

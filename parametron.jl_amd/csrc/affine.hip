@@ -1,0 +1,303 @@
+// Dense affine nodes: A*x (+|-) b  ->  Vector{AffineFunction} term block (LinearTerm AoS) or, fused with
+// the MOI copy, MOI.VectorAffineTerm AoS.  HBM-bound streaming transpose (column-major in, row-major out).
+//
+// Reference loops replaced (see include/parametron_hip.h):
+//   matvecmul!    src/functions.jl:775-798      vecadd!/vecsubtract!  src/functions.jl:751-764
+//   update!(::MOI.VectorAffineFunction, ...)    src/moi_interop.jl:64-81
+//
+// Kernel shape (gfx950): 64x64 tile per 256-thread workgroup.  Loads: each half-wave reads one column
+// segment of 64 rows as 32 x 16 B (512 B contiguous).  The tile is transposed through LDS (pitch 65
+// doubles) and written row-major; every wave store instruction covers one contiguous 1 KiB (LinearTerm)
+// or 1 KiB-chunks of the 1.5 KiB row segment (24-byte VectorAffineTerm, assembled as 16-byte chunks so
+// that all stores are global_store_dwordx4).  Algorithmic bytes: 8 read + 16 (LT) / 24 (VAT) written
+// per matrix entry.
+#include "common.h"
+
+namespace pmt {
+
+constexpr int TILE = 64;
+constexpr int PITCH = TILE + 1;
+
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u64 f2u(double x) { return (u64)__double_as_longlong(x); }
+
+template <bool NT>
+__device__ __forceinline__ void store16(u64x2 *p, u64x2 v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store8(u64 *p, u64 v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// MODE 0: LinearTerm output   MODE 1: VectorAffineTerm output
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void affine_tile_kernel(
+    const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+    const int64_t *__restrict__ xvar, const double *__restrict__ b, int sign,
+    const int64_t *__restrict__ varmap, int64_t row_offset,
+    u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out) {
+    __shared__ double tile[TILE * PITCH];
+    __shared__ u64 vmx[TILE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * TILE;
+    const int64_t r0 = (int64_t)blockIdx.y * TILE;
+    const int nr = (int)min((int64_t)TILE, rows - r0);
+    const int nc = (int)min((int64_t)TILE, cols - c0);
+    const bool full = (nr == TILE) && (nc == TILE);
+
+    // ---- load phase: column-major A tile -> LDS tile[row][col]
+    if (full && vec_in) {
+        const int cg = t >> 5;             // 0..7 : column within the group of 8
+        const int lr = (t & 31) * 2;       // row pair
+        const double *base = A + (c0 + cg) * lda + r0 + lr;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            f64x2 v = *reinterpret_cast<const f64x2 *>(base + (int64_t)it * 8 * lda);
+            const int c = it * 8 + cg;
+            tile[lr * PITCH + c] = v.x;
+            tile[(lr + 1) * PITCH + c] = v.y;
+        }
+    } else {
+        const int r = t & 63;
+        for (int c = t >> 6; c < nc; c += 4)
+            if (r < nr) tile[r * PITCH + c] = A[(c0 + c) * lda + r0 + r];
+    }
+    if (t < nc) {
+        const int64_t v = xvar[c0 + t];
+        vmx[t] = (u64)(MODE == 1 ? map_var(varmap, v) : v);
+    }
+    // constants: one column of blocks writes 0.0 (+|-) b[row]
+    if (blockIdx.x == 0 && t < nr && out_consts)
+        out_consts[r0 + t] = signed_const(b ? b[r0 + t] : 0.0, b ? sign : 0);
+    __syncthreads();
+
+    // ---- store phase
+    if (MODE == 0) {
+        // 16 B per term: one wave store = 64 terms = 1 KiB contiguous
+        if (lane < nc) {
+            const u64 var = vmx[lane];
+            for (int r = wave; r < nr; r += 4) {
+                u64x2 v;
+                v.x = f2u(tile[r * PITCH + lane]);
+                v.y = var;
+                store16<NT>(reinterpret_cast<u64x2 *>(out + ((r0 + r) * cols + c0 + lane) * 2), v);
+            }
+        }
+    } else {
+        if (full && vec_out) {
+            // rows in pairs: 3 full-wave 16-byte stores per pair (row segment = 192 qwords = 96 chunks)
+            for (int rp = wave * 2; rp < TILE; rp += 8) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    int r, chunk;
+                    if (s == 0) { r = rp; chunk = lane; }
+                    else if (s == 1) { r = rp + (lane >> 5); chunk = 64 + (lane & 31); }
+                    else { r = rp + 1; chunk = lane; }
+                    const int q0 = chunk * 2;
+                    const u64 rowidx = (u64)(row_offset + r0 + r + 1);
+                    u64 w[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = q0 + h;
+                        const int term = q / 3;
+                        const int f = q - term * 3;
+                        w[h] = (f == 0) ? rowidx : (f == 1 ? f2u(tile[r * PITCH + term]) : vmx[term]);
+                    }
+                    u64x2 v; v.x = w[0]; v.y = w[1];
+                    store16<NT>(reinterpret_cast<u64x2 *>(out + ((r0 + r) * cols + c0) * 3 + q0), v);
+                }
+            }
+        } else {
+            if (lane < nc) {
+                const u64 var = vmx[lane];
+                for (int r = wave; r < nr; r += 4) {
+                    u64 *p = out + ((r0 + r) * cols + c0 + lane) * 3;
+                    store8<NT>(p, (u64)(row_offset + r0 + r + 1));
+                    store8<NT>(p + 1, f2u(tile[r * PITCH + lane]));
+                    store8<NT>(p + 2, var);
+                }
+            }
+        }
+    }
+}
+
+// x (+|-) v for x::Vector{Variable}
+__global__ void vars_addsub_kernel(const int64_t *__restrict__ xvar, int64_t n, const double *__restrict__ v, int sign,
+                                   const int64_t *__restrict__ varmap, int64_t row_offset,
+                                   LT *__restrict__ out_lt, VAT *__restrict__ out_vat, double *__restrict__ out_consts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t var = xvar[i];
+    if (out_lt) { LT t; t.coeff = 1.0; t.var = var; out_lt[i] = t; }
+    if (out_vat) { VAT t; t.output_index = row_offset + i + 1; t.coeff = 1.0; t.var = map_var(varmap, var); out_vat[i] = t; }
+    if (out_consts) out_consts[i] = signed_const(v ? v[i] : 0.0, v ? sign : 0);
+}
+
+__global__ void consts_kernel(const double *__restrict__ d, int64_t n, int sign, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = signed_const(d[i], sign);
+}
+
+// ---- MOI copies of materialised native functions (src/moi_interop.jl:35-81)
+__global__ void pack_scalar_affine_kernel(const LT *__restrict__ in, int64_t n, const int64_t *__restrict__ varmap, LT *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LT t = in[i];
+    t.var = map_var(varmap, t.var);
+    out[i] = t;
+}
+__global__ void pack_scalar_quadratic_kernel(const QT *__restrict__ in, int64_t n, const int64_t *__restrict__ varmap, QT *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    QT t = in[i];
+    QT o;
+    o.coeff = (t.row == t.col) ? 2 * t.coeff : t.coeff;     // moi_interop.jl:58
+    o.row = map_var(varmap, t.row);
+    o.col = map_var(varmap, t.col);
+    out[i] = o;
+}
+// one wave per row (handles ragged rows through row_ptr)
+__global__ void pack_vector_affine_kernel(const LT *__restrict__ in, const int64_t *__restrict__ row_ptr, int64_t rows, int64_t row_len,
+                                          const int64_t *__restrict__ varmap, int64_t row_offset, VAT *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t beg = row_ptr ? row_ptr[row] : row * row_len;
+    const int64_t end = row_ptr ? row_ptr[row + 1] : beg + row_len;
+    for (int64_t k = beg + lane; k < end; k += 64) {
+        LT t = in[k];
+        VAT o;
+        o.output_index = row_offset + row + 1;
+        o.coeff = t.coeff;
+        o.var = map_var(varmap, t.var);
+        out[k] = o;
+    }
+}
+
+static int validate_affine(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
+                           int sign, const void *out_terms) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "affine: negative dimension");
+    PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "affine: lda < rows");
+    PMT_REQUIRE(sign >= -1 && sign <= 1, PMT_INVALID_ARGUMENT, "affine: sign must be -1, 0 or +1");
+    if (rows > 0 && cols > 0) {
+        PMT_REQUIRE(A && xvar && out_terms, PMT_INVALID_ARGUMENT, "affine: null pointer");
+    }
+    PMT_REQUIRE(sign == 0 || b || rows == 0, PMT_INVALID_ARGUMENT, "affine: sign != 0 needs b");
+    return PMT_OK;
+}
+
+static bool env_nt() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PMT_NONTEMPORAL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
+template <int MODE>
+static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                         const int64_t *varmap, int64_t row_offset, void *out_terms, double *out_consts, hipStream_t s) {
+    if (rows == 0 || cols == 0) return PMT_OK;   // cols == 0 (constants only) is handled by the callers
+    const int vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+    const int vec_out = ((reinterpret_cast<uintptr_t>(out_terms) & 15) == 0 && (cols & 1) == 0) ? 1 : 0;
+    dim3 grid((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TILE));
+    if (env_nt())
+        hipLaunchKernelGGL((affine_tile_kernel<MODE, true>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
+                           reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
+    else
+        hipLaunchKernelGGL((affine_tile_kernel<MODE, false>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
+                           reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
+    return check_launch("affine_tile_kernel");
+}
+
+}  // namespace pmt
+
+using namespace pmt;
+
+extern "C" int pmt_affine_assemble_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
+                                       int sign, pmt_linear_term *out_terms, double *out_consts, void *stream) {
+    int rc = validate_affine(A, lda, rows, cols, xvar, b, sign, out_terms);
+    if (rc) return rc;
+    if (cols == 0 && rows > 0 && out_consts)
+        return b && sign ? pmt_consts_f64(b, rows, sign, out_consts, stream)
+                         : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
+    return dispatch(stream, [=](hipStream_t s) {
+        return launch_affine<0>(A, lda, rows, cols, xvar, b, sign, nullptr, 0, out_terms, out_consts, s);
+    });
+}
+
+extern "C" int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
+                                          int sign, const int64_t *varmap, int64_t row_offset, pmt_vector_affine_term *out_terms,
+                                          double *out_consts, void *stream) {
+    int rc = validate_affine(A, lda, rows, cols, xvar, b, sign, out_terms);
+    if (rc) return rc;
+    if (cols == 0 && rows > 0 && out_consts)
+        return b && sign ? pmt_consts_f64(b, rows, sign, out_consts, stream)
+                         : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
+    return dispatch(stream, [=](hipStream_t s) {
+        return launch_affine<1>(A, lda, rows, cols, xvar, b, sign, varmap, row_offset, out_terms, out_consts, s);
+    });
+}
+
+extern "C" int pmt_vars_addsub_f64(const int64_t *xvar, int64_t n, const double *v, int sign, const int64_t *varmap, int64_t row_offset,
+                                   pmt_linear_term *out_terms_lt, pmt_vector_affine_term *out_terms_vat, double *out_consts, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vars_addsub: negative length");
+    PMT_REQUIRE(sign >= -1 && sign <= 1, PMT_INVALID_ARGUMENT, "vars_addsub: sign must be -1, 0 or +1");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(xvar, PMT_INVALID_ARGUMENT, "vars_addsub: null xvar");
+    PMT_REQUIRE(sign == 0 || v, PMT_INVALID_ARGUMENT, "vars_addsub: sign != 0 needs v");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(vars_addsub_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, xvar, n, v, sign, varmap, row_offset,
+                           out_terms_lt, out_terms_vat, out_consts);
+        return check_launch("vars_addsub_kernel");
+    });
+}
+
+extern "C" int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "consts: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(d && out, PMT_INVALID_ARGUMENT, "consts: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(consts_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d, n, sign, out);
+        return check_launch("consts_kernel");
+    });
+}
+
+extern "C" int pmt_pack_scalar_affine_f64(const pmt_linear_term *terms, int64_t n, const int64_t *varmap, pmt_linear_term *out_terms,
+                                          void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "pack_scalar_affine: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(terms && out_terms, PMT_INVALID_ARGUMENT, "pack_scalar_affine: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(pack_scalar_affine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, terms, n, varmap, out_terms);
+        return check_launch("pack_scalar_affine_kernel");
+    });
+}
+
+extern "C" int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int64_t nq, const int64_t *varmap,
+                                             pmt_quadratic_term *out_quad, void *stream) {
+    PMT_REQUIRE(nq >= 0, PMT_DIMENSION_MISMATCH, "pack_scalar_quadratic: negative length");
+    if (nq == 0) return PMT_OK;
+    PMT_REQUIRE(quad && out_quad, PMT_INVALID_ARGUMENT, "pack_scalar_quadratic: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad);
+        return check_launch("pack_scalar_quadratic_kernel");
+    });
+}
+
+extern "C" int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const int64_t *row_ptr, int64_t rows, int64_t row_len,
+                                          const int64_t *varmap, int64_t row_offset, pmt_vector_affine_term *out_terms, void *stream) {
+    PMT_REQUIRE(rows >= 0 && row_len >= 0, PMT_DIMENSION_MISMATCH, "pack_vector_affine: negative dimension");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE((terms && out_terms) || (!row_ptr && row_len == 0), PMT_INVALID_ARGUMENT, "pack_vector_affine: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(pack_vector_affine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, terms, row_ptr, rows, row_len, varmap,
+                           row_offset, out_terms);
+        return check_launch("pack_vector_affine_kernel");
+    });
+}

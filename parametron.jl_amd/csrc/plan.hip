@@ -1,0 +1,195 @@
+// Plan = device buffers + a tape of recorded launches (the native stand-in for the reference's
+// LazyExpression/FunctionWrapper evaluation loop, src/lazyexpression.jl:50-61 and
+// src/FunctionWrappersQuickFix.jl:108-126, driven by update!(m::Model) src/model.jl:132-143).
+//
+// The host (Python here, Julia in INTEGRATION.md) analyses the lazy-expression DAG once, sizes every
+// `dest` buffer (↔ dest = deepcopy(expr()), src/lazyexpression.jl:202,230,243) and issues the pmt_*_f64
+// calls with the plan's recording handle as `stream`; those calls are validated immediately and stored
+// as closures.  pmt_plan_update() replays the closures on the plan's HIP stream — no allocation, no
+// host-side term bookkeeping (the reference's @allocated == 0 contract) — or, once
+// pmt_plan_instantiate_graph() has captured them, launches one hipGraph.
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace pmt {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
+
+}  // namespace pmt
+
+struct pmt_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    bool recording = false;
+    std::vector<void *> allocations;
+    size_t bytes = 0;
+    std::vector<pmt::Launch> tape;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    char recording_tag = 0;   // &recording_tag is the recording handle
+};
+
+namespace pmt {
+
+static std::mutex g_mu;
+static std::unordered_map<void *, pmt_plan *> g_recording;   // recording handle -> plan
+
+int dispatch(void *stream, Launch launch) {
+    if (stream) {
+        pmt_plan *plan = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            auto it = g_recording.find(stream);
+            if (it != g_recording.end()) plan = it->second;
+        }
+        if (plan) {
+            if (!plan->recording) return fail(PMT_STATE_ERROR, "plan is not recording (call pmt_plan_begin_record first)");
+            plan->tape.push_back(std::move(launch));
+            return PMT_OK;
+        }
+    }
+    return launch(reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // namespace pmt
+
+using namespace pmt;
+
+extern "C" const char *pmt_last_error(void) { return g_last_error.c_str(); }
+extern "C" int pmt_version(void) { return 100; }
+extern "C" int pmt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int pmt_plan_create(int device, void *stream, pmt_plan **out) {
+    PMT_REQUIRE(out, PMT_INVALID_ARGUMENT, "plan_create: null out");
+    PMT_HIP_CHECK(hipSetDevice(device));
+    pmt_plan *p = new pmt_plan();
+    p->device = device;
+    if (stream) {
+        p->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete p; return fail(PMT_HIP_ERROR, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+        p->owns_stream = true;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_recording[&p->recording_tag] = p;
+    }
+    *out = p;
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_destroy(pmt_plan *plan) {
+    if (!plan) return PMT_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        g_recording.erase(&plan->recording_tag);
+    }
+    (void)hipSetDevice(plan->device);
+    (void)hipStreamSynchronize(plan->stream);
+    if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    for (void *p : plan->allocations) (void)hipFree(p);
+    if (plan->owns_stream) (void)hipStreamDestroy(plan->stream);
+    delete plan;
+    return PMT_OK;
+}
+
+extern "C" void *pmt_plan_stream(pmt_plan *plan) { return plan ? plan->stream : nullptr; }
+extern "C" void *pmt_plan_recording_stream(pmt_plan *plan) { return plan ? &plan->recording_tag : nullptr; }
+extern "C" size_t pmt_plan_bytes_allocated(const pmt_plan *plan) { return plan ? plan->bytes : 0; }
+extern "C" int64_t pmt_plan_tape_length(const pmt_plan *plan) { return plan ? (int64_t)plan->tape.size() : 0; }
+
+extern "C" int pmt_plan_alloc(pmt_plan *plan, size_t bytes, void **out_device_ptr) {
+    PMT_REQUIRE(plan && out_device_ptr, PMT_INVALID_ARGUMENT, "plan_alloc: null argument");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    void *p = nullptr;
+    size_t sz = bytes ? bytes : 16;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    PMT_HIP_CHECK(hipMemsetAsync(p, 0, sz, plan->stream));
+    plan->allocations.push_back(p);
+    plan->bytes += sz;
+    *out_device_ptr = p;
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_upload: null plan");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(device_dst && host_src, PMT_INVALID_ARGUMENT, "plan_upload: null pointer");
+    PMT_HIP_CHECK(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, plan->stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch: null plan");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(host_dst && device_src, PMT_INVALID_ARGUMENT, "plan_fetch: null pointer");
+    PMT_HIP_CHECK(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, plan->stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_synchronize(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_synchronize: null plan");
+    PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_begin_record(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_begin_record: null plan");
+    PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is already recording");
+    PMT_REQUIRE(!plan->graph_exec, PMT_STATE_ERROR, "plan graph already instantiated");
+    plan->recording = true;
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_end_record(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_end_record: null plan");
+    PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan is not recording");
+    plan->recording = false;
+    return PMT_OK;
+}
+
+static int replay(pmt_plan *plan, hipStream_t s) {
+    for (auto &l : plan->tape) {
+        int rc = l(s);
+        if (rc) return rc;
+    }
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_update(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_update: null plan");
+    PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");
+    if (plan->graph_exec) {
+        PMT_HIP_CHECK(hipGraphLaunch(plan->graph_exec, plan->stream));
+        return PMT_OK;
+    }
+    return replay(plan, plan->stream);
+}
+
+extern "C" int pmt_plan_instantiate_graph(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_instantiate_graph: null plan");
+    PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");
+    if (plan->graph_exec) return PMT_OK;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
+    int rc = replay(plan, plan->stream);
+    hipError_t e = hipStreamEndCapture(plan->stream, &plan->graph);
+    if (rc) { if (plan->graph) { (void)hipGraphDestroy(plan->graph); plan->graph = nullptr; } return rc; }
+    if (e != hipSuccess) return fail(PMT_HIP_ERROR, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    PMT_HIP_CHECK(hipGraphInstantiate(&plan->graph_exec, plan->graph, nullptr, nullptr, 0));
+    return PMT_OK;
+}

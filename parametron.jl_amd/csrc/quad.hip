@@ -1,0 +1,269 @@
+// Quadratic nodes, literal (uncombined) forms: every output term is one product written once.
+// Write-bound streaming kernels: 24-byte QuadraticTerm AoS output assembled as 16-byte chunks so that the
+// bulk of the stores are global_store_dwordx4 regardless of the 24-byte element size.
+//
+// Reference loops replaced (see include/parametron_hip.h):
+//   _vecdot!(::QuadraticFunction, x, y)  src/functions.jl:702-709  over  muladd! :548-576 / :537-546
+//   _vecdot! Variable/LinearTerm form    src/functions.jl:689-700
+//   bilinearmul!                         src/functions.jl:840-858
+//   update!(::MOI.ScalarQuadraticFunction, f, varmap)  src/moi_interop.jl:45-62 (fused when moi != 0)
+#include "common.h"
+
+namespace pmt {
+
+typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64 d2u(double x) { return (u64)__double_as_longlong(x); }
+
+// Cooperative write of `nterms` consecutive QuadraticTerms starting at term index `term0` of `out`
+// (viewed as an array of 8-byte words).  F(term) -> (coeff bits, row, col) is evaluated per word.
+// All lanes of the block must call this together.
+template <typename F>
+__device__ __forceinline__ void write_qt_segment(u64 *__restrict__ out, int64_t term0, int nterms, F f) {
+    const int64_t base = term0 * 3;                 // first 8-byte word of the segment
+    const int nwords = nterms * 3;
+    const int lead = (int)((reinterpret_cast<uintptr_t>(out + base) >> 3) & 1);   // 1: segment starts in the upper half of a 16-byte slot
+    if (lead && threadIdx.x == 0) out[base] = f(0, 0);
+    for (int c = threadIdx.x; lead + 2 * c < nwords; c += blockDim.x) {
+        const int q0 = lead + 2 * c;
+        const int t0 = q0 / 3, f0 = q0 - 3 * t0;
+        if (q0 + 1 < nwords) {
+            const int q1 = q0 + 1;
+            const int t1 = q1 / 3, f1 = q1 - 3 * t1;
+            u64x2 v;
+            v.x = f(t0, f0);
+            v.y = f(t1, f1);
+            *reinterpret_cast<u64x2 *>(out + base + q0) = v;
+        } else {
+            out[base + q0] = f(t0, f0);
+        }
+    }
+}
+
+// ---- literal expansion of x . y for Vector{AffineFunction} with uniform row lengths
+constexpr int QE_BT = 1024;   // y-terms staged per block
+constexpr int QE_AB = 8;      // x-terms per block
+
+__global__ __launch_bounds__(256) void quad_expand_kernel(
+    int64_t rows, const LT *__restrict__ x_terms, int64_t nx, const LT *__restrict__ y_terms, int64_t ny,
+    int moi, const int64_t *__restrict__ varmap, u64 *__restrict__ out_quad) {
+    __shared__ double yc[QE_BT];
+    __shared__ u64 yvm[QE_BT];
+    __shared__ int64_t yv[QE_BT];
+    const int64_t b0 = (int64_t)blockIdx.x * QE_BT;
+    const int bt = (int)min((int64_t)QE_BT, ny - b0);
+    const int64_t a0 = (int64_t)blockIdx.y * QE_AB;
+    for (int64_t i = blockIdx.z; i < rows; i += gridDim.z) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < bt; k += blockDim.x) {
+            const LT t = y_terms[i * ny + b0 + k];
+            yc[k] = t.coeff;
+            yv[k] = t.var;
+            yvm[k] = (u64)(moi ? map_var(varmap, t.var) : t.var);
+        }
+        __syncthreads();
+        const int64_t a1 = min(a0 + QE_AB, nx);
+        for (int64_t a = a0; a < a1; ++a) {
+            const LT xa = x_terms[i * nx + a];
+            const u64 xvm = (u64)(moi ? map_var(varmap, xa.var) : xa.var);
+            write_qt_segment(out_quad, (i * nx + a) * ny + b0, bt, [&](int term, int field) -> u64 {
+                if (field == 0) {
+                    double c = xa.coeff * yc[term];                       // functions.jl:149
+                    if (moi && xa.var == yv[term]) c = 2 * c;             // moi_interop.jl:58
+                    return d2u(c);
+                }
+                return field == 1 ? xvm : yvm[term];
+            });
+        }
+    }
+}
+
+// affine part of muladd!(dest, x::AffineFunction, y::AffineFunction): src/functions.jl:560-573
+__global__ void quad_expand_linear_kernel(int64_t rows, const LT *__restrict__ x_terms, int64_t nx, const double *__restrict__ x_consts,
+                                          const LT *__restrict__ y_terms, int64_t ny, const double *__restrict__ y_consts,
+                                          int moi, const int64_t *__restrict__ varmap, LT *__restrict__ out_lin) {
+    const int64_t w = nx + ny;
+    const int64_t total = rows * w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t i = idx / w;
+        const int64_t k = idx - i * w;
+        LT t;
+        double c;
+        if (k < nx) { t = x_terms[i * nx + k]; c = y_consts[i]; }       // xlinear[i] * yconst  (:567)
+        else { t = y_terms[i * ny + (k - nx)]; c = x_consts[i]; }       // ylinear[i] * xconst  (:571)
+        LT o;
+        o.coeff = c * t.coeff;                                           // term * c -> c * coeff (:159-160)
+        o.var = moi ? map_var(varmap, t.var) : t.var;
+        out_lin[idx] = o;
+    }
+}
+
+// out = ((0 + a0*b0) + a1*b1) + ...  strictly left to right (src/functions.jl:574 under the loop of :705-707).
+// sign_a / sign_b: 2 = use the array as is; -1/0/+1 = use 0.0 (+|-) value (constants of a fused A*x (+|-) b node).
+__global__ __launch_bounds__(256) void seq_dot_kernel(const double *__restrict__ a, int sign_a, const double *__restrict__ b, int sign_b,
+                                                      int64_t n, double *__restrict__ out) {
+    __shared__ double prod[1024];
+    double acc = 0.0;
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int cnt = (int)min((int64_t)1024, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+            const double av = sign_a == 2 ? a[base + k] : signed_const(a[base + k], sign_a);
+            const double bv = sign_b == 2 ? b[base + k] : signed_const(b[base + k], sign_b);
+            prod[k] = av * bv;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < cnt; ++k) acc = acc + prod[k];
+    }
+    if (threadIdx.x == 0) *out = acc;
+}
+
+int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(seq_dot_kernel, dim3(1), dim3(256), 0, s, a, sign_a, b, sign_b, n, out);
+    return check_launch("seq_dot_kernel");
+}
+
+// ---- bilinearmul!: one block row per x index
+__global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict__ Q, int64_t nxr, int64_t ny,
+                                                       const int64_t *__restrict__ xvar, const int64_t *__restrict__ yvar,
+                                                       int moi, const int64_t *__restrict__ varmap, u64 *__restrict__ out_quad) {
+    __shared__ double qc[QE_BT];
+    __shared__ u64 yvm[QE_BT];
+    __shared__ int64_t yv[QE_BT];
+    const int64_t b0 = (int64_t)blockIdx.x * QE_BT;
+    const int bt = (int)min((int64_t)QE_BT, ny - b0);
+    for (int k = threadIdx.x; k < bt; k += blockDim.x) {
+        const int64_t v = yvar[b0 + k];
+        yv[k] = v;
+        yvm[k] = (u64)(moi ? map_var(varmap, v) : v);
+    }
+    for (int64_t r = blockIdx.y; r < nxr; r += gridDim.y) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < bt; k += blockDim.x) qc[k] = Q[r * ny + b0 + k];   // Q[k]: column-major linear index (:853)
+        __syncthreads();
+        const int64_t xv = xvar[r];
+        const u64 xvm = (u64)(moi ? map_var(varmap, xv) : xv);
+        write_qt_segment(out_quad, r * ny + b0, bt, [&](int term, int field) -> u64 {
+            if (field == 0) {
+                double c = qc[term];
+                if (moi && xv == yv[term]) c = 2 * c;
+                return d2u(c);
+            }
+            return field == 1 ? xvm : yvm[term];
+        });
+    }
+}
+
+__global__ void vecdot_terms_kernel(int64_t n, const double *__restrict__ xc, const int64_t *__restrict__ xvar,
+                                    const double *__restrict__ yc, const int64_t *__restrict__ yvar, int moi,
+                                    const int64_t *__restrict__ varmap, QT *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = xc ? xc[i] : 1.0, b = yc ? yc[i] : 1.0;
+    double c = a * b;                                                   // functions.jl:146-149
+    const int64_t xv = xvar[i], yv = yvar[i];
+    if (moi && xv == yv) c = 2 * c;
+    QT o;
+    o.coeff = c;
+    o.row = moi ? map_var(varmap, xv) : xv;
+    o.col = moi ? map_var(varmap, yv) : yv;
+    out[i] = o;
+}
+
+__global__ void vecdot_affs_vars_kernel(int64_t rows, const LT *__restrict__ x_terms, int64_t L, const double *__restrict__ x_consts,
+                                        const int64_t *__restrict__ yvar, int moi, const int64_t *__restrict__ varmap,
+                                        QT *__restrict__ out_quad, LT *__restrict__ out_lin) {
+    const int64_t total = rows * L;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + rows; idx += stride) {
+        if (idx < total) {
+            const int64_t i = idx / L;
+            const LT t = x_terms[idx];
+            const int64_t yv = yvar[i];
+            QT o;
+            o.coeff = (moi && t.var == yv) ? 2 * t.coeff : t.coeff;      // LinearTerm * Variable (:147)
+            o.row = moi ? map_var(varmap, t.var) : t.var;
+            o.col = moi ? map_var(varmap, yv) : yv;
+            out_quad[idx] = o;
+        } else {
+            const int64_t i = idx - total;
+            LT o;
+            o.coeff = x_consts[i];                                        // x.constant[] * y (:543)
+            o.var = moi ? map_var(varmap, yvar[i]) : yvar[i];
+            out_lin[i] = o;
+        }
+    }
+}
+
+}  // namespace pmt
+
+using namespace pmt;
+
+extern "C" int pmt_quad_expand_f64(int64_t rows, const pmt_linear_term *x_terms, int64_t nx, const double *x_consts,
+                                   const pmt_linear_term *y_terms, int64_t ny, const double *y_consts, int moi, const int64_t *varmap,
+                                   pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const, void *stream) {
+    PMT_REQUIRE(rows >= 0 && nx >= 0 && ny >= 0, PMT_DIMENSION_MISMATCH, "quad_expand: negative dimension");
+    PMT_REQUIRE(out_const, PMT_INVALID_ARGUMENT, "quad_expand: null out_const");
+    if (rows > 0) {
+        PMT_REQUIRE(x_consts && y_consts, PMT_INVALID_ARGUMENT, "quad_expand: null constants");
+        PMT_REQUIRE((nx == 0 || x_terms) && (ny == 0 || y_terms), PMT_INVALID_ARGUMENT, "quad_expand: null terms");
+        PMT_REQUIRE(nx * ny == 0 || out_quad, PMT_INVALID_ARGUMENT, "quad_expand: null out_quad");
+        PMT_REQUIRE(nx + ny == 0 || out_lin, PMT_INVALID_ARGUMENT, "quad_expand: null out_lin");
+    }
+    return dispatch(stream, [=](hipStream_t s) {
+        if (rows > 0 && nx > 0 && ny > 0) {
+            dim3 grid((unsigned)cdiv(ny, QE_BT), (unsigned)cdiv(nx, QE_AB), (unsigned)std::min<int64_t>(rows, 65535));
+            hipLaunchKernelGGL(quad_expand_kernel, grid, dim3(256), 0, s, rows, x_terms, nx, y_terms, ny, moi, varmap,
+                               reinterpret_cast<u64 *>(out_quad));
+            int rc = check_launch("quad_expand_kernel");
+            if (rc) return rc;
+        }
+        if (rows > 0 && nx + ny > 0) {
+            const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * (nx + ny), 256), 256 * 8);
+            hipLaunchKernelGGL(quad_expand_linear_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, nx, x_consts, y_terms, ny, y_consts,
+                               moi, varmap, out_lin);
+            int rc = check_launch("quad_expand_linear_kernel");
+            if (rc) return rc;
+        }
+        return launch_seq_dot(x_consts, 2, y_consts, 2, rows, out_const, s);
+    });
+}
+
+extern "C" int pmt_bilinear_f64(const double *Q, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar, int moi,
+                                const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "bilinear: negative dimension");
+    if (rows == 0 || cols == 0) return PMT_OK;
+    PMT_REQUIRE(Q && xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "bilinear: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        dim3 grid((unsigned)cdiv(cols, QE_BT), (unsigned)std::min<int64_t>(rows, 65535));
+        hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, s, Q, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
+        return check_launch("bilinear_kernel");
+    });
+}
+
+extern "C" int pmt_vecdot_terms_f64(int64_t n, const double *xc, const int64_t *xvar, const double *yc, const int64_t *yvar, int moi,
+                                    const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vecdot_terms: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "vecdot_terms: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(vecdot_terms_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, xc, xvar, yc, yvar, moi, varmap, out_quad);
+        return check_launch("vecdot_terms_kernel");
+    });
+}
+
+extern "C" int pmt_vecdot_affs_vars_f64(int64_t rows, const pmt_linear_term *x_terms, int64_t L, const double *x_consts, const int64_t *yvar,
+                                        int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_linear_term *out_lin,
+                                        void *stream) {
+    PMT_REQUIRE(rows >= 0 && L >= 0, PMT_DIMENSION_MISMATCH, "vecdot_affs_vars: negative dimension");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE(x_consts && yvar && out_lin && (L == 0 || (x_terms && out_quad)), PMT_INVALID_ARGUMENT, "vecdot_affs_vars: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * L + rows, 256), 256 * 8);
+        hipLaunchKernelGGL(vecdot_affs_vars_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, L, x_consts, yvar, moi, varmap, out_quad,
+                           out_lin);
+        return check_launch("vecdot_affs_vars_kernel");
+    });
+}

@@ -1,0 +1,190 @@
+// Generic term-list nodes on materialised Vector{AffineFunction} blocks (flat LinearTerm buffer + row_ptr +
+// constants).  These cover the builders that are not on BASELINE's dense fast path; they are simple
+// coalesced streaming kernels (one wave per row, or one thread per term).
+//
+// Reference loops replaced (see include/parametron_hip.h):
+//   copyto!/add!/subtract! on AffineFunction   src/functions.jl:422-427,455,477-485 (vecadd!/vecsubtract! :751-764, vcat! :969-994)
+//   scale!/mul!/muladd!(aff, number)           src/functions.jl:895-915,578,515-523
+//   matvecmul!(y, A, x::Vector{AffineFunction}) src/functions.jl:800-822
+//   _vecdot! affine forms                      src/functions.jl:665-687
+#include "common.h"
+
+namespace pmt {
+
+int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s);
+
+__global__ __launch_bounds__(256) void affvec_combine_kernel(
+    int64_t rows,
+    const LT *__restrict__ xa, const int64_t *__restrict__ xa_ptr, int64_t xa_len, const double *__restrict__ ca,
+    const LT *__restrict__ xb, const int64_t *__restrict__ xb_ptr, int64_t xb_len, const double *__restrict__ cb, int sb,
+    LT *__restrict__ out, const int64_t *__restrict__ out_ptr, int64_t out_len, double *__restrict__ out_consts) {
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t obeg = out_ptr ? out_ptr[row] : row * out_len;
+    int64_t na = 0;
+    if (xa) {
+        const int64_t beg = xa_ptr ? xa_ptr[row] : row * xa_len;
+        na = (xa_ptr ? xa_ptr[row + 1] : beg + xa_len) - beg;
+        for (int64_t k = lane; k < na; k += 64) out[obeg + k] = xa[beg + k];
+    }
+    if (xb) {
+        const int64_t beg = xb_ptr ? xb_ptr[row] : row * xb_len;
+        const int64_t nb = (xb_ptr ? xb_ptr[row + 1] : beg + xb_len) - beg;
+        for (int64_t k = lane; k < nb; k += 64) {
+            LT t = xb[beg + k];
+            if (sb < 0) t.coeff = -t.coeff;                       // -x.linear[i]  (functions.jl:481, :158)
+            out[obeg + na + k] = t;
+        }
+    }
+    if (lane == 0 && out_consts) {
+        double c = ca ? ca[row] : 0.0;                            // copyto! :425 / :419 / zero! :244
+        if (cb) c = sb < 0 ? c - cb[row] : c + cb[row];           // :483 / :455 / :452 / :474
+        out_consts[row] = c;
+    }
+}
+
+__global__ void affvec_scale_kernel(int64_t rows, int64_t nterms, const LT *__restrict__ y, const double *__restrict__ yc,
+                                    const double *__restrict__ s_dev, double s_host, LT *__restrict__ out, double *__restrict__ out_consts) {
+    const double s = s_dev ? *s_dev : s_host;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nterms + rows; i += stride) {
+        if (i < nterms) {
+            LT t = y[i];
+            t.coeff = s * t.coeff;                                // x.linear[i] * y -> y * coeff (functions.jl:519, :159-160)
+            out[i] = t;
+        } else {
+            const int64_t r = i - nterms;
+            out_consts[r] = 0.0 + yc[r] * s;                      // zero! then dest.constant += x.constant * y (:521)
+        }
+    }
+}
+
+__global__ void matvecmul_affs_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                      const LT *__restrict__ x, int64_t L, LT *__restrict__ out) {
+    const int64_t per_row = cols * L;
+    const int64_t total = rows * per_row;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t row = idx / per_row;
+        const int64_t rem = idx - row * per_row;
+        const int64_t col = rem / L;
+        LT t = x[rem];                                             // x[col].linear[k], rem == col*L + k
+        t.coeff = A[col * lda + row] * t.coeff;                    // muladd!(y[row], A[i], x[col]) (:817 -> :519)
+        out[idx] = t;
+    }
+}
+// const[row] = ((0 + xc[0]*A[row,0]) + xc[1]*A[row,1]) + ...   (functions.jl:521 in column order :815-820)
+__global__ void matvecmul_affs_consts_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                             const double *__restrict__ xc, double *__restrict__ out_consts) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double acc = 0.0;
+    for (int64_t col = 0; col < cols; ++col) {
+        const double p = xc[col] * A[col * lda + row];
+        acc = acc + p;
+    }
+    out_consts[row] = acc;
+}
+
+__global__ void vecdot_numbers_vars_kernel(const double *__restrict__ v, const int64_t *__restrict__ xvar, int64_t n,
+                                           LT *__restrict__ out, double *__restrict__ out_const) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && out_const) *out_const = 0.0;
+    if (i >= n) return;
+    LT t; t.coeff = v[i]; t.var = xvar[i];                         // x[i] * y[i] (functions.jl:684, :120)
+    out[i] = t;
+}
+
+__global__ void vecdot_numbers_affs_kernel(const double *__restrict__ v, int64_t n, const LT *__restrict__ x, int64_t L,
+                                           LT *__restrict__ out) {
+    const int64_t total = n * L;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t i = idx / L;
+        LT t = x[idx];
+        t.coeff = v[i] * t.coeff;                                  // muladd!(dest, x::Number, y::Aff) (:524 -> :519)
+        out[idx] = t;
+    }
+}
+
+}  // namespace pmt
+
+using namespace pmt;
+
+extern "C" int pmt_affvec_combine_f64(int64_t rows, const pmt_linear_term *xa_terms, const int64_t *xa_row_ptr, int64_t xa_row_len,
+                                      const double *xa_consts, const pmt_linear_term *xb_terms, const int64_t *xb_row_ptr,
+                                      int64_t xb_row_len, const double *xb_consts, int sb, pmt_linear_term *out_terms,
+                                      const int64_t *out_row_ptr, int64_t out_row_len, double *out_consts, void *stream) {
+    PMT_REQUIRE(rows >= 0 && xa_row_len >= 0 && xb_row_len >= 0 && out_row_len >= 0, PMT_DIMENSION_MISMATCH, "affvec_combine: negative dimension");
+    PMT_REQUIRE(sb == 1 || sb == -1, PMT_INVALID_ARGUMENT, "affvec_combine: sb must be +1 or -1");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE(out_consts, PMT_INVALID_ARGUMENT, "affvec_combine: null out_consts");
+    if (!xa_row_ptr && !xb_row_ptr && !out_row_ptr)
+        PMT_REQUIRE((xa_terms ? xa_row_len : 0) + (xb_terms ? xb_row_len : 0) == out_row_len, PMT_DIMENSION_MISMATCH,
+                    "affvec_combine: out_row_len != len(a) + len(b)");
+    PMT_REQUIRE(out_terms || out_row_len == 0, PMT_INVALID_ARGUMENT, "affvec_combine: null out_terms");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(affvec_combine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, rows, xa_terms, xa_row_ptr, xa_row_len,
+                           xa_consts, xb_terms, xb_row_ptr, xb_row_len, xb_consts, sb, out_terms, out_row_ptr, out_row_len, out_consts);
+        return check_launch("affvec_combine_kernel");
+    });
+}
+
+extern "C" int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_linear_term *y_terms, const double *y_consts, const double *s_dev,
+                                    double s_host, pmt_linear_term *out_terms, double *out_consts, void *stream) {
+    PMT_REQUIRE(rows >= 0 && nterms >= 0, PMT_DIMENSION_MISMATCH, "affvec_scale: negative dimension");
+    if (rows == 0 && nterms == 0) return PMT_OK;
+    PMT_REQUIRE((nterms == 0 || (y_terms && out_terms)) && (rows == 0 || (y_consts && out_consts)), PMT_INVALID_ARGUMENT, "affvec_scale: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(nterms + rows, 256), 256 * 8);
+        hipLaunchKernelGGL(affvec_scale_kernel, dim3(blocks), dim3(256), 0, s, rows, nterms, y_terms, y_consts, s_dev, s_host, out_terms, out_consts);
+        return check_launch("affvec_scale_kernel");
+    });
+}
+
+extern "C" int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const pmt_linear_term *x_terms,
+                                      int64_t x_row_len, const double *x_consts, pmt_linear_term *out_terms, double *out_consts,
+                                      void *stream) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0 && x_row_len >= 0, PMT_DIMENSION_MISMATCH, "matvecmul_affs: negative dimension");
+    PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "matvecmul_affs: lda < rows");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE(out_consts && (cols == 0 || (A && x_consts)), PMT_INVALID_ARGUMENT, "matvecmul_affs: null pointer");
+    PMT_REQUIRE(cols * x_row_len == 0 || (x_terms && out_terms), PMT_INVALID_ARGUMENT, "matvecmul_affs: null terms");
+    return dispatch(stream, [=](hipStream_t s) {
+        if (cols * x_row_len > 0) {
+            const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cols * x_row_len, 256), 256 * 16);
+            hipLaunchKernelGGL(matvecmul_affs_kernel, dim3(blocks), dim3(256), 0, s, A, lda, rows, cols, x_terms, x_row_len, out_terms);
+            int rc = check_launch("matvecmul_affs_kernel");
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(matvecmul_affs_consts_kernel, dim3((unsigned)cdiv(rows, 64)), dim3(64), 0, s, A, lda, rows, cols, x_consts, out_consts);
+        return check_launch("matvecmul_affs_consts_kernel");
+    });
+}
+
+extern "C" int pmt_vecdot_numbers_vars_f64(const double *v, const int64_t *xvar, int64_t n, pmt_linear_term *out_terms, double *out_const,
+                                           void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vecdot_numbers_vars: negative length");
+    PMT_REQUIRE(out_const && (n == 0 || (v && xvar && out_terms)), PMT_INVALID_ARGUMENT, "vecdot_numbers_vars: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        hipLaunchKernelGGL(vecdot_numbers_vars_kernel, dim3((unsigned)std::max<int64_t>(1, cdiv(n, 256))), dim3(256), 0, s, v, xvar, n, out_terms, out_const);
+        return check_launch("vecdot_numbers_vars_kernel");
+    });
+}
+
+extern "C" int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n, const pmt_linear_term *x_terms, int64_t x_row_len, const double *x_consts,
+                                           pmt_linear_term *out_terms, double *out_const, void *stream) {
+    PMT_REQUIRE(n >= 0 && x_row_len >= 0, PMT_DIMENSION_MISMATCH, "vecdot_numbers_affs: negative dimension");
+    PMT_REQUIRE(out_const && (n == 0 || (v && x_consts)), PMT_INVALID_ARGUMENT, "vecdot_numbers_affs: null pointer");
+    PMT_REQUIRE(n * x_row_len == 0 || (x_terms && out_terms), PMT_INVALID_ARGUMENT, "vecdot_numbers_affs: null terms");
+    return dispatch(stream, [=](hipStream_t s) {
+        if (n * x_row_len > 0) {
+            const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n * x_row_len, 256), 256 * 8);
+            hipLaunchKernelGGL(vecdot_numbers_affs_kernel, dim3(blocks), dim3(256), 0, s, v, n, x_terms, x_row_len, out_terms);
+            int rc = check_launch("vecdot_numbers_affs_kernel");
+            if (rc) return rc;
+        }
+        return launch_seq_dot(x_consts, 2, v, 2, n, out_const, s);   // dest.constant += x.constant * y (functions.jl:521)
+    });
+}

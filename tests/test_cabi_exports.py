@@ -1,0 +1,63 @@
+"""CPU-only: the C-ABI library builds, loads, and exports every symbol include/parametron_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    entry.build()
+    from parametron_jl_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "parametron_hip.h")).read()
+    declared = set(re.findall(r"\b(pmt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    raw = C.CDLL(lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "symbol %s missing from libparametron_hip.so" % name
+        assert name in lib.SIGNATURES, "symbol %s has no ctypes signature" % name
+    assert set(lib.SIGNATURES) <= declared
+
+
+def test_term_layouts_match_julia_isbits(lib):
+    assert lib.LT.itemsize == 16 and lib.QT.itemsize == 24 and lib.VAT.itemsize == 24
+    assert lib.VAT.names == ("out", "coeff", "var")
+    assert lib.load().pmt_version() >= 100
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    # validation happens before any launch, so error mapping can be checked on a CPU-only box
+    L = lib.load()
+    with pytest.raises(lib.DimensionMismatch):
+        lib.call("pmt_affine_assemble_f64", None, 1, 2, 2, None, None, 0, None, None, None)      # lda < rows
+    with pytest.raises(lib.ArgumentError):
+        lib.call("pmt_affine_assemble_f64", None, 2, 2, 2, None, None, 5, None, None, None)      # bad sign
+    with pytest.raises(lib.DimensionMismatch):
+        lib.call("pmt_quad_expand_f64", -1, None, 0, None, None, 0, None, 0, None, None, None, None, None)
+    assert b"" != L.pmt_last_error()
+
+
+def test_product_path_fails_loudly_without_gpu(lib):
+    if lib.load().pmt_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(lib.ErrorException):
+        lib.require_gpu()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "parametron.jl_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|libparametron_oracle|pmo_[a-z_]+\s*\(", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not bad.search(src), "product source %s references the oracle" % os.path.join(dirpath, f)
