@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""bench.py — QP re-evaluations/s of the Parametron hot path on MI355X.
+
+A "step" is one update!(model) (src/model.jl:132-143) of BASELINE config 2 — dense least-squares QP, n = 4096
+variables, A 4096x4096, b 4096, C 512x4096, d 512, fp64 — i.e. one rebuild of every MOI coefficient buffer
+(Q, q, constant, constraint triplets, constraint constants) from the Parameter values resident in HBM:
+    objective   residual . residual, residual = A*x - b   -> canonical MOI.ScalarQuadraticFunction (pmt_quad_gram_f64)
+    constraint  C*x - d in Zeros(m)                       -> MOI.VectorAffineFunction       (pmt_affine_pack_vector_f64)
+The literal (uncombined) objective the reference would emit is 1.65 TB at this size; the canonical
+form = canonicalize!(literal) is what is rebuilt here, see DESIGN.md.
+
+python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+N > 1 runs N independent QP instances (one per GPU, no data-path collective): weak scaling.
+--workload batch runs BASELINE config 4 instead (8192 x n=128 QPs sharded by instance + RCCL all-gather of the
+coefficient slabs).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# f64 MFMA: the local guides list no peak.  AMD's datasheet figure for MI355X FP64 matrix is 78.6 TFLOP/s;
+# tools/mfma_f64_peak.hip measures the sustained v_mfma_f64_16x16x4_f64 issue rate on the box.
+F64_MFMA_PEAK_TFLOPS = 78.6
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="c2", choices=["c2", "batch"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (no per-kernel events)")
+    return p.parse_args()
+
+
+def dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def profile_report(_lib):
+    L = _lib.load()
+    n = L.pmt_profile_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    L.pmt_profile_report(buf, int(n) + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, tot, mn, mx = line.split("\t")
+        out[name] = {"launches": int(cnt), "avg_ms": float(tot) / max(1, int(cnt)), "min_ms": float(mn), "max_ms": float(mx)}
+    return out
+
+
+class C2Workload:
+    """BASELINE config 2: n = r = 4096, m = 512."""
+
+    n, r, m = 4096, 4096, 512
+
+    def __init__(self, torch, _lib, rank):
+        self.torch, self._lib = torch, _lib
+        n, r, m = self.n, self.r, self.m
+        dev = torch.device("cuda", torch.cuda.current_device())
+        f64, i64 = torch.float64, torch.int64
+        self.A = torch.empty(r * n, dtype=f64, device=dev)
+        self.b = torch.empty(r, dtype=f64, device=dev)
+        self.Cm = torch.empty(m * n, dtype=f64, device=dev)
+        self.d = torch.empty(m, dtype=f64, device=dev)
+        self.xvar = torch.arange(1, n + 1, dtype=i64, device=dev)
+        self.varmap = torch.arange(1, n + 1, dtype=i64, device=dev)            # model_var_to_optimizer (src/model.jl:100-107)
+        self.nq = n * (n + 1) // 2
+        self.Q = torch.empty(self.nq * 3, dtype=i64, device=dev)               # MOI.ScalarQuadraticTerm[]
+        self.q = torch.empty(n * 2, dtype=i64, device=dev)                     # MOI.ScalarAffineTerm[]
+        self.const = torch.empty(1, dtype=f64, device=dev)
+        self.Ct = torch.empty(m * n * 3, dtype=i64, device=dev)                # MOI.VectorAffineTerm[]
+        self.Cc = torch.empty(m, dtype=f64, device=dev)
+        ws_bytes = _lib.load().pmt_quad_gram_workspace_bytes(r, n)
+        self.ws = torch.empty(max(1, ws_bytes // 8), dtype=f64, device=dev)
+        self.stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # device-side Parameter callbacks (README.md:36-43 rand!): seeds A:1 b:2 C:3 d:4, distinct per instance
+        s = 1000 * rank
+        _lib.call("pmt_fill_uniform_f64", dptr(self.A), r * n, 1 + s, 1.0, self.stream)
+        _lib.call("pmt_fill_uniform_f64", dptr(self.b), r, 2 + s, 1.0, self.stream)
+        _lib.call("pmt_fill_uniform_f64", dptr(self.Cm), m * n, 3 + s, 1.0, self.stream)
+        _lib.call("pmt_fill_uniform_f64", dptr(self.d), m, 4 + s, 2.0, self.stream)
+        self.plan = C.c_void_p()
+        _lib.call("pmt_plan_create", torch.cuda.current_device(), self.stream, C.byref(self.plan))
+        rec = C.c_void_p(_lib.load().pmt_plan_recording_stream(self.plan))
+        _lib.call("pmt_plan_begin_record", self.plan)
+        _lib.call("pmt_quad_gram_f64", dptr(self.A), r, r, n, dptr(self.xvar), dptr(self.b), -1, 1, dptr(self.varmap),
+                  dptr(self.Q), dptr(self.q), dptr(self.const), dptr(self.ws), rec)
+        _lib.call("pmt_affine_pack_vector_f64", dptr(self.Cm), m, m, n, dptr(self.xvar), dptr(self.d), -1, dptr(self.varmap), 0,
+                  dptr(self.Ct), dptr(self.Cc), rec)
+        _lib.call("pmt_plan_end_record", self.plan)
+
+    def step(self):
+        self._lib.call("pmt_plan_update", self.plan)
+
+    name = "C2 dense least-squares QP: n=4096 vars, A 4096x4096, m=512 equality rows, fp64; canonical Q,q,const + C,d MOI triplets"
+    units_per_step = 1
+
+    # algorithmic work of the dominant kernel per launch
+    def gram_flops(self):
+        return float(self.r) * self.n * (self.n + 1)
+
+    def step_bytes(self):
+        n, r, m = self.n, self.r, self.m
+        return 8.0 * (r * n + r + m * n + m) + 24.0 * self.nq + 16.0 * n + 8 + 24.0 * m * n + 8.0 * m
+
+
+def affine_microbench(torch, _lib, wl, reps=20):
+    """The affine-assembly kernel on the 4096x4096 residual block (matvecmul! + vecsubtract!, LinearTerm output):
+    24*r*n algorithmic bytes per launch (8 read + 16 written), north_star's >= 60 % HBM target."""
+    n, r = wl.n, wl.r
+    out = torch.empty(r * n * 2, dtype=torch.int64, device=wl.A.device)
+    consts = torch.empty(r, dtype=torch.float64, device=wl.A.device)
+    for _ in range(3):
+        _lib.call("pmt_affine_assemble_f64", dptr(wl.A), r, r, n, dptr(wl.xvar), dptr(wl.b), -1, dptr(out), dptr(consts), wl.stream)
+    torch.cuda.synchronize()
+    _lib.call("pmt_profile_enable", 1)
+    for _ in range(reps):
+        _lib.call("pmt_affine_assemble_f64", dptr(wl.A), r, r, n, dptr(wl.xvar), dptr(wl.b), -1, dptr(out), dptr(consts), wl.stream)
+    torch.cuda.synchronize()
+    rep = profile_report(_lib)
+    _lib.call("pmt_profile_enable", 0)
+    k = rep.get("affine_tile_kernel<LT>")
+    if not k:
+        return None
+    nbytes = 24.0 * r * n
+    gbs = nbytes / (k["avg_ms"] * 1e-3) / 1e9
+    return {"kernel": "affine_tile_kernel<LT>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_ms": k["avg_ms"], "algorithmic_bytes": nbytes,
+            "shape": "A 4096x4096 -> 16.8M LinearTerms"}
+
+
+def cpu_baseline(wl):
+    """The reference's literal CPU path restated in C (oracle/, single thread like the reference), timed on this box's
+    host cores on a bounded sample of config 2: all affine nodes and the constraint MOI copy at full size; the
+    literal quadratic expansion + MOI copy on `rows` of the 4096 residual rows, extrapolated linearly (every row
+    costs the same n^2 terms; the full literal output would be 1.65 TB)."""
+    import numpy as np
+    from oracle import oracle as O
+    n, r, m = wl.n, wl.r, wl.m
+    A = O.fill_uniform(r * n, 1)
+    b = O.fill_uniform(r, 2)
+    Cm = O.fill_uniform(m * n, 3)
+    d = O.fill_uniform(m, 4, 2.0)
+    xvar = np.arange(1, n + 1, dtype=np.int64)
+    w = O.LsqWorkspace(n, r, m)
+    rows = 2
+
+    def affine_part():
+        w.eval_residual(A, b, xvar)
+        w.eval_residual(A, b, xvar)          # the reference evaluates `residual` twice (no memoisation, lazyexpression.jl:53-61)
+        w.eval_constraint(Cm, d, xvar)
+        return w.constraint.moi(xvar)
+
+    def quad_part():
+        w.eval_vecdot(rows)
+        return w.objective.moi(xvar)
+
+    affine_part(); quad_part()               # first touch: the reference's first solve! allocates, later ones do not
+    t0 = time.perf_counter(); affine_part(); t_aff = time.perf_counter() - t0
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        quad_part()
+    t_quad = (time.perf_counter() - t0) / reps
+    total = t_aff + t_quad * (r / rows)
+    return {"value": 1.0 / total, "unit": "re-evaluations/s", "cores": 1, "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": "C restatement of the reference loops (oracle/), 1 thread: matvecmul!+vecsubtract! x2, constraint C*x-d and its MOI "
+                      "copy at full size (%.3f s); literal _vecdot!/muladd! expansion + MOI copy on %d of %d residual rows (%.3f s), "
+                      "extrapolated x%d — the full literal objective is 1.65 TB and cannot be materialised" % (t_aff, rows, r, t_quad, r // rows),
+            "seconds_per_reevaluation_extrapolated": total}
+
+
+def run_batch(args, torch, dist, _lib, rank, world):
+    from parametron_jl_amd import batch
+    return batch.bench(args, torch, dist, _lib, rank, world)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import parametron_jl_amd  # noqa: F401
+    from parametron_jl_amd import _lib
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.workload == "batch":
+        return run_batch(args, torch, dist, _lib, rank, world)
+
+    wl = C2Workload(torch, _lib, rank)
+    if args.graph:
+        _lib.call("pmt_plan_instantiate_graph", wl.plan)
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.call("pmt_profile_enable", 0 if args.graph else 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernels = profile_report(_lib) if not args.graph else {}
+    _lib.call("pmt_profile_enable", 0)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * wl.units_per_step * args.steps / elapsed
+
+    if rank == 0:
+        out = {
+            "metric": "QP re-evaluations/sec (Q,q,C,d rebuild) at n=4096",
+            "value": value, "unit": "re-evaluations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl.name, "n": wl.n, "r": wl.r, "m": wl.m, "objective_mode": "canonical",
+                       "instances_per_gpu": 1, "parallelism": "replicas (independent QP instances, no collective)" if world > 1 else "single GPU",
+                       "replay": "hipGraph" if args.graph else "tape"},
+            "step_algorithmic_bytes": wl.step_bytes(), "step_flops": wl.gram_flops(),
+        }
+        g = kernels.get("quad_gram_kernel")
+        if g:
+            tf = wl.gram_flops() / (g["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "quad_gram_kernel", "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "avg_ms": g["avg_ms"], "algorithmic_flops": wl.gram_flops(),
+                               "peak_source": "MI355X datasheet FP64 matrix 78.6 TFLOP/s (not in the local guides); see DESIGN.md"}
+        else:
+            out["roofline"] = None
+        v = kernels.get("affine_tile_kernel<VAT>")
+        if v:
+            nb = 32.0 * wl.m * wl.n
+            out["roofline_constraint_pack"] = {"kernel": "affine_tile_kernel<VAT>", "bound": "hbm", "achieved": nb / (v["avg_ms"] * 1e-3) / 1e9,
+                                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "avg_ms": v["avg_ms"], "algorithmic_bytes": nb}
+        out["kernels"] = kernels
+        if world == 1:
+            out["roofline_affine"] = affine_microbench(torch, _lib, wl)
+            out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -209,6 +209,15 @@ int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stre
 int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Per-kernel timing report — the device analogue of `findallocs` (src/debug.jl:4-23), which walks the DAG and
+ * reports a cost per node.  While enabled, every launch is bracketed by HIP events on its own stream (never inside
+ * a hipGraph capture).  pmt_profile_report synchronises on the recorded events and writes one line per kernel:
+ * "<kernel>\t<launches>\t<total_ms>\t<min_ms>\t<max_ms>\n"; returns the untruncated length.
+ * ------------------------------------------------------------------------------------- */
+int pmt_profile_enable(int on);
+int64_t pmt_profile_report(char *host_buf, size_t cap);
+
+/* ---------------------------------------------------------------------------------------
  * Plan = a recorded re-evaluation: device buffers + a tape of the launches above.
  * Built once by the host from the lazy-expression DAG (↔ `dest = deepcopy(expr())` pre-allocation,
  * src/lazyexpression.jl:202,230,243), replayed by every update!(model) (src/model.jl:132-143) with no

@@ -100,6 +100,7 @@ def lib():
             "pmo_lsq_eval_residual": (ci, [vp, vp, vp, vp]),
             "pmo_lsq_eval_constraint": (ci, [vp, vp, vp, vp]),
             "pmo_lsq_eval_objective": (ci, [vp, vp, vp, vp, ci, i64]),
+            "pmo_lsq_eval_vecdot": (ci, [vp, i64]),
             "pmo_fill_uniform": (None, [vp, i64, C.c_uint64, f64]),
         }
         for name, (res, args) in sig.items():
@@ -462,6 +463,10 @@ class LsqWorkspace:
 
     def eval_objective(self, A_colmajor, b, xvar, twice=True, rows_limit=-1):
         _check(lib().pmo_lsq_eval_objective(self.h, _ptr(A_colmajor), _ptr(b), _ptr(xvar), 1 if twice else 0, rows_limit))
+
+
+    def eval_vecdot(self, rows_limit=-1):
+        _check(lib().pmo_lsq_eval_vecdot(self.h, rows_limit))
 
 
 class _BorrowedQuad(Quad):

@@ -610,6 +610,12 @@ int pmo_lsq_eval_objective(pmo_lsq_workspace *w, const double *A, const double *
     return pmo_vecdot_quad_affs_affs(w->objective, w->residual, rows, w->residual, rows);
 }
 
+/* only the vecdot! node (HOT LOOP 3) on the already evaluated residual — lets bench.py time the nodes separately */
+int pmo_lsq_eval_vecdot(pmo_lsq_workspace *w, int64_t rows_limit) {
+    int64_t rows = (rows_limit < 0 || rows_limit > w->r) ? w->r : rows_limit;
+    return pmo_vecdot_quad_affs_affs(w->objective, w->residual, rows, w->residual, rows);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* synthetic inputs: counter-based RNG shared (bit-for-bit) with the device fill kernel
  * (SURVEY §8d): u = splitmix64(seed * 0x9E3779B97F4A7C15 + index) >> 11 * 2^-53 in [0,1) */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "pmt_consts_f64": (_ci, [_vp, _i64, _ci, _vp, _vp]),
     "pmt_fill_uniform_f64": (_ci, [_vp, _i64, _u64, _f64, _vp]),
+    "pmt_profile_enable": (_ci, [_ci]),
+    "pmt_profile_report": (_i64, [C.c_char_p, _sz]),
     "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),
     "pmt_plan_destroy": (_ci, [_vp]),
     "pmt_plan_stream": (_vp, [_vp]),
@@ -89,6 +91,15 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ErrorException(
                 "libparametron_hip.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever copy is loaded
+        # first serves the whole process, and torch cannot initialise on top of the system copy ("No HIP GPUs are
+        # available").  Hosts that use torch for device memory / streams / torch.distributed must therefore have
+        # torch loaded BEFORE this library; a torch-free host (the Julia binding) uses /opt/rocm's runtime.
+        if os.environ.get("PMT_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

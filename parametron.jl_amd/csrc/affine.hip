@@ -207,10 +207,10 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
     const int vec_out = ((reinterpret_cast<uintptr_t>(out_terms) & 15) == 0 && (cols & 1) == 0) ? 1 : 0;
     dim3 grid((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TILE));
     if (env_nt())
-        hipLaunchKernelGGL((affine_tile_kernel<MODE, true>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
+        PMT_LAUNCH_NAMED(MODE == 0 ? "affine_tile_kernel<LT>" : "affine_tile_kernel<VAT>", (affine_tile_kernel<MODE, true>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
                            reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
     else
-        hipLaunchKernelGGL((affine_tile_kernel<MODE, false>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
+        PMT_LAUNCH_NAMED(MODE == 0 ? "affine_tile_kernel<LT>" : "affine_tile_kernel<VAT>", (affine_tile_kernel<MODE, false>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
                            reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
     return check_launch("affine_tile_kernel");
 }
@@ -252,7 +252,7 @@ extern "C" int pmt_vars_addsub_f64(const int64_t *xvar, int64_t n, const double 
     PMT_REQUIRE(xvar, PMT_INVALID_ARGUMENT, "vars_addsub: null xvar");
     PMT_REQUIRE(sign == 0 || v, PMT_INVALID_ARGUMENT, "vars_addsub: sign != 0 needs v");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(vars_addsub_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, xvar, n, v, sign, varmap, row_offset,
+        PMT_LAUNCH(vars_addsub_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, xvar, n, v, sign, varmap, row_offset,
                            out_terms_lt, out_terms_vat, out_consts);
         return check_launch("vars_addsub_kernel");
     });
@@ -263,7 +263,7 @@ extern "C" int pmt_consts_f64(const double *d, int64_t n, int sign, double *out,
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(d && out, PMT_INVALID_ARGUMENT, "consts: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(consts_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d, n, sign, out);
+        PMT_LAUNCH(consts_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d, n, sign, out);
         return check_launch("consts_kernel");
     });
 }
@@ -274,7 +274,7 @@ extern "C" int pmt_pack_scalar_affine_f64(const pmt_linear_term *terms, int64_t 
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(terms && out_terms, PMT_INVALID_ARGUMENT, "pack_scalar_affine: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(pack_scalar_affine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, terms, n, varmap, out_terms);
+        PMT_LAUNCH(pack_scalar_affine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, terms, n, varmap, out_terms);
         return check_launch("pack_scalar_affine_kernel");
     });
 }
@@ -285,7 +285,7 @@ extern "C" int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int
     if (nq == 0) return PMT_OK;
     PMT_REQUIRE(quad && out_quad, PMT_INVALID_ARGUMENT, "pack_scalar_quadratic: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad);
+        PMT_LAUNCH(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad);
         return check_launch("pack_scalar_quadratic_kernel");
     });
 }
@@ -296,7 +296,7 @@ extern "C" int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const in
     if (rows == 0) return PMT_OK;
     PMT_REQUIRE((terms && out_terms) || (!row_ptr && row_len == 0), PMT_INVALID_ARGUMENT, "pack_vector_affine: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(pack_vector_affine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, terms, row_ptr, rows, row_len, varmap,
+        PMT_LAUNCH(pack_vector_affine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, terms, row_ptr, rows, row_len, varmap,
                            row_offset, out_terms);
         return check_launch("pack_vector_affine_kernel");
     });

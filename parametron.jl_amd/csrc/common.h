@@ -35,6 +35,20 @@ int fail(int code, const std::string &msg);
 using Launch = std::function<int(hipStream_t)>;
 int dispatch(void *stream, Launch launch);
 
+// Per-kernel timing (the analogue of the reference's per-node `findallocs` report, src/debug.jl:4-23): when enabled
+// through pmt_profile_enable(), every launch is bracketed by HIP events on its own stream.
+struct ProfScope {
+    ProfScope(const char *name, hipStream_t s);
+    ~ProfScope();
+    const char *name_; hipStream_t s_; hipEvent_t e0_ = nullptr, e1_ = nullptr;
+};
+#define PMT_LAUNCH_NAMED(name, kernel, grid, block, shmem, s, ...)          \
+    do {                                                                    \
+        ::pmt::ProfScope _prof(name, s);                                    \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, s, __VA_ARGS__);     \
+    } while (0)
+#define PMT_LAUNCH(kernel, grid, block, shmem, s, ...) PMT_LAUNCH_NAMED(#kernel, kernel, grid, block, shmem, s, __VA_ARGS__)
+
 inline int check_launch(const char *name) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PMT_HIP_ERROR, std::string(name) + ": " + hipGetErrorString(e));

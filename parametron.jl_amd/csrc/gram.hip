@@ -75,7 +75,18 @@ __device__ __forceinline__ void store_panel(double *panel, const f64x2 (&reg)[4]
     }
 }
 
-__global__ __launch_bounds__(256, 2) void quad_gram_kernel(GramArgs g) {
+// M4 = true : v_mfma_f64_4x4x4_4b_f64 (4 independent 4x4x4 blocks per instruction).  Measured on MI355X
+//             (tools/mfma_f64_peak.hip): 17 cycles/instruction = 72.5 TFLOP/s, i.e. the datasheet FP64-matrix
+//             rate, whereas v_mfma_f64_16x16x4_f64 issues every 138 cycles = 34.9 TFLOP/s.  The hardware
+//             ignores cbsz/abid on f64 MFMA (tools/mfma_probe2.hip), so the 16 (row group, column group) pairs
+//             of a 16x16 tile are covered by 4 instructions whose B operand is read from LDS with the column
+//             groups rotated by s = 0..3 blocks.  Operand lane maps (tools/mfma_probe.hip):
+//               A: lane = i + 4b + 16k   B: lane = j + 4b + 16k   D: lane = j + 4b + 16i   (block b, 4x4 tile)
+//             so A/B registers are those of the 16x16x4 form (row|col = lane & 15, k = lane >> 4) and
+//             acc[tm][tn][s] of lane l holds C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
+// M4 = false: v_mfma_f64_16x16x4_f64, acc[tm][tn][v] = C[16tm + (l>>4) + 4v][16tn + (l&15)].
+template <bool M4>
+__global__ __launch_bounds__(256, M4 ? 1 : 2) void quad_gram_kernel(GramArgs g) {
     __shared__ double lds[2][2][GT * GP];   // [buffer][panel J/K][col*GP + k]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -112,20 +123,38 @@ __global__ __launch_bounds__(256, 2) void quad_gram_kernel(GramArgs g) {
             if (!diag) load_panel(g, k0, (int64_t)(s + 1) * BK, rk, tid);
         }
         const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
-        const double *pk = lds[cur][diag ? 0 : 1] + (wc * 64 + lm) * GP + lk;
+        const double *pkbase = lds[cur][diag ? 0 : 1] + (wc * 64) * GP + lk;
+        const double *pk = pkbase + lm * GP;
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            double a[4], b[4];
+            double a[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = pj[t * 16 * GP + ks * 4];
-                b[t] = pk[t * 16 * GP + ks * 4];
+            for (int t = 0; t < 4; ++t) a[t] = pj[t * 16 * GP + ks * 4];
+            if (M4) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    double b[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int rc = ((((lm >> 2) + s) & 3) << 2) | (lm & 3);        // column group rotated by s blocks
+                        b[s] = pkbase[(tn * 16 + rc) * GP + ks * 4];
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[tm][tn][s] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[s], acc[tm][tn][s], 0, 0, 0);
+                }
+            } else {
+                double b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = pk[t * 16 * GP + ks * 4];
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
             }
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
         }
         if (s + 1 < nstage) {
             store_panel(lds[cur ^ 1][0], rj, tid);
@@ -139,16 +168,22 @@ __global__ __launch_bounds__(256, 2) void quad_gram_kernel(GramArgs g) {
     u64 *out = reinterpret_cast<u64 *>(g.out_quad);
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
-        const int64_t k = k0 + wc * 64 + tn * 16 + lm;
-        if (k >= n) continue;
-        const int64_t kv = g.xvar[k];
-        const u64 kvm = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int64_t j = j0 + wr * 64 + tm * 16 + lk + 4 * v;
-                if (j >= n || j > k) continue;
+                int64_t j, k;
+                if (M4) {
+                    const int b = (lane >> 2) & 3;
+                    j = j0 + wr * 64 + tm * 16 + 4 * b + lk;
+                    k = k0 + wc * 64 + tn * 16 + 4 * ((b + v) & 3) + (lane & 3);
+                } else {
+                    j = j0 + wr * 64 + tm * 16 + lk + 4 * v;
+                    k = k0 + wc * 64 + tn * 16 + lm;
+                }
+                if (k >= n || j >= n || j > k) continue;
+                const int64_t kv = g.xvar[k];
+                const u64 kvm = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
                 const int64_t jv = g.xvar[j];
                 double c = acc[tm][tn][v];
                 if (g.moi || j != k) c = 2 * c;          // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling
@@ -211,10 +246,14 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
             g.ntiles = (int)cdiv(cols, GT);
             g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
             const int nblk = g.ntiles * (g.ntiles + 1) / 2;
-            hipLaunchKernelGGL(quad_gram_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g);
+            // first measurement (profiles/r01_notes.md): 16x16x4 path 1.85 ms, 4x4x4_4b path 2.56 ms at n = r = 4096 —
+            // the faster instruction loses until the tile loop is restructured (2 waves/SIMD, stream-K balance).
+            static const bool m16 = [] { const char *e = getenv("PMT_GRAM_MFMA4"); return !(e && e[0] == '1'); }();
+            if (m16) PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+            else PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
             int rc = check_launch("quad_gram_kernel");
             if (rc) return rc;
-            hipLaunchKernelGGL(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
+            PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
             rc = check_launch("gram_linear_kernel");
             if (rc) return rc;
         }

@@ -8,6 +8,7 @@
 // as closures.  pmt_plan_update() replays the closures on the plan's HIP stream — no allocation, no
 // host-side term bookkeeping (the reference's @allocated == 0 contract) — or, once
 // pmt_plan_instantiate_graph() has captured them, launches one hipGraph.
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -60,7 +61,80 @@ int dispatch(void *stream, Launch launch) {
 
 }  // namespace pmt
 
+// ---- per-kernel timing ---------------------------------------------------------------------------------
+namespace pmt {
+
+struct ProfRecord { const char *name; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof_records;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+
+ProfScope::ProfScope(const char *name, hipStream_t s) : name_(name), s_(s) {
+    if (!g_prof_on) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (st != hipStreamCaptureStatusNone) return;          // never time inside a graph capture
+    e0_ = prof_event(); e1_ = prof_event();
+    if (e0_ && e1_) (void)hipEventRecord(e0_, s);
+}
+ProfScope::~ProfScope() {
+    if (!e0_ || !e1_) return;
+    (void)hipEventRecord(e1_, s_);
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_prof_records.push_back({name_, e0_, e1_});
+}
+
+}  // namespace pmt
+
 using namespace pmt;
+
+extern "C" int pmt_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &r : g_prof_records) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+    g_prof_records.clear();
+    g_prof_on = on != 0;
+    return PMT_OK;
+}
+
+// Waits for every timed launch, then writes one line per kernel: "<name>\t<count>\t<total_ms>\t<min_ms>\t<max_ms>\n".
+// Returns the number of bytes needed (excluding the terminating NUL); truncates to `cap`.
+extern "C" int64_t pmt_profile_report(char *buf, size_t cap) {
+    std::vector<ProfRecord> recs;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        recs = g_prof_records;
+    }
+    struct Agg { int64_t n = 0; double tot = 0, mn = 1e300, mx = 0; };
+    std::vector<std::pair<std::string, Agg>> aggs;
+    for (auto &r : recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        Agg *a = nullptr;
+        for (auto &p : aggs) if (p.first == r.name) { a = &p.second; break; }
+        if (!a) { aggs.emplace_back(r.name, Agg()); a = &aggs.back().second; }
+        a->n++; a->tot += ms; a->mn = std::min(a->mn, (double)ms); a->mx = std::max(a->mx, (double)ms);
+    }
+    std::string out;
+    char line[512];
+    for (auto &p : aggs) {
+        snprintf(line, sizeof line, "%s\t%lld\t%.6f\t%.6f\t%.6f\n", p.first.c_str(), (long long)p.second.n, p.second.tot, p.second.mn, p.second.mx);
+        out += line;
+    }
+    if (buf && cap) {
+        size_t k = std::min(cap - 1, out.size());
+        memcpy(buf, out.data(), k);
+        buf[k] = 0;
+    }
+    return (int64_t)out.size();
+}
 
 extern "C" const char *pmt_last_error(void) { return g_last_error.c_str(); }
 extern "C" int pmt_version(void) { return 100; }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void seq_dot_kernel(const double *__restrict__
 }
 
 int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s) {
-    hipLaunchKernelGGL(seq_dot_kernel, dim3(1), dim3(256), 0, s, a, sign_a, b, sign_b, n, out);
+    PMT_LAUNCH(seq_dot_kernel, dim3(1), dim3(256), 0, s, a, sign_a, b, sign_b, n, out);
     return check_launch("seq_dot_kernel");
 }
 
@@ -215,14 +215,14 @@ extern "C" int pmt_quad_expand_f64(int64_t rows, const pmt_linear_term *x_terms,
     return dispatch(stream, [=](hipStream_t s) {
         if (rows > 0 && nx > 0 && ny > 0) {
             dim3 grid((unsigned)cdiv(ny, QE_BT), (unsigned)cdiv(nx, QE_AB), (unsigned)std::min<int64_t>(rows, 65535));
-            hipLaunchKernelGGL(quad_expand_kernel, grid, dim3(256), 0, s, rows, x_terms, nx, y_terms, ny, moi, varmap,
+            PMT_LAUNCH(quad_expand_kernel, grid, dim3(256), 0, s, rows, x_terms, nx, y_terms, ny, moi, varmap,
                                reinterpret_cast<u64 *>(out_quad));
             int rc = check_launch("quad_expand_kernel");
             if (rc) return rc;
         }
         if (rows > 0 && nx + ny > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * (nx + ny), 256), 256 * 8);
-            hipLaunchKernelGGL(quad_expand_linear_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, nx, x_consts, y_terms, ny, y_consts,
+            PMT_LAUNCH(quad_expand_linear_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, nx, x_consts, y_terms, ny, y_consts,
                                moi, varmap, out_lin);
             int rc = check_launch("quad_expand_linear_kernel");
             if (rc) return rc;
@@ -238,7 +238,7 @@ extern "C" int pmt_bilinear_f64(const double *Q, int64_t rows, int64_t cols, con
     PMT_REQUIRE(Q && xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "bilinear: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         dim3 grid((unsigned)cdiv(cols, QE_BT), (unsigned)std::min<int64_t>(rows, 65535));
-        hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, s, Q, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
+        PMT_LAUNCH(bilinear_kernel, grid, dim3(256), 0, s, Q, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
         return check_launch("bilinear_kernel");
     });
 }
@@ -249,7 +249,7 @@ extern "C" int pmt_vecdot_terms_f64(int64_t n, const double *xc, const int64_t *
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "vecdot_terms: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(vecdot_terms_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, xc, xvar, yc, yvar, moi, varmap, out_quad);
+        PMT_LAUNCH(vecdot_terms_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, xc, xvar, yc, yvar, moi, varmap, out_quad);
         return check_launch("vecdot_terms_kernel");
     });
 }
@@ -262,7 +262,7 @@ extern "C" int pmt_vecdot_affs_vars_f64(int64_t rows, const pmt_linear_term *x_t
     PMT_REQUIRE(x_consts && yvar && out_lin && (L == 0 || (x_terms && out_quad)), PMT_INVALID_ARGUMENT, "vecdot_affs_vars: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * L + rows, 256), 256 * 8);
-        hipLaunchKernelGGL(vecdot_affs_vars_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, L, x_consts, yvar, moi, varmap, out_quad,
+        PMT_LAUNCH(vecdot_affs_vars_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, L, x_consts, yvar, moi, varmap, out_quad,
                            out_lin);
         return check_launch("vecdot_affs_vars_kernel");
     });

@@ -30,7 +30,7 @@ extern "C" int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, doubl
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
-        hipLaunchKernelGGL(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
+        PMT_LAUNCH(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
         return check_launch("fill_uniform_kernel");
     });
 }

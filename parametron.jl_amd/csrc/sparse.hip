@@ -65,7 +65,7 @@ extern "C" int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *pe
     PMT_REQUIRE(nzval && perm && term_row && term_var && out_terms, PMT_INVALID_ARGUMENT, "sparse_pack_vector: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(nnz, 256), 256 * 8);
-        hipLaunchKernelGGL(sparse_pack_vector_kernel, dim3(blocks), dim3(256), 0, s, nzval, perm, term_row, term_var, nnz, varmap, row_offset, out_terms);
+        PMT_LAUNCH(sparse_pack_vector_kernel, dim3(blocks), dim3(256), 0, s, nzval, perm, term_row, term_var, nnz, varmap, row_offset, out_terms);
         return check_launch("sparse_pack_vector_kernel");
     });
 }

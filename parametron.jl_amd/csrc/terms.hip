@@ -125,7 +125,7 @@ extern "C" int pmt_affvec_combine_f64(int64_t rows, const pmt_linear_term *xa_te
                     "affvec_combine: out_row_len != len(a) + len(b)");
     PMT_REQUIRE(out_terms || out_row_len == 0, PMT_INVALID_ARGUMENT, "affvec_combine: null out_terms");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(affvec_combine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, rows, xa_terms, xa_row_ptr, xa_row_len,
+        PMT_LAUNCH(affvec_combine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, rows, xa_terms, xa_row_ptr, xa_row_len,
                            xa_consts, xb_terms, xb_row_ptr, xb_row_len, xb_consts, sb, out_terms, out_row_ptr, out_row_len, out_consts);
         return check_launch("affvec_combine_kernel");
     });
@@ -138,7 +138,7 @@ extern "C" int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_line
     PMT_REQUIRE((nterms == 0 || (y_terms && out_terms)) && (rows == 0 || (y_consts && out_consts)), PMT_INVALID_ARGUMENT, "affvec_scale: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(nterms + rows, 256), 256 * 8);
-        hipLaunchKernelGGL(affvec_scale_kernel, dim3(blocks), dim3(256), 0, s, rows, nterms, y_terms, y_consts, s_dev, s_host, out_terms, out_consts);
+        PMT_LAUNCH(affvec_scale_kernel, dim3(blocks), dim3(256), 0, s, rows, nterms, y_terms, y_consts, s_dev, s_host, out_terms, out_consts);
         return check_launch("affvec_scale_kernel");
     });
 }
@@ -154,11 +154,11 @@ extern "C" int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows
     return dispatch(stream, [=](hipStream_t s) {
         if (cols * x_row_len > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cols * x_row_len, 256), 256 * 16);
-            hipLaunchKernelGGL(matvecmul_affs_kernel, dim3(blocks), dim3(256), 0, s, A, lda, rows, cols, x_terms, x_row_len, out_terms);
+            PMT_LAUNCH(matvecmul_affs_kernel, dim3(blocks), dim3(256), 0, s, A, lda, rows, cols, x_terms, x_row_len, out_terms);
             int rc = check_launch("matvecmul_affs_kernel");
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(matvecmul_affs_consts_kernel, dim3((unsigned)cdiv(rows, 64)), dim3(64), 0, s, A, lda, rows, cols, x_consts, out_consts);
+        PMT_LAUNCH(matvecmul_affs_consts_kernel, dim3((unsigned)cdiv(rows, 64)), dim3(64), 0, s, A, lda, rows, cols, x_consts, out_consts);
         return check_launch("matvecmul_affs_consts_kernel");
     });
 }
@@ -168,7 +168,7 @@ extern "C" int pmt_vecdot_numbers_vars_f64(const double *v, const int64_t *xvar,
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vecdot_numbers_vars: negative length");
     PMT_REQUIRE(out_const && (n == 0 || (v && xvar && out_terms)), PMT_INVALID_ARGUMENT, "vecdot_numbers_vars: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        hipLaunchKernelGGL(vecdot_numbers_vars_kernel, dim3((unsigned)std::max<int64_t>(1, cdiv(n, 256))), dim3(256), 0, s, v, xvar, n, out_terms, out_const);
+        PMT_LAUNCH(vecdot_numbers_vars_kernel, dim3((unsigned)std::max<int64_t>(1, cdiv(n, 256))), dim3(256), 0, s, v, xvar, n, out_terms, out_const);
         return check_launch("vecdot_numbers_vars_kernel");
     });
 }
@@ -181,7 +181,7 @@ extern "C" int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n, const pmt
     return dispatch(stream, [=](hipStream_t s) {
         if (n * x_row_len > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n * x_row_len, 256), 256 * 8);
-            hipLaunchKernelGGL(vecdot_numbers_affs_kernel, dim3(blocks), dim3(256), 0, s, v, n, x_terms, x_row_len, out_terms);
+            PMT_LAUNCH(vecdot_numbers_affs_kernel, dim3(blocks), dim3(256), 0, s, v, n, x_terms, x_row_len, out_terms);
             int rc = check_launch("vecdot_numbers_affs_kernel");
             if (rc) return rc;
         }
