@@ -107,6 +107,21 @@ int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_linear_term *y_
                          const double *s_dev, double s_host,
                          pmt_linear_term *out_terms, double *out_consts, void *stream);
 
+/* dest[i] = (s, yvar[i]): scale!(dest::Vector{LinearTerm}, x::Number, y::Vector{Variable}) src/functions.jl:873-893 */
+int pmt_scale_vars_f64(const int64_t *yvar, int64_t n, const double *s_dev, double s_host, pmt_linear_term *out_terms, void *stream);
+/* dest .= s .* y for number arrays: scale! src/functions.jl:917-925 */
+int pmt_scale_numbers_f64(const double *y, int64_t n, const double *s_dev, double s_host, double *out, void *stream);
+/* dest[j, i] = A[i, j] — the closure of the `adjoint` rewrite rule src/lazyexpression.jl:206-217.
+ * src is rows x cols (leading dimension lds), dst is cols x rows (leading dimension ldd), both column-major. */
+int pmt_transpose_f64(const double *src, int64_t lds, int64_t rows, int64_t cols, double *dst, int64_t ldd, void *stream);
+/* quadratic term lists: out = [ qa ; sb*qb ], sb = +1/-1: copyto! src/functions.jl:434-439, add! :459, subtract! :492-500 */
+int pmt_quad_combine_f64(const pmt_quadratic_term *qa, int64_t na, const pmt_quadratic_term *qb, int64_t nb, int sb,
+                         pmt_quadratic_term *out, void *stream);
+/* out[i] = (s * q[i].coeff, row, col): muladd!(dest::QuadraticFunction, x::QuadraticFunction, y::Number) :526-534 */
+int pmt_quad_scale_f64(const pmt_quadratic_term *q, int64_t n, const double *s_dev, double s_host, pmt_quadratic_term *out, void *stream);
+/* device-to-device copy on the stream (array-of-references copyto! nodes, src/lazyexpression.jl:280-282) */
+int pmt_copy_bytes(void *dst, const void *src, size_t bytes, void *stream);
+
 /* y = A * X with X::Vector{AffineFunction} of uniform length L:
  * row `row` = concat over col of A[row,col]*X[col].linear ; const = sum_col X.c[col]*A[row,col] (in col order).
  * matvecmul!(y, A, x::Vector{AffineFunction}) src/functions.jl:800-822 (muladd! :524 -> :515-523). */

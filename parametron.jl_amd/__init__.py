@@ -1,7 +1,39 @@
 """parametron.jl_amd — MI355X-native implementation of Parametron.jl's parameter-update hot path.
 
-Host-side mirror of the reference API (Model / Variable / Parameter / expression / objective /
-constraint / solve!) over the C ABI of libparametron_hip.so (include/parametron_hip.h).
+Host-side mirror of the reference API (Model / Variable / Parameter / @expression / @objective / @constraint /
+solve!, src/Parametron.jl:3-36) over the C ABI of libparametron_hip.so (include/parametron_hip.h).  Import as
+`import parametron_jl_amd` (the directory name is not a Python identifier; parametron_jl_amd.py is the alias).
 """
 from . import _lib  # noqa: F401
 from ._lib import ArgumentError, DimensionMismatch, ErrorException  # noqa: F401
+from .functions import (AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, canonicalize,  # noqa: F401
+                        prune_zero)
+from .parameter import DeviceUniformParameter, Parameter  # noqa: F401
+from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, lazy, transpose, vcat, vect,  # noqa: F401
+                             wrap)
+from .hostops import Transpose  # noqa: F401
+from . import moi  # noqa: F401
+from .model import (AbstractOptimizer, Maximize, Minimize, MockOptimizer, Model, constraint, dualstatus, initialize,  # noqa: F401
+                    mock_model, objective, objectivevalue, primalstatus, setdirty, setobjective, solve,
+                    terminationstatus, update, value)
+
+findallocs = None  # the reference's per-node allocation report (src/debug.jl) has a device analogue: profile_report()
+
+
+def profile_enable(on=True):
+    """Per-kernel timing of every launch (the device analogue of findallocs, src/debug.jl:4-23)."""
+    _lib.call("pmt_profile_enable", 1 if on else 0)
+
+
+def profile_report():
+    """{kernel: {launches, avg_ms, min_ms, max_ms}} since profile_enable(True)."""
+    import ctypes as C
+    L = _lib.load()
+    n = L.pmt_profile_report(None, 0)
+    buf = C.create_string_buffer(int(n) + 1)
+    L.pmt_profile_report(buf, int(n) + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, tot, mn, mx = line.split("\t")
+        out[name] = {"launches": int(cnt), "avg_ms": float(tot) / max(1, int(cnt)), "min_ms": float(mn), "max_ms": float(mx)}
+    return out

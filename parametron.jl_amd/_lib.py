@@ -47,6 +47,12 @@ SIGNATURES = {
     "pmt_vars_addsub_f64": (_ci, [_vp, _i64, _vp, _ci, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pmt_affvec_combine_f64": (_ci, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _i64, _vp, _vp]),
     "pmt_affvec_scale_f64": (_ci, [_i64, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _vp]),
+    "pmt_scale_vars_f64": (_ci, [_vp, _i64, _vp, _f64, _vp, _vp]),
+    "pmt_scale_numbers_f64": (_ci, [_vp, _i64, _vp, _f64, _vp, _vp]),
+    "pmt_transpose_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "pmt_quad_combine_f64": (_ci, [_vp, _i64, _vp, _i64, _ci, _vp, _vp]),
+    "pmt_quad_scale_f64": (_ci, [_vp, _i64, _vp, _f64, _vp, _vp]),
+    "pmt_copy_bytes": (_ci, [_vp, _vp, _sz, _vp]),
     "pmt_matvecmul_affs_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pmt_vecdot_numbers_vars_f64": (_ci, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "pmt_vecdot_numbers_affs_f64": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -108,9 +108,123 @@ __global__ void vecdot_numbers_affs_kernel(const double *__restrict__ v, int64_t
     }
 }
 
+// dest[j, i] = A[i, j]: the `adjoint` rewrite rule's closure (src/lazyexpression.jl:206-217); 32x32 LDS tile transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ src, int64_t lds_, int64_t rows, int64_t cols,
+                                                        double *__restrict__ dst, int64_t ldd) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = r0 + tx, c = c0 + k;
+        if (r < rows && c < cols) tile[k][tx] = src[c * lds_ + r];    // column-major read, rows fastest
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t c = c0 + tx, r = r0 + k;
+        if (r < rows && c < cols) dst[r * ldd + c] = tile[tx][k];     // dst is cols x rows column-major: dst[c, r]
+    }
+}
+
+// quadratic term lists: out = [ qa ; sb * qb ]  (copyto! :434-439, add! :459, subtract! :492-500) or s * q (muladd! :526-534)
+__global__ void quad_combine_kernel(const QT *__restrict__ qa, int64_t na, const QT *__restrict__ qb, int64_t nb, int sb, QT *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+        QT t = i < na ? qa[i] : qb[i - na];
+        if (i >= na && sb < 0) t.coeff = -t.coeff;
+        out[i] = t;
+    }
+}
+__global__ void quad_scale_kernel(const QT *__restrict__ q, int64_t n, const double *__restrict__ s_dev, double s_host, QT *__restrict__ out) {
+    const double s = s_dev ? *s_dev : s_host;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        QT t = q[i];
+        t.coeff = s * t.coeff;                                          // x.quadratic[i] * y -> y * coeff (functions.jl:530, :159-160)
+        out[i] = t;
+    }
+}
+// scale!(dest::Vector{LinearTerm}, x::Number, y::Vector{Variable}) src/functions.jl:873-893: dest[i] = (s, yvar[i])
+__global__ void scale_vars_kernel(const int64_t *__restrict__ yvar, int64_t n, const double *__restrict__ s_dev, double s_host, LT *__restrict__ out) {
+    const double s = s_dev ? *s_dev : s_host;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { LT t; t.coeff = s; t.var = yvar[i]; out[i] = t; }
+}
+// scale!(dest::Array{<:Number}, x::Number, y::Array{<:Number}) src/functions.jl:917-925: dest .= x .* y
+__global__ void scale_numbers_kernel(const double *__restrict__ y, int64_t n, const double *__restrict__ s_dev, double s_host, double *__restrict__ out) {
+    const double s = s_dev ? *s_dev : s_host;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = s * y[i];
+}
+
 }  // namespace pmt
 
 using namespace pmt;
+
+extern "C" int pmt_transpose_f64(const double *src, int64_t lds_, int64_t rows, int64_t cols, double *dst, int64_t ldd, void *stream) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "transpose: negative dimension");
+    PMT_REQUIRE(lds_ >= rows && ldd >= cols, PMT_DIMENSION_MISMATCH, "transpose: leading dimension too small");
+    if (rows == 0 || cols == 0) return PMT_OK;
+    PMT_REQUIRE(src && dst, PMT_INVALID_ARGUMENT, "transpose: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_LAUNCH(transpose_kernel, dim3((unsigned)cdiv(rows, 32), (unsigned)cdiv(cols, 32)), dim3(256), 0, s, src, lds_, rows, cols, dst, ldd);
+        return check_launch("transpose_kernel");
+    });
+}
+
+extern "C" int pmt_quad_combine_f64(const pmt_quadratic_term *qa, int64_t na, const pmt_quadratic_term *qb, int64_t nb, int sb,
+                                    pmt_quadratic_term *out, void *stream) {
+    PMT_REQUIRE(na >= 0 && nb >= 0, PMT_DIMENSION_MISMATCH, "quad_combine: negative length");
+    PMT_REQUIRE(sb == 1 || sb == -1, PMT_INVALID_ARGUMENT, "quad_combine: sb must be +1 or -1");
+    if (na + nb == 0) return PMT_OK;
+    PMT_REQUIRE(out && (na == 0 || qa) && (nb == 0 || qb), PMT_INVALID_ARGUMENT, "quad_combine: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(na + nb, 256), 256 * 8);
+        PMT_LAUNCH(quad_combine_kernel, dim3(blocks), dim3(256), 0, s, qa, na, qb, nb, sb, out);
+        return check_launch("quad_combine_kernel");
+    });
+}
+
+extern "C" int pmt_quad_scale_f64(const pmt_quadratic_term *q, int64_t n, const double *s_dev, double s_host, pmt_quadratic_term *out,
+                                  void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "quad_scale: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(q && out, PMT_INVALID_ARGUMENT, "quad_scale: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
+        PMT_LAUNCH(quad_scale_kernel, dim3(blocks), dim3(256), 0, s, q, n, s_dev, s_host, out);
+        return check_launch("quad_scale_kernel");
+    });
+}
+
+extern "C" int pmt_scale_vars_f64(const int64_t *yvar, int64_t n, const double *s_dev, double s_host, pmt_linear_term *out, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "scale_vars: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(yvar && out, PMT_INVALID_ARGUMENT, "scale_vars: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_LAUNCH(scale_vars_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, yvar, n, s_dev, s_host, out);
+        return check_launch("scale_vars_kernel");
+    });
+}
+
+extern "C" int pmt_scale_numbers_f64(const double *y, int64_t n, const double *s_dev, double s_host, double *out, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "scale_numbers: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(y && out, PMT_INVALID_ARGUMENT, "scale_numbers: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
+        PMT_LAUNCH(scale_numbers_kernel, dim3(blocks), dim3(256), 0, s, y, n, s_dev, s_host, out);
+        return check_launch("scale_numbers_kernel");
+    });
+}
+
+extern "C" int pmt_copy_bytes(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(dst && src, PMT_INVALID_ARGUMENT, "copy_bytes: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+        return PMT_OK;
+    });
+}
 
 extern "C" int pmt_affvec_combine_f64(int64_t rows, const pmt_linear_term *xa_terms, const int64_t *xa_row_ptr, int64_t xa_row_len,
                                       const double *xa_consts, const pmt_linear_term *xb_terms, const int64_t *xb_row_ptr,

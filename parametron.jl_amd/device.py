@@ -1,0 +1,284 @@
+"""Device context and device value descriptors for one Model.
+
+One Model = one pmt_plan (include/parametron_hip.h): it owns the HIP stream and every device buffer — the `dest`
+of each lazy-expression node is allocated when the node is created (↔ `dest = deepcopy(expr())`,
+src/lazyexpression.jl:202,230,243) and never reallocated, so steady-state update!() performs no allocation.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LT, QT, VAT, ArgumentError
+
+
+class DeviceContext:
+    def __init__(self, device=0):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.plan = C.c_void_p()
+        _lib.call("pmt_plan_create", int(device), None, C.byref(self.plan))
+        self.stream = C.c_void_p(self.lib.pmt_plan_stream(self.plan))
+        self.rec = C.c_void_p(self.lib.pmt_plan_recording_stream(self.plan))
+        self.recording = False
+        self._keep = []          # host arrays that must outlive asynchronous uploads
+
+    def close(self):
+        if self.plan:
+            self.lib.pmt_plan_destroy(self.plan)
+            self.plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.call("pmt_plan_alloc", self.plan, int(nbytes), C.byref(p))
+        return p.value
+
+    def bytes_allocated(self):
+        return int(self.lib.pmt_plan_bytes_allocated(self.plan))
+
+    def upload(self, dptr, host):
+        host = np.ascontiguousarray(host)
+        if host.nbytes == 0:
+            return
+        self._keep.append(host)
+        _lib.call("pmt_plan_upload", self.plan, C.c_void_p(dptr), host.ctypes.data_as(C.c_void_p), host.nbytes)
+
+    def upload_new(self, host):
+        host = np.ascontiguousarray(host)
+        p = self.alloc(max(host.nbytes, 8))
+        self.upload(p, host)
+        return p
+
+    def fetch(self, host, dptr, nbytes):
+        if nbytes == 0:
+            return
+        _lib.call("pmt_plan_fetch", self.plan, host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), int(nbytes))
+
+    def synchronize(self):
+        _lib.call("pmt_plan_synchronize", self.plan)
+        self._keep.clear()
+
+    # ---- launches: immediate on the plan's stream, or appended to the tape while recording
+    def launch_stream(self):
+        return self.rec if self.recording else self.stream
+
+    def call(self, name, *args):
+        _lib.call(name, *args, self.launch_stream())
+
+    def begin_record(self):
+        _lib.call("pmt_plan_begin_record", self.plan)
+        self.recording = True
+
+    def end_record(self):
+        _lib.call("pmt_plan_end_record", self.plan)
+        self.recording = False
+
+    def replay(self):
+        _lib.call("pmt_plan_update", self.plan)
+
+    def instantiate_graph(self):
+        _lib.call("pmt_plan_instantiate_graph", self.plan)
+
+    def tape_length(self):
+        return int(self.lib.pmt_plan_tape_length(self.plan))
+
+
+def P(ptr):
+    return C.c_void_p(ptr) if ptr else None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device value descriptors (what a node's `dest` looks like in HBM)
+
+class DV:
+    kind = "?"
+
+
+class DNum(DV):
+    """Number: f64[1]."""
+    kind = "num"
+
+    def __init__(self, ctx, value=None):
+        self.buf = ctx.alloc(8)
+        if value is not None:
+            ctx.upload(self.buf, np.array([value], dtype=np.float64))
+
+
+class DVec(DV):
+    """Vector{Float64}: f64[n]."""
+    kind = "vec"
+
+    def __init__(self, ctx, n):
+        self.n = int(n)
+        self.buf = ctx.alloc(8 * max(self.n, 1))
+
+
+class DMat(DV):
+    """Matrix{Float64}, column-major, lda == rows."""
+    kind = "mat"
+
+    def __init__(self, ctx, rows, cols):
+        self.rows, self.cols = int(rows), int(cols)
+        self.buf = ctx.alloc(8 * max(self.rows * self.cols, 1))
+
+
+class DVars(DV):
+    """Vector{Variable}: static Int64 indices; `lt` = the same variables as LinearTerm(1.0, var) (copyto!(f, ::Variable), src/functions.jl:421)."""
+    kind = "varvec"
+
+    def __init__(self, ctx, variables):
+        self.vars = np.array([v.index for v in variables], dtype=np.int64)
+        self.n = len(self.vars)
+        self.buf = ctx.upload_new(self.vars) if self.n else ctx.alloc(8)
+        self._lt = None
+        self.ctx = ctx
+
+    def lt(self):
+        if self._lt is None:
+            t = np.empty(self.n, dtype=LT)
+            t["coeff"] = 1.0
+            t["var"] = self.vars
+            self._lt = self.ctx.upload_new(t)
+        return self._lt
+
+    def strictly_increasing(self):
+        return bool(np.all(np.diff(self.vars) > 0))
+
+
+class DLinVec(DV):
+    """Vector{LinearTerm{Float64}}: LT[n]."""
+    kind = "ltvec"
+
+    def __init__(self, ctx, n):
+        self.n = int(n)
+        self.terms = ctx.alloc(16 * max(self.n, 1))
+
+
+class DAffVec(DV):
+    """Vector{AffineFunction{Float64}}: flat LT buffer + per-row constants; uniform rows (row_len) or ragged (row_ptr)."""
+    kind = "affvec"
+
+    def __init__(self, ctx, rows, row_len=None, row_ptr=None, alloc=True):
+        self.ctx = ctx
+        self.rows = int(rows)
+        if row_ptr is not None:
+            self.row_ptr = np.asarray(row_ptr, dtype=np.int64)
+            self.row_len = 0
+            self.nterms = int(self.row_ptr[-1]) if self.rows else 0
+            lens = np.diff(self.row_ptr)
+            if self.rows and np.all(lens == lens[0]):          # uniform after all
+                self.row_len, self.row_ptr = int(lens[0]), None
+        else:
+            self.row_ptr = None
+            self.row_len = int(row_len)
+            self.nterms = self.rows * self.row_len
+        self.row_ptr_buf = ctx.upload_new(self.row_ptr) if self.row_ptr is not None else None
+        self.terms = ctx.alloc(16 * max(self.nterms, 1)) if alloc else None
+        self.consts = ctx.alloc(8 * max(self.rows, 1)) if alloc else None
+
+    def uniform(self):
+        return self.row_ptr is None
+
+    def host_row_ptr(self):
+        if self.row_ptr is not None:
+            return self.row_ptr
+        return np.arange(self.rows + 1, dtype=np.int64) * self.row_len
+
+    def materialized(self):
+        return self
+
+
+class DDenseAff(DAffVec):
+    """A*x (+|-) b kept implicit (A, xvar, b, sign): variable indices are the column's, so nothing but A and b is read.
+    The LinearTerm block is written only if a consumer needs it (`require_terms`)."""
+
+    def __init__(self, ctx, mat, xvars, vec, sign):
+        super().__init__(ctx, mat.rows, row_len=mat.cols, alloc=False)
+        self.mat, self.xvars, self.vec, self.sign = mat, xvars, vec, sign
+        self.need_terms = False
+
+    def require_terms(self):
+        if not self.need_terms:
+            self.need_terms = True
+            self.terms = self.ctx.alloc(16 * max(self.nterms, 1))
+            self.consts = self.ctx.alloc(8 * max(self.rows, 1))
+        return self
+
+    def materialized(self):
+        return self.require_terms()
+
+
+class DVarsAff(DAffVec):
+    """x (+|-) v for x::Vector{Variable} kept implicit: one term (1.0, x[i]) per row."""
+
+    def __init__(self, ctx, xvars, vec, sign):
+        super().__init__(ctx, xvars.n, row_len=1, alloc=False)
+        self.xvars, self.vec, self.sign = xvars, vec, sign
+        self.need_terms = False
+
+    def require_terms(self):
+        if not self.need_terms:
+            self.need_terms = True
+            self.terms = self.ctx.alloc(16 * max(self.nterms, 1))
+            self.consts = self.ctx.alloc(8 * max(self.rows, 1))
+        return self
+
+    def materialized(self):
+        return self.require_terms()
+
+
+class DAff(DV):
+    """AffineFunction{Float64}: LT[nterms] + f64[1]."""
+    kind = "aff"
+
+    def __init__(self, ctx, nterms, alloc=True):
+        self.nterms = int(nterms)
+        self.terms = ctx.alloc(16 * max(self.nterms, 1)) if alloc else None
+        self.const = ctx.alloc(8) if alloc else None
+
+
+class DQuad(DV):
+    """QuadraticFunction{Float64}: QT[nq] + LT[nl] + f64[1].  Buffers may be deferred (`materialize`) because the literal
+    expansion of a large residual . residual cannot exist in memory."""
+    kind = "quad"
+
+    def __init__(self, ctx, nq, nl, alloc=True):
+        self.ctx = ctx
+        self.nq, self.nl = int(nq), int(nl)
+        self.quad = self.lin = self.const = None
+        if alloc:
+            self.materialize()
+
+    def materialize(self):
+        if self.quad is None:
+            need = 24 * self.nq + 16 * self.nl
+            if need > (200 << 30):
+                raise MemoryError("the literal (uncombined) expansion needs %.1f GB of QuadraticTerms; use the canonical "
+                                  "objective mode (Model(..., quadratic_mode='canonical'))" % (need / 1e9))
+            self.quad = self.ctx.alloc(24 * max(self.nq, 1))
+            self.lin = self.ctx.alloc(16 * max(self.nl, 1))
+            self.const = self.ctx.alloc(8)
+        return self
+
+
+def fetch_terms(ctx, ptr, n, dtype):
+    out = np.empty(int(n), dtype=dtype)
+    ctx.fetch(out, ptr, out.nbytes)
+    return out
+
+
+def fetch_f64(ctx, ptr, n):
+    out = np.empty(int(n), dtype=np.float64)
+    ctx.fetch(out, ptr, out.nbytes)
+    return out
+
+
+__all__ = ["DeviceContext", "DV", "DNum", "DVec", "DMat", "DVars", "DLinVec", "DAffVec", "DDenseAff", "DVarsAff", "DAff", "DQuad",
+           "fetch_terms", "fetch_f64", "P", "LT", "QT", "VAT", "ArgumentError"]

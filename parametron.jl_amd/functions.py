@@ -193,14 +193,14 @@ class AffineFunction:
 
     __array_priority__ = 1000
 
-    def __init__(self, linear=(), constant=0.0):
+    def __init__(self, linear=(), constant=0):
         self.linear = [t if isinstance(t, LinearTerm) else LinearTerm(t[0], t[1] if isinstance(t[1], Variable) else Variable(t[1]))
                        for t in linear]
         self.constant = constant
 
     @staticmethod
     def zero():
-        return AffineFunction([], 0.0)                                 # :243
+        return AffineFunction([], 0)                                   # :243
 
     @staticmethod
     def of(x):
@@ -208,9 +208,9 @@ class AffineFunction:
         if isinstance(x, AffineFunction):
             return AffineFunction(list(x.linear), x.constant)
         if isinstance(x, LinearTerm):
-            return AffineFunction([x], 0.0)
+            return AffineFunction([x], 0)
         if isinstance(x, Variable):
-            return AffineFunction([LinearTerm(1.0, x)], 0.0)
+            return AffineFunction([LinearTerm(1, x)], 0)
         if _isnum(x):
             return AffineFunction([], x)
         raise TypeError(type(x))
@@ -250,7 +250,7 @@ class AffineFunction:
         if _isnum(x):
             self.constant = self.constant + x
         elif isinstance(x, Variable):
-            self.linear.append(LinearTerm(1.0, x))
+            self.linear.append(LinearTerm(1, x))
         elif isinstance(x, LinearTerm):
             self.linear.append(x)
         elif isinstance(x, AffineFunction):
@@ -264,7 +264,7 @@ class AffineFunction:
         if _isnum(x):
             self.constant = self.constant - x
         elif isinstance(x, Variable):
-            self.linear.append(LinearTerm(-1.0, x))
+            self.linear.append(LinearTerm(-1, x))
         elif isinstance(x, LinearTerm):
             self.linear.append(-x)
         elif isinstance(x, AffineFunction):
@@ -515,6 +515,20 @@ def _power_by_squaring(x, p):
     if p == 2:
         return x * x
     raise ArgumentError("powers above 2 leave the quadratic function types")
+
+
+def _relation(op):
+    def method(self, other):
+        from .lazyexpression import Relation
+        return Relation(self, op, other)
+    return method
+
+
+for _cls in (Variable, LinearTerm, QuadraticTerm, AffineFunction, QuadraticFunction):
+    # `x + 2y >= 4` inside constraint(model, ...) (src/model.jl:224-249); `==` keeps Julia's structural meaning,
+    # use constraint(model, lhs, "==", rhs) for equality constraints between constants.
+    _cls.__le__ = _relation("<=")
+    _cls.__ge__ = _relation(">=")
 
 
 def canonicalize(f):

@@ -1,0 +1,330 @@
+"""Model: the user API and the driver of the hot path (src/model.jl:1-274).
+
+    model = Model(optimizer)
+    x = [Variable(model) for _ in range(n)]
+    A = Parameter(f, np.zeros((n, n)), model) ...
+    residual = A * x - b                       # @expression A * x - b
+    objective(model, Minimize, dot(residual, residual))
+    constraint(model, C * x == d)
+    solve(model)                               # solve!(model): initialize! once, update!, optimize!
+
+update!(model) = setdirty!; refresh dirty Parameters in the reference's evaluation order (host callback + H2D copy, or a
+device fill); replay the recorded tape of node kernels and MOI-pack kernels on the model's HIP stream
+(pmt_plan_update — no allocation, no host term bookkeeping); copy the MOI buffers to the host function objects and hand
+them to the optimizer with MOI.set (third party from there on).
+"""
+import numpy as np
+
+from . import moi
+from ._lib import ArgumentError, ErrorException
+from .device import DeviceContext
+from .functions import AffineFunction, Variable, _isnum
+from .lazyexpression import DeviceNode, Relation, evaluate, lazy, schedule
+from .parameter import Parameter
+
+Minimize, Maximize = "Minimize", "Maximize"
+
+
+class AbstractOptimizer:
+    """The slice of MathOptInterface the reference drives (src/model.jl:118,157,166-194; src/moi_interop.jl:134,171).
+    A concrete optimizer wraps a solver; the package ships only MockOptimizer (↔ src/mockmodel.jl)."""
+
+    def copy_to(self, backend):
+        """MOI.copy_to(optimizer, backend) -> index map {'variables': int64[nvars] optimizer index of Variable k (1-based),
+        'constraints': {constraint: optimizer constraint index}}"""
+        raise NotImplementedError
+
+    def set_objective_function(self, f):
+        raise NotImplementedError
+
+    def set_constraint_function(self, index, f):
+        raise NotImplementedError
+
+    def optimize(self):
+        raise NotImplementedError
+
+    def variable_primal(self, index):
+        raise NotImplementedError
+
+    def objective_value(self):
+        raise NotImplementedError
+
+    def termination_status(self):
+        raise NotImplementedError
+
+    def primal_status(self):
+        raise NotImplementedError
+
+    def dual_status(self):
+        raise NotImplementedError
+
+
+class MockOptimizer(AbstractOptimizer):
+    """mock_model()'s optimizer (src/mockmodel.jl:3-6): records what it is given, optimises nothing."""
+
+    def __init__(self, variable_offset=0):
+        self.variable_offset = variable_offset
+        self.objective = None
+        self.constraints = {}
+        self.sets = {}
+        self.nvars = 0
+        self.sense = None
+        self.optimize_calls = 0
+        self.set_calls = 0
+
+    def copy_to(self, backend):
+        self.nvars = backend.nvars
+        self.sense = backend.sense
+        self.objective = backend.objective.f
+        cmap = {}
+        for i, c in enumerate(backend.constraints):
+            cmap[c] = i
+            self.constraints[i] = c.f
+            self.sets[i] = c.set
+        return {"variables": np.arange(1, backend.nvars + 1, dtype=np.int64) + self.variable_offset, "constraints": cmap}
+
+    def set_objective_function(self, f):
+        self.objective = f
+        self.set_calls += 1
+
+    def set_constraint_function(self, index, f):
+        self.constraints[index] = f
+        self.set_calls += 1
+
+    def optimize(self):
+        self.optimize_calls += 1
+
+    def variable_primal(self, index):
+        return 0.0
+
+    def objective_value(self):
+        return 0.0
+
+    def termination_status(self):
+        return "OPTIMIZE_NOT_CALLED" if not self.optimize_calls else "OPTIMAL"
+
+    def primal_status(self):
+        return "NO_SOLUTION"
+
+    def dual_status(self):
+        return "NO_SOLUTION"
+
+
+class _Backend:
+    """What MOI.copy_to sees of the ParametronMOIModel backend (src/moi_interop.jl:2-11)."""
+
+    def __init__(self, nvars, sense, objective, constraints):
+        self.nvars, self.sense, self.objective, self.constraints = nvars, sense, objective, constraints
+
+
+class Model:
+    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False):       # src/model.jl:10-22
+        if quadratic_mode not in ("auto", "literal", "canonical"):
+            raise ArgumentError("quadratic_mode must be 'auto', 'literal' or 'canonical'")
+        self.params = []
+        self.optimizer = optimizer
+        self.initialized = False
+        self.nvars = 0
+        self.sense = Minimize
+        self.objective = moi.Objective(self, AffineFunction.zero())     # default objective (issue #62, src/model.jl:15)
+        self.constraints = moi.Constraints()
+        self.model_var_to_optimizer = np.zeros(0, dtype=np.int64)
+        self.quadratic_mode = quadratic_mode
+        self._device_index = device
+        self._ctx = None
+        self._use_graph = use_graph
+        self._records = []
+
+    def __repr__(self):
+        return "Model{Float64, %s}(…)" % type(self.optimizer).__name__
+
+    # ---- device
+    def device(self):
+        if self._ctx is None:
+            self._ctx = DeviceContext(self._device_index)            # raises loudly without a GPU / built library
+        return self._ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    # ---- setup API
+    def setdirty(self):                                                # src/model.jl:40
+        for p in self.params:
+            p.setdirty()
+
+    def addparameter(self, p):                                         # src/model.jl:42
+        self.params.append(p)
+        return p
+
+    def _add_variable(self):                                           # src/model.jl:49-53
+        if self.initialized:
+            raise ErrorException("Model has already been initialized.")
+        self.nvars += 1
+        return self.nvars
+
+    def setobjective(self, sense, expr):                               # src/model.jl:60-66
+        if self.initialized:
+            raise ErrorException("Model was already initialized. setobjective! can only be called before initialization.")
+        if sense not in (Minimize, Maximize):
+            raise ArgumentError("sense must be Minimize or Maximize")
+        self.objective = moi.Objective(self, expr)
+        self.sense = sense
+
+    def add_constraint(self, c):                                       # src/model.jl:68-73
+        if self.initialized:
+            raise ErrorException("Model was already initialized. add_constraint can only be called before initialization.")
+        c.modelindex = len(self.constraints)
+        self.constraints.push(c)
+
+    def _add(self, expr, scalar_set, vector_set):                      # src/model.jl:75-95
+        kind = moi.canonical_function_kind(expr.out.kind if isinstance(expr, DeviceNode) else moi.kind_of(expr))
+        if kind == "affvec":
+            n = expr.out.rows if isinstance(expr, DeviceNode) else len(expr)
+            self.add_constraint(moi.Constraint(self, expr, vector_set(n)))
+        else:
+            self.add_constraint(moi.Constraint(self, expr, scalar_set(0.0)))
+
+    def add_nonnegative_constraint(self, expr): self._add(expr, moi.GreaterThan, moi.Nonnegatives)
+    def add_nonpositive_constraint(self, expr): self._add(expr, moi.LessThan, moi.Nonpositives)
+    def add_zero_constraint(self, expr): self._add(expr, moi.EqualTo, moi.Zeros)
+
+    def add_integer_constraint(self, x):                               # src/model.jl:97
+        self.add_constraint(moi.Constraint(self, None, moi.Integer(), function=moi.SingleVariable(x)))
+
+    def add_binary_constraint(self, x):                                # src/model.jl:98
+        self.add_constraint(moi.Constraint(self, None, moi.ZeroOne(), function=moi.SingleVariable(x)))
+
+    # ---- initialize! / update! / solve!
+    def initialize(self):                                              # src/model.jl:117-122
+        backend = _Backend(self.nvars, self.sense, self.objective, list(self.constraints))
+        records = [r for r in [self.objective] + list(self.constraints) if not r.isconstant]
+        self._records = records
+        if records:
+            ctx = self.device()
+            self._varmap_buf = ctx.alloc(8 * max(self.nvars, 1))
+            ident = np.arange(1, self.nvars + 1, dtype=np.int64)     # IdentityVarMap until mapindices! (src/moi_interop.jl:32-33)
+            ctx.upload(self._varmap_buf, ident)
+            emitters = [r.compile(ctx, self._varmap_buf, self.quadratic_mode) for r in records]
+            self._order = schedule([r.expr for r in records])
+            for x in self._order:
+                if isinstance(x, DeviceNode):
+                    x.prepare()
+            ctx.begin_record()
+            try:
+                for x in self._order:
+                    if isinstance(x, DeviceNode):
+                        x.emit(ctx)
+                for e in emitters:
+                    e(ctx)
+            finally:
+                ctx.end_record()
+            # first evaluation with the identity map so that copy_to sees sized, filled functions (src/moi_interop.jl:127,157)
+            self._run_tape()
+        indexmap = self.optimizer.copy_to(backend)
+        self._mapindices(indexmap)
+        if records and self._use_graph:
+            self.device().instantiate_graph()
+        self.initialized = True
+
+    def _mapindices(self, indexmap):                                   # src/model.jl:100-107
+        for c in self.constraints:
+            c.optimizerindex = indexmap["constraints"][c]
+        self.model_var_to_optimizer = np.asarray(indexmap["variables"], dtype=np.int64).copy()
+        if self._records:
+            self.device().upload(self._varmap_buf, self.model_var_to_optimizer)
+
+    def _refresh_parameters(self):
+        ctx = self.device()
+        from .lazyexpression import device_value_of
+        for x in self._order:
+            if isinstance(x, Parameter):
+                device_value_of(x, ctx)
+
+    def _run_tape(self):
+        ctx = self.device()
+        self._refresh_parameters()
+        ctx.replay()
+        for r in self._records:
+            r.fetch(ctx)
+        ctx.synchronize()
+        for r in self._records:
+            r.finish_fetch()
+
+    def update(self):                                                  # src/model.jl:132-143
+        self.setdirty()
+        if self._records:
+            self._run_tape()
+        if not self.objective.isconstant:                              # src/moi_interop.jl:131-137
+            self.optimizer.set_objective_function(self.objective.f)
+        for c in self.constraints:                                     # src/moi_interop.jl:168-175, order :236-247
+            if not c.isconstant:
+                self.optimizer.set_constraint_function(c.optimizerindex, c.f)
+
+    def solve(self):                                                   # src/model.jl:151-159
+        if not self.initialized:
+            self.initialize()
+        self.update()
+        self.optimizer.optimize()
+
+    # ---- results (src/model.jl:166-194)
+    def value(self, x):
+        if isinstance(x, (list, tuple, np.ndarray)):
+            return np.array([self.value(v) for v in x])
+        return self.optimizer.variable_primal(int(self.model_var_to_optimizer[x.index - 1]))
+
+    def objectivevalue(self): return self.optimizer.objective_value()
+    def terminationstatus(self): return self.optimizer.termination_status()
+    def primalstatus(self): return self.optimizer.primal_status()
+    def dualstatus(self): return self.optimizer.dual_status()
+
+
+# ---- function forms of the reference's exported names
+def mock_model(**kw):                                                   # src/mockmodel.jl:3-6
+    return Model(MockOptimizer(), **kw)
+
+
+def setobjective(model, sense, expr): model.setobjective(sense, expr)
+def initialize(model): model.initialize()
+def update(model): model.update()
+def solve(model): model.solve()
+def value(model, x): return model.value(x)
+def objectivevalue(model): return model.objectivevalue()
+def terminationstatus(model): return model.terminationstatus()
+def primalstatus(model): return model.primalstatus()
+def dualstatus(model): return model.dualstatus()
+def setdirty(x): x.setdirty()
+
+
+def objective(model, sense, expr):
+    """@objective(model, sense, expr) (src/model.jl:267-271)."""
+    model.setobjective(sense, expr)
+
+
+INTEGERS = ("ℤ", "Integers")
+ZERO_ONE = ("{0, 1}", "ZeroOne")
+
+
+def constraint(model, rel, op=None, rhs=None):
+    """@constraint(model, lhs (>=|<=|==|in) rhs) (src/model.jl:224-249): always lhs - rhs in the matching cone."""
+    if not isinstance(rel, Relation):
+        if op is None:
+            raise ArgumentError("Expected expression of the form `a relation b`")          # src/model.jl:226
+        rel = Relation(rel, op, rhs)
+    lhs, op, rhs = rel.lhs, rel.op, rel.rhs
+    if op in ("in", "∈"):
+        if rhs in INTEGERS:
+            return model.add_integer_constraint(lhs)
+        if rhs in ZERO_ONE:
+            return model.add_binary_constraint(lhs)
+        raise ArgumentError("'in' only supports ℤ/Integers and {0, 1}/ZeroOne")              # src/model.jl:243
+    if op not in (">=", "<=", "=="):
+        raise ArgumentError("Relation not recognized")                                        # src/model.jl:246
+    expr = lazy("-", lhs, rhs)
+    if op == ">=":
+        model.add_nonnegative_constraint(expr)
+    elif op == "<=":
+        model.add_nonpositive_constraint(expr)
+    else:
+        model.add_zero_constraint(expr)

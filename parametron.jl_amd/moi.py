@@ -1,0 +1,282 @@
+"""MathOptInterface hand-off (src/moi_interop.jl): function/set records, Objective / Constraint / Constraints and the
+native -> MOI copies `update!(moi_f, f, varmap)` (:35-81).
+
+MOI function buffers are numpy structured arrays with exactly the Julia isbits layouts, so a
+Julia host can pass `pointer(moi_f.terms)` as the destination of pmt_plan_fetch.  For non-constant records the copy
+itself runs on the device (the pack kernels write MOI terms, through `varmap`, into device twins of these buffers);
+constant records are converted once on the host at setup, as in the reference (`isconstant`, :123,132,153,169).
+"""
+import numpy as np
+
+from ._lib import LT, QT, VAT, ArgumentError
+from .device import DAff, DAffVec, DDenseAff, DQuad, DVarsAff, P
+from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
+from .lazyexpression import DeviceNode, kind_of
+
+MIN_SENSE, MAX_SENSE = "MIN_SENSE", "MAX_SENSE"
+
+
+# ---- sets (MOI.AbstractSet)
+class _Set:
+    def __init__(self, value=None):
+        self.value = value
+
+    def __repr__(self):
+        return "%s(%r)" % (type(self).__name__, self.value)
+
+    def __eq__(self, o):
+        return type(o) is type(self) and o.value == self.value
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.value))
+
+
+class GreaterThan(_Set): pass
+class LessThan(_Set): pass
+class EqualTo(_Set): pass
+class Nonnegatives(_Set): pass
+class Nonpositives(_Set): pass
+class Zeros(_Set): pass
+class Integer(_Set): pass
+class ZeroOne(_Set): pass
+
+
+# ---- functions (MOI.AbstractFunction)
+class ScalarAffineFunction:
+    def __init__(self, nterms=0):
+        self.terms = np.zeros(nterms, dtype=LT)
+        self.constant = 0.0
+
+
+class ScalarQuadraticFunction:
+    def __init__(self, naff=0, nquad=0):
+        self.affine_terms = np.zeros(naff, dtype=LT)
+        self.quadratic_terms = np.zeros(nquad, dtype=QT)
+        self.constant = 0.0
+
+
+class VectorAffineFunction:
+    def __init__(self, nterms=0, nrows=0):
+        self.terms = np.zeros(nterms, dtype=VAT)
+        self.constants = np.zeros(nrows, dtype=np.float64)
+
+
+class SingleVariable:
+    def __init__(self, variable):
+        self.variable = variable
+
+
+# ---- host restatement of update!(moi_f, f, varmap) for CONSTANT records (setup time)
+def _vm(varmap, idx):
+    return idx if varmap is None else int(varmap[idx - 1])
+
+
+def update_scalar_affine(moi_f, f, varmap=None):                      # src/moi_interop.jl:35-43
+    moi_f.constant = float(f.constant)
+    moi_f.terms = np.zeros(len(f.linear), dtype=LT)
+    for i, t in enumerate(f.linear):
+        moi_f.terms[i] = (t.coeff, _vm(varmap, t.var.index))
+    return moi_f
+
+
+def update_scalar_quadratic(moi_f, f, varmap=None):                   # src/moi_interop.jl:45-62
+    update_scalar_affine_part = ScalarAffineFunction()
+    update_scalar_affine(update_scalar_affine_part, f.affine, varmap)
+    moi_f.constant = update_scalar_affine_part.constant
+    moi_f.affine_terms = update_scalar_affine_part.terms
+    moi_f.quadratic_terms = np.zeros(len(f.quadratic), dtype=QT)
+    for i, t in enumerate(f.quadratic):
+        coeff = 2 * t.coeff if t.rowvar == t.colvar else t.coeff        # :58
+        moi_f.quadratic_terms[i] = (coeff, _vm(varmap, t.rowvar.index), _vm(varmap, t.colvar.index))
+    return moi_f
+
+
+def update_vector_affine(moi_f, fs, varmap=None):                     # src/moi_interop.jl:64-81
+    n = sum(len(f.linear) for f in fs)
+    moi_f.constants = np.zeros(len(fs), dtype=np.float64)
+    moi_f.terms = np.zeros(n, dtype=VAT)
+    i = 0
+    for row, f in enumerate(fs):
+        for t in f.linear:
+            moi_f.terms[i] = (row + 1, t.coeff, _vm(varmap, t.var.index))
+            i += 1
+        moi_f.constants[row] = f.constant
+    return moi_f
+
+
+def canonical_function_kind(kind):                                     # src/moi_interop.jl:96-101
+    if kind in ("var", "lt", "aff", "num"):
+        return "aff"
+    if kind in ("varvec", "affvec"):
+        return "affvec"
+    if kind in ("qt", "quad"):
+        return "quad"
+    raise ArgumentError("no canonical function type for %s" % kind)
+
+
+def _to_native(kind, val):
+    if kind == "aff":
+        return AffineFunction.of(float(val) if _isnum(val) else val)
+    if kind == "quad":
+        return QuadraticFunction.of(val)
+    return [AffineFunction.of(float(v) if _isnum(v) else v) for v in val]
+
+
+class _Record:
+    """Common part of Objective and Constraint (src/moi_interop.jl:113-129, 141-166)."""
+
+    def _setup(self, model, expr):
+        self.model = model
+        self.expr = expr
+        self.isconstant = not isinstance(expr, DeviceNode)                # "it's just a value; not a LazyExpression" (:123)
+        self.dev = None                                                   # device twin of the MOI buffers (set by compile)
+        if self.isconstant:
+            self.kind = canonical_function_kind(kind_of(expr))
+            native = _to_native(self.kind, expr)
+            if self.kind == "aff":
+                self.f = update_scalar_affine(ScalarAffineFunction(), native)
+            elif self.kind == "quad":
+                self.f = update_scalar_quadratic(ScalarQuadraticFunction(), native)
+            else:
+                self.f = update_vector_affine(VectorAffineFunction(), native)
+            self.nrows = len(native) if self.kind == "affvec" else 1
+        else:
+            self.kind = canonical_function_kind(expr.out.kind)
+            self.f = None                                                 # sized by compile()
+            self.nrows = expr.out.rows if self.kind == "affvec" else 1
+
+    # ---- device side of update!(moi_f, expr(), varmap)
+    def compile(self, ctx, varmap_buf, quadratic_mode):
+        """Allocate the MOI buffers (host + device twin) and return the emitter of the MOI copy."""
+        out = self.expr.out
+        if self.kind == "aff":
+            n = out.nterms
+            self.f = ScalarAffineFunction(n)
+            dev_terms = ctx.alloc(16 * max(n, 1))
+            self.dev = {"terms": dev_terms, "const": out.const}
+
+            def emit(c):
+                c.call("pmt_pack_scalar_affine_f64", P(out.terms), n, P(varmap_buf), P(dev_terms))
+            return emit
+        if self.kind == "quad":
+            gram = getattr(self.expr, "gram_candidate", None)
+            literal_terms = out.nq
+            use_gram = gram is not None and gram.xvars.strictly_increasing() and (
+                quadratic_mode == "canonical" or (quadratic_mode == "auto" and literal_terms > (1 << 24)))
+            if use_gram:
+                n = gram.mat.cols
+                nq = n * (n + 1) // 2
+                self.f = ScalarQuadraticFunction(n, nq)
+                dq, dl, dc = ctx.alloc(24 * max(nq, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
+                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(gram.mat.rows, n))))
+                self.dev = {"quad": dq, "lin": dl, "const": dc}
+                self.mode = "canonical"
+                vec = gram.vec.buf if gram.vec is not None else None
+
+                def emit(c):
+                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.rows, gram.mat.rows, n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
+                           1, P(varmap_buf), P(dq), P(dl), P(dc), P(ws))
+                return emit
+            self.mode = "literal"
+            out.materialize()
+            self.f = ScalarQuadraticFunction(out.nl, out.nq)
+            dq, dl = ctx.alloc(24 * max(out.nq, 1)), ctx.alloc(16 * max(out.nl, 1))
+            self.dev = {"quad": dq, "lin": dl, "const": out.const}
+
+            def emit(c):
+                c.call("pmt_pack_scalar_quadratic_f64", P(out.quad), out.nq, P(varmap_buf), P(dq))
+                c.call("pmt_pack_scalar_affine_f64", P(out.lin), out.nl, P(varmap_buf), P(dl))
+            return emit
+        # Vector{AffineFunction}
+        self.f = VectorAffineFunction(out.nterms, out.rows)
+        dt = ctx.alloc(24 * max(out.nterms, 1))
+        if isinstance(out, DDenseAff) and not out.need_terms:
+            dc = ctx.alloc(8 * max(out.rows, 1))
+            self.dev = {"terms": dt, "consts": dc}
+            vec = out.vec.buf if out.vec is not None else None
+
+            def emit(c):
+                c.call("pmt_affine_pack_vector_f64", P(out.mat.buf), out.mat.rows, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec),
+                       out.sign if vec else 0, P(varmap_buf), 0, P(dt), P(dc))
+            return emit
+        if isinstance(out, DVarsAff) and not out.need_terms:
+            dc = ctx.alloc(8 * max(out.rows, 1))
+            self.dev = {"terms": dt, "consts": dc}
+
+            def emit(c):
+                c.call("pmt_vars_addsub_f64", P(out.xvars.buf), out.rows, P(out.vec.buf), out.sign, P(varmap_buf), 0, None, P(dt), P(dc))
+            return emit
+        m = out.materialized()
+        self.dev = {"terms": dt, "consts": m.consts}
+
+        def emit(c):
+            c.call("pmt_pack_vector_affine_f64", P(m.terms), P(m.row_ptr_buf), m.rows, m.row_len, P(varmap_buf), 0, P(dt))
+        return emit
+
+    def fetch(self, ctx):
+        """D2H of the MOI buffers into the host function object (asynchronous; caller synchronises)."""
+        f, d = self.f, self.dev
+        if self.kind == "aff":
+            ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
+            self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
+        elif self.kind == "quad":
+            ctx.fetch(f.quadratic_terms, d["quad"], f.quadratic_terms.nbytes)
+            ctx.fetch(f.affine_terms, d["lin"], f.affine_terms.nbytes)
+            self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
+        else:
+            ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
+            ctx.fetch(f.constants, d["consts"], f.constants.nbytes)
+
+    def finish_fetch(self):
+        if self.kind in ("aff", "quad"):
+            self.f.constant = float(self._c[0])
+
+
+class Objective(_Record):                                                 # src/moi_interop.jl:113-137
+    def __init__(self, model, expr):
+        self._setup(model, expr)
+        if self.kind not in ("aff", "quad"):
+            raise ArgumentError("the objective must be a scalar affine or quadratic function")
+
+
+class Constraint(_Record):                                                # src/moi_interop.jl:141-175
+    def __init__(self, model, expr, set_, function=None):
+        self.set = set_
+        self.modelindex = None
+        self.optimizerindex = None
+        if function is not None:                                          # SingleVariable-in-Integer/ZeroOne (:161-165)
+            self.model, self.expr, self.isconstant, self.kind, self.f, self.nrows, self.dev = model, None, True, "single", function, 1, None
+            return
+        self._setup(model, expr)
+
+    @property
+    def spec(self):
+        fname = {"aff": "scalaraffinefunction", "quad": "scalarquadraticfunction", "affvec": "vectoraffinefunction", "single": "singlevariable"}[self.kind]
+        return fname + "_in_" + type(self.set).__name__.lower()
+
+
+# the 14 typed constraint vectors in the reference's fixed order (src/moi_interop.jl:180-193)
+CONSTRAINT_ORDER = [
+    "scalaraffinefunction_in_greaterthan", "scalaraffinefunction_in_lessthan", "scalaraffinefunction_in_equalto",
+    "vectoraffinefunction_in_nonnegatives", "vectoraffinefunction_in_nonpositives", "vectoraffinefunction_in_zeros",
+    "scalarquadraticfunction_in_greaterthan", "scalarquadraticfunction_in_lessthan", "scalarquadraticfunction_in_equalto",
+    "vectorquadraticfunction_in_nonnegatives", "vectorquadraticfunction_in_nonpositives", "vectorquadraticfunction_in_zeros",
+    "singlevariable_in_integer", "singlevariable_in_zeroone",
+]
+
+
+class Constraints:                                                        # src/moi_interop.jl:195-262
+    def __init__(self):
+        self.by_spec = {name: [] for name in CONSTRAINT_ORDER}
+
+    def push(self, c):
+        if c.spec not in self.by_spec:
+            raise ArgumentError("unsupported constraint type %s" % c.spec)
+        self.by_spec[c.spec].append(c)
+
+    def __iter__(self):                                                    # update! order (:236-247)
+        for name in CONSTRAINT_ORDER:
+            yield from self.by_spec[name]
+
+    def __len__(self):
+        return sum(len(v) for v in self.by_spec.values())
