@@ -13,11 +13,16 @@
 // [128 columns][BK rows]; panels are staged global -> registers -> LDS (double buffered, one barrier per stage)
 // with 16-byte loads along K.  f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4*reg
 // (cdna_hip_programming.md §3 — differs from the f32/bf16 map).  Only tiles with jb <= kb are computed.
+#include <cstring>
+
 #include "common.h"
 
 namespace pmt {
 
 int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s);
+size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
+int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
+                   pmt_quadratic_term *out_quad, void *workspace, hipStream_t s);
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -224,8 +229,7 @@ __global__ __launch_bounds__(256) void gram_linear_kernel(const double *__restri
 using namespace pmt;
 
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
-    (void)rows; (void)cols;
-    return 16;
+    return gram_sk_workspace_bytes(rows, cols);
 }
 
 extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
@@ -246,12 +250,23 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
             g.ntiles = (int)cdiv(cols, GT);
             g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
             const int nblk = g.ntiles * (g.ntiles + 1) / 2;
-            // first measurement (profiles/r01_notes.md): 16x16x4 path 1.85 ms, 4x4x4_4b path 2.56 ms at n = r = 4096 —
-            // the faster instruction loses until the tile loop is restructured (2 waves/SIMD, stream-K balance).
-            static const bool m16 = [] { const char *e = getenv("PMT_GRAM_MFMA4"); return !(e && e[0] == '1'); }();
-            if (m16) PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
-            else PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
-            int rc = check_launch("quad_gram_kernel");
+            // PMT_GRAM_IMPL: "sk" (default) stream-K persistent kernel on the 4x4x4_4b MFMA (gram_sk.hip);
+            // "tiles16" / "tiles4": one workgroup per tile on the 16x16x4 / 4x4x4_4b MFMA (first-round kernels, kept for A/B:
+            // 1.85 ms / 2.56 ms at n = r = 4096, profiles/r01a_*).
+            static const int impl = [] {
+                const char *e = getenv("PMT_GRAM_IMPL");
+                if (e && !strcmp(e, "tiles16")) return 1;
+                if (e && !strcmp(e, "tiles4")) return 2;
+                return 0;
+            }();
+            int rc;
+            if (impl == 0) {
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, workspace, s);
+            } else {
+                if (impl == 1) PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+                else PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+                rc = check_launch("quad_gram_kernel");
+            }
             if (rc) return rc;
             PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
             rc = check_launch("gram_linear_kernel");

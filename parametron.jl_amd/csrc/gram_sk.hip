@@ -1,0 +1,389 @@
+// Canonical least-squares objective, stream-K form: the upper triangle of 2*A'A on v_mfma_f64_4x4x4_4b_f64.
+//
+// Why this shape (measured on MI355X, profiles/r01a_*, r01b_*):
+//   * v_mfma_f64_4x4x4_4b_f64 issues every 16-17 cycles (72.5 TFLOP/s chip-wide), v_mfma_f64_16x16x4_f64 every 138
+//     (34.9 TFLOP/s) — the 4-block form is the full-rate f64 matrix instruction on gfx950.
+//   * 528 tiles of 128x128 on 256 CUs quantise to 3 rounds of 2.06 needed; a persistent grid that splits the
+//     contraction (stream-K) gives every workgroup the same number of (tile, K-chunk) units.
+//   * PMC (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE) showed the matrix pipe idle whenever the waves sharing a SIMD sit
+//     at the same barrier; variant "wg256" therefore runs TWO independent 4-wave workgroups per CU (one wave per SIMD
+//     each, 64x64 wave tiles) so that one workgroup's load/store/barrier phase overlaps the other's MFMA phase, while
+//     "wg512" runs one 8-wave workgroup (64x32 wave tiles).
+// Work unit = (tile, K-chunk of KC rows).  Units are numbered tile-major and dealt out in contiguous, equal ranges to
+// G persistent workgroups.  A workgroup that covers all chunks of a tile writes the QuadraticTerms directly (fused
+// epilogue: x2, canonical upper-triangular position, varmap); otherwise it stores its partial accumulators in a
+// workspace slot and `gram_sk_fixup_kernel` adds the partials of each split tile in ascending workgroup order
+// (deterministic) and writes the terms.  At the BASELINE size (n = r = 4096: 528 tiles x 16 chunks = 8448 units, 33 or
+// 16.5 per workgroup) every tile is touched by at most two (three) workgroups.
+//
+// Operand lane maps of the 4x4x4_4b form were probed on hardware (tools/mfma_probe.hip):
+//   A: lane = i + 4b + 16k    B: lane = j + 4b + 16k    D: lane = j + 4b + 16i     (block b, 4x4 tile, k = 0..3)
+// i.e. A/B registers look like those of the 16x16x4 form (row|col = lane & 15, k = lane >> 4); block b pairs row group b
+// with column group b, so the 16 (row group, column group) pairs of a 16x16 tile take 4 instructions whose B operand is read
+// from LDS with the column groups rotated by s = 0..3 (cbsz/abid broadcast is ignored for f64: tools/mfma_probe2.hip).
+// acc[tm][tn][s] of lane l = C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
+#include "common.h"
+
+namespace pmt {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+constexpr int ST = 128;            // output tile edge
+constexpr int SKC = 256;           // contraction depth per work unit
+constexpr int MAXG = 512;          // upper bound on persistent workgroups
+constexpr int SLOT = ST * ST;      // doubles per partial-tile slot
+
+struct SKArgs {
+    const double *A; int64_t lda, rows, cols;
+    const int64_t *xvar; const int64_t *varmap; int moi;
+    QT *out_quad;
+    int ntiles, nchunk, G;
+    int64_t U;
+    int vec_in;
+    double *ws;
+};
+
+// TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
+template <int TN>
+struct Cfg {
+    static constexpr int NW = (TN == 4) ? 4 : 8;
+    static constexpr int NT = NW * 64;
+    static constexpr int WCOLS = 16 * TN;             // columns per wave
+    static constexpr int NWC = ST / WCOLS;            // waves along N
+    static constexpr int NACC = 4 * TN * 4;           // fp64 accumulators per lane
+    static constexpr int NLD = (ST * 8) / NT;         // 16-byte pieces per thread per panel per 16 rows
+};
+
+__device__ __forceinline__ void sk_tri_unrank(int t, int nt, int &jb, int &kb) {
+    int j = (int)((2.0 * nt + 1.0 - sqrt((2.0 * nt + 1.0) * (2.0 * nt + 1.0) - 8.0 * (double)t)) * 0.5);
+    if (j < 0) j = 0;
+    if (j > nt - 1) j = nt - 1;
+    while (j > 0 && (j * nt - j * (j - 1) / 2) > t) --j;
+    while (j + 1 < nt && ((j + 1) * nt - (j + 1) * j / 2) <= t) ++j;
+    jb = j;
+    kb = j + (t - (j * nt - j * (j - 1) / 2));
+}
+
+__device__ __forceinline__ int64_t sk_unit_begin(const SKArgs &g, int b) { return (int64_t)b * g.U / g.G; }
+
+// (row, col) inside the 128x128 tile of accumulator r = (tm*TN + tn)*4 + s of thread tid
+template <int TN>
+__device__ __forceinline__ void sk_acc_pos(int tid, int r, int &row, int &col) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / Cfg<TN>::NWC, wc = wave % Cfg<TN>::NWC;
+    const int tm = r / (4 * TN), tn = (r / 4) % TN, s = r & 3;
+    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+    row = wr * 64 + tm * 16 + 4 * b + i;
+    col = wc * Cfg<TN>::WCOLS + tn * 16 + 4 * ((b + s) & 3) + j;
+}
+
+// 2*acc -> QuadraticTerm at the canonical upper-triangular position
+__device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, int row, int col, double v) {
+    const int64_t n = g.cols;
+    const int64_t j = (int64_t)jb * ST + row, k = (int64_t)kb * ST + col;
+    if (k >= n || j >= n || j > k) return;
+    const int64_t jv = g.xvar[j], kv = g.xvar[k];
+    double c = v;
+    if (g.moi || j != k) c = 2 * c;          // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
+    const int64_t pos = j * n - (j * (j - 1)) / 2 + (k - j);
+    u64 *p = reinterpret_cast<u64 *>(g.out_quad) + pos * 3;
+    p[0] = (u64)__double_as_longlong(c);
+    p[1] = (u64)(g.moi ? map_var(g.varmap, jv) : jv);
+    p[2] = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
+}
+
+// Tile epilogue through LDS: accumulators -> smem[64][129] (half a tile at a time) -> row-contiguous QuadraticTerm runs.
+// For output row j the tile's entries k = max(j, k0) .. k0+127 are consecutive terms of the canonical upper triangle, so
+// each wave writes whole row segments as 16-byte chunks (global_store_dwordx4) instead of three scattered 8-byte stores
+// per element; the mapped variable indices of the tile's 128 columns / 64 rows are gathered once into LDS.
+// smem must hold 64*129 + 192 doubles; all threads of the workgroup call this together.
+constexpr int EPITCH = 129;
+constexpr int EPI_DOUBLES = 64 * EPITCH + 192;
+
+template <int TN>
+__device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int tid) {
+    using C = Cfg<TN>;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const int64_t n = g.cols;
+    const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
+    double *tile = smem;
+    u64 *cmap = reinterpret_cast<u64 *>(smem + 64 * EPITCH);
+    u64 *rmap = cmap + 128;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wr = wave / C::NWC;
+    u64 *out = reinterpret_cast<u64 *>(g.out_quad);
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (h == 0 && tid < 128) {
+            const int64_t k = k0 + tid;
+            const int64_t kv = k < n ? g.xvar[k] : 1;
+            cmap[tid] = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
+        }
+        if (tid >= 128 && tid < 192) {
+            const int64_t j = j0 + h * 64 + (tid - 128);
+            const int64_t jv = j < n ? g.xvar[j] : 1;
+            rmap[tid - 128] = (u64)(g.moi ? map_var(g.varmap, jv) : jv);
+        }
+        if (wr == h) {
+#pragma unroll
+            for (int r = 0; r < C::NACC; ++r) {
+                int row, col;
+                sk_acc_pos<TN>(tid, r, row, col);
+                double c = acc[r];
+                if (g.moi || (j0 + row) != (k0 + col)) c = 2 * c;   // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling
+                tile[(row - h * 64) * EPITCH + col] = c;
+            }
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += C::NW) {
+            const int64_t j = j0 + h * 64 + row;
+            if (j >= n) break;
+            const int64_t kstart = j > k0 ? j : k0;
+            const int64_t kend = (k0 + ST < n) ? k0 + ST : n;
+            const int nterms = (int)(kend - kstart);
+            if (nterms <= 0) continue;
+            const int coff = (int)(kstart - k0);
+            const int64_t term0 = j * n - (j * (j - 1)) / 2 + (kstart - j);
+            u64 *seg = out + term0 * 3;
+            const int nwords = nterms * 3;
+            const int lead = (int)((reinterpret_cast<uintptr_t>(seg) >> 3) & 1);
+            const double *trow = tile + row * EPITCH + coff;
+            const u64 rv = rmap[row];
+            auto word = [&](int q) -> u64 {
+                const int t = q / 3, f = q - 3 * t;
+                return f == 0 ? (u64)__double_as_longlong(trow[t]) : (f == 1 ? rv : cmap[coff + t]);
+            };
+            if (lead && lane == 0) seg[0] = word(0);
+            for (int c = lane; lead + 2 * c < nwords; c += 64) {
+                const int q0 = lead + 2 * c;
+                if (q0 + 1 < nwords) {
+                    u64x2 v;
+                    v.x = word(q0);
+                    v.y = word(q0 + 1);
+                    *reinterpret_cast<u64x2 *>(seg + q0) = v;
+                } else {
+                    seg[q0] = word(q0);
+                }
+            }
+        }
+    }
+}
+
+template <int TN, int BK>
+__device__ __forceinline__ void sk_load_panel(const SKArgs &g, int64_t c0, int64_t i0, int64_t iend,
+                                              f64x2 (&reg)[Cfg<TN>::NLD * (BK / 16)], int tid, bool fast) {
+    constexpr int KP = BK / 2;                         // 16-byte pieces per column
+    constexpr int CPP = Cfg<TN>::NT / KP;              // columns covered per pass
+    const int kp = tid % KP, cc = tid / KP;
+#pragma unroll
+    for (int p = 0; p < ST / CPP; ++p) {
+        const int64_t col = c0 + cc + CPP * p;
+        const int64_t row = i0 + 2 * kp;
+        const double *src = g.A + col * g.lda + row;
+        f64x2 v;
+        if (fast) {
+            v = *reinterpret_cast<const f64x2 *>(src);
+        } else {
+            v.x = 0.0; v.y = 0.0;
+            if (col < g.cols) {
+                if (g.vec_in && row + 1 < iend) v = *reinterpret_cast<const f64x2 *>(src);
+                else {
+                    if (row < iend) v.x = src[0];
+                    if (row + 1 < iend) v.y = src[1];
+                }
+            }
+        }
+        reg[p] = v;
+    }
+}
+// The LDS pitch BK+1 is odd so that the 16 columns a half-wave reads for one k land on 16 distinct bank pairs
+// (ds_read_b64 / ds_read2_b64); the price is 8-byte instead of 16-byte LDS stores.
+template <int TN, int BK>
+__device__ __forceinline__ void sk_store_panel(double *panel, const f64x2 (&reg)[Cfg<TN>::NLD * (BK / 16)], int tid) {
+    constexpr int KP = BK / 2;
+    constexpr int CPP = Cfg<TN>::NT / KP;
+    const int kp = tid % KP, cc = tid / KP;
+#pragma unroll
+    for (int p = 0; p < ST / CPP; ++p) {
+        double *d = panel + (cc + CPP * p) * (BK + 1) + 2 * kp;
+        d[0] = reg[p].x;
+        d[1] = reg[p].y;
+    }
+}
+
+// ABL: ablation switch for profiling only (0 = the kernel; 1 = no LDS operand reads; 2 = no global loads / LDS stores).
+// Results are wrong for ABL != 0; selected with PMT_GRAM_SK_ABLATE.
+template <int TN, int BK, int WPS, int ABL>
+__global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
+    using C = Cfg<TN>;
+    constexpr int GP = BK + 1;
+    constexpr int NREG = C::NLD * (BK / 16);
+    __shared__ double lds[2][2][ST * GP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / C::NWC, wc = wave % C::NWC;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int bid = blockIdx.x;
+    const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
+
+    for (int64_t u = u0; u < u1;) {
+        const int tile = (int)(u / g.nchunk);
+        const int c0 = (int)(u - (int64_t)tile * g.nchunk);
+        const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
+        int jb, kb;
+        sk_tri_unrank(tile, g.ntiles, jb, kb);
+        const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
+        const bool diag = (jb == kb);
+        const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
+
+        double acc[C::NACC];
+#pragma unroll
+        for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
+
+        const int nstage = (int)((iend - ibeg + BK - 1) / BK);
+        const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
+        f64x2 rj[NREG], rk[NREG];
+        __syncthreads();                                   // previous segment's readers are done with both buffers
+        if (nstage > 0) {
+            sk_load_panel<TN, BK>(g, j0, ibeg, iend, rj, tid, fast);
+            if (!diag) sk_load_panel<TN, BK>(g, k0, ibeg, iend, rk, tid, fast);
+            sk_store_panel<TN, BK>(lds[0][0], rj, tid);
+            if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
+        }
+        __syncthreads();
+        for (int s = 0; s < nstage; ++s) {
+            const int cur = s & 1;
+            if (ABL != 2 && s + 1 < nstage) {
+                const int64_t inext = ibeg + (int64_t)(s + 1) * BK;
+                sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
+                if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
+            }
+            const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
+            const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
+            // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
+            // a whole stage ahead (fully unrolled it spills ~100 VGPRs)
+#pragma unroll(TN == 4 ? 1 : BK / 4)
+            for (int ks = 0; ks < BK / 4; ++ks) {
+                double a[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[t] = (ABL == 1) ? (double)(tid + t) : pj[t * 16 * GP + ks * 4];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    double b[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
+                        b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
+                    }
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
+                }
+            }
+            if (ABL != 2 && s + 1 < nstage) {
+                sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
+                if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
+            }
+            __syncthreads();
+        }
+
+        if (c0 == 0 && c1 == g.nchunk) {
+            static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
+            sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+        } else {
+            // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
+            const int slot = 2 * bid + (u == u0 ? 0 : 1);
+            double *w = g.ws + (int64_t)slot * SLOT + tid;
+#pragma unroll
+            for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+        }
+        u += (c1 - c0);
+    }
+}
+
+// one workgroup per tile: if the tile was split, add its partials in ascending workgroup order and write the terms
+template <int TN>
+__global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
+    using C = Cfg<TN>;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t ub = (int64_t)tile * g.nchunk, ue = ub + g.nchunk - 1;       // first / last unit of this tile
+    auto owner = [&](int64_t u) {
+        int b = (int)((u * g.G) / g.U);
+        if (b >= g.G) b = g.G - 1;
+        while (b + 1 < g.G && sk_unit_begin(g, b + 1) <= u) ++b;
+        while (b > 0 && sk_unit_begin(g, b) > u) --b;
+        return b;
+    };
+    const int blo = owner(ub), bhi = owner(ue);
+    if (blo == bhi) return;                                                   // one workgroup did the whole tile
+    double acc[C::NACC];
+#pragma unroll
+    for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
+    for (int b = blo; b <= bhi; ++b) {
+        const int64_t bu0 = sk_unit_begin(g, b);
+        const int first_tile = (int)(bu0 / g.nchunk);
+        const int slot = 2 * b + (first_tile == tile ? 0 : 1);
+        const double *w = g.ws + (int64_t)slot * SLOT + tid;
+#pragma unroll
+        for (int r = 0; r < C::NACC; ++r) acc[r] = acc[r] + w[r * C::NT];
+    }
+    int jb, kb;
+    sk_tri_unrank(tile, g.ntiles, jb, kb);
+    __shared__ double smem[EPI_DOUBLES];
+    sk_epilogue<TN>(g, jb, kb, acc, smem, tid);
+}
+
+size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
+    (void)rows; (void)cols;
+    return (size_t)MAXG * 2 * SLOT * sizeof(double);
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
+                   pmt_quadratic_term *out_quad, void *workspace, hipStream_t s) {
+    SKArgs g;
+    g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
+    g.ntiles = (int)cdiv(cols, ST);
+    g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
+    const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;
+    g.U = T * g.nchunk;
+    // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16;
+    //          2 = wg512 with BK 32
+    static const int variant = env_int("PMT_GRAM_SK_VARIANT", 1);   // measured equal within noise (profiles/r01b_gram_variants.txt)
+    static const int abl = env_int("PMT_GRAM_SK_ABLATE", 0);
+    static const int gdef = env_int("PMT_GRAM_SK_BLOCKS", 0);
+    const int gwant = gdef > 0 ? gdef : (variant == 0 ? 512 : 256);
+    g.G = (int)std::min<int64_t>(g.U, std::min(gwant, MAXG));
+    g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+    g.ws = reinterpret_cast<double *>(workspace);
+    if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
+    const dim3 grid((unsigned)g.G);
+#define SK_LAUNCH(TN, BK, WPS)                                                                                              \
+    do {                                                                                                                    \
+        if (abl == 1) PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
+        else if (abl == 2) PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
+    } while (0)
+    if (variant == 0) SK_LAUNCH(4, 16, 2);
+    else if (variant == 1) SK_LAUNCH(2, 16, 2);
+    else SK_LAUNCH(2, 32, 2);
+#undef SK_LAUNCH
+    int rc = check_launch("gram_sk_kernel");
+    if (rc) return rc;
+    if (g.nchunk > 1) {
+        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<4>, dim3((unsigned)T), dim3(Cfg<4>::NT), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<2>, dim3((unsigned)T), dim3(Cfg<2>::NT), 0, s, g);
+        rc = check_launch("gram_sk_fixup_kernel");
+    }
+    return rc;
+}
+
+}  // namespace pmt
