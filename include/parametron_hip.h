@@ -218,10 +218,28 @@ int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *perm, const i
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Batched independent QPs (BASELINE config 4).  In the reference a batch is many independent Models (src/model.jl:1-22); all
+ * instances share one structure, so per re-evaluation only coefficients are produced: one slab of
+ * pmt_batch_lsq_slab_doubles(n, m) doubles per instance,
+ *     [ Q: n(n+1)/2 | q: n | const: 1 | C: m*n row-major | d-consts: m ],
+ * = the coefficients of the canonical MOI objective of residual . residual (Appendix A.3) and of the constraint block
+ * C*x (+|-) d (Appendix A.4).  Inputs are instance-major: A[B][r*n] column-major, b[B][r], C[B][m*n] column-major, d[B][m].
+ * pmt_batch_expand_f64 rebuilds the full MOI term buffers (with indices through xvar / varmap) of ONE instance from its slab.
+ * ------------------------------------------------------------------------------------- */
+int64_t pmt_batch_lsq_slab_doubles(int64_t n, int64_t m);
+int pmt_batch_lsq_coeffs_f64(const double *A, const double *b, const double *C, const double *d, int64_t B, int64_t n, int64_t r,
+                             int64_t m, int sign_b, int sign_d, double *out, int64_t out_stride, void *stream);
+int pmt_batch_expand_f64(const double *slab, int64_t n, int64_t m, const int64_t *xvar, const int64_t *varmap,
+                         pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
+                         pmt_vector_affine_term *out_vat, double *out_vconsts, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Device-side Parameter update callbacks for synthetic inputs (counter-based):
  * dst[i] = scale * U[0,1)(seed, i)   — the analogue of `Parameter(rand!, zeros(n, n), model)` README.md:36-43
  * ------------------------------------------------------------------------------------- */
 int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, void *stream);
+/* the same stream from element index_offset on: dst[i] = scale * U(seed, index_offset + i) (shard of a larger array) */
+int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed, uint64_t index_offset, double scale, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-kernel timing report — the device analogue of `findallocs` (src/debug.jl:4-23), which walks the DAG and

@@ -67,8 +67,12 @@ SIGNATURES = {
     "pmt_pack_vector_affine_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "pmt_batch_lsq_slab_doubles": (_i64, [_i64, _i64]),
+    "pmt_batch_lsq_coeffs_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
+    "pmt_batch_expand_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_consts_f64": (_ci, [_vp, _i64, _ci, _vp, _vp]),
     "pmt_fill_uniform_f64": (_ci, [_vp, _i64, _u64, _f64, _vp]),
+    "pmt_fill_uniform_offset_f64": (_ci, [_vp, _i64, _u64, _u64, _f64, _vp]),
     "pmt_profile_enable": (_ci, [_ci]),
     "pmt_profile_report": (_i64, [C.c_char_p, _sz]),
     "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),

@@ -212,18 +212,177 @@ __device__ __forceinline__ void sk_store_panel(double *panel, const f64x2 (&reg)
     }
 }
 
+// acc = sum over rows [ibeg, iend) of A[i, j0 + .]' * A[i, k0 + .] for this thread's accumulators of the 128x128 tile.
+// K-contiguous column panels go global -> registers -> LDS (double buffered, one barrier per BK rows).
 // ABL: ablation switch for profiling only (0 = the kernel; 1 = no LDS operand reads; 2 = no global loads / LDS stores).
-// Results are wrong for ABL != 0; selected with PMT_GRAM_SK_ABLATE.
+template <int TN, int BK, int ABL>
+__device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64_t k0, bool diag, int64_t ibeg, int64_t iend,
+                                              double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
+    using C = Cfg<TN>;
+    constexpr int GP = BK + 1;
+    constexpr int NREG = C::NLD * (BK / 16);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / C::NWC, wc = wave % C::NWC;
+    const int lm = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
+
+    const int nstage = (int)((iend - ibeg + BK - 1) / BK);
+    const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
+    f64x2 rj[NREG], rk[NREG];
+    __syncthreads();                                   // previous users of the LDS buffers are done
+    if (nstage > 0) {
+        sk_load_panel<TN, BK>(g, j0, ibeg, iend, rj, tid, fast);
+        if (!diag) sk_load_panel<TN, BK>(g, k0, ibeg, iend, rk, tid, fast);
+        sk_store_panel<TN, BK>(lds[0][0], rj, tid);
+        if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        if (ABL != 2 && s + 1 < nstage) {
+            const int64_t inext = ibeg + (int64_t)(s + 1) * BK;
+            sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
+            if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
+        }
+        const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
+        const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
+        // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
+        // a whole stage ahead (fully unrolled it spills ~100 VGPRs)
+#pragma unroll(TN == 4 ? 1 : BK / 4)
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double a[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = (ABL == 1) ? (double)(tid + t) : pj[t * 16 * GP + ks * 4];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                double b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
+                    b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
+                }
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
+            }
+        }
+        if (ABL != 2 && s + 1 < nstage) {
+            sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
+            if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- batched instances (BASELINE config 4): one workgroup per (instance, tile), coefficient-only output ----------------
+// out[inst*out_stride + tri(j,k)] = 2 * sum_i A_inst[i,j] * A_inst[i,k]   (the MOI coefficient of the canonical term (j,k); the
+// index arrays are identical for every instance and are not rewritten).
+struct BatchGramArgs {
+    const double *A; int64_t lda, rows, cols, strideA;
+    double *out; int64_t out_stride;
+    int ntiles, vec_in;
+};
+
+__global__ __launch_bounds__(Cfg<2>::NT, 2) void batch_gram_kernel(BatchGramArgs bg) {
+    constexpr int TN = 2, BK = 16;
+    using C = Cfg<TN>;
+    __shared__ double lds[2][2][ST * (BK + 1)];
+    const int tid = threadIdx.x;
+    const int64_t inst = blockIdx.y;
+    SKArgs g;
+    g.A = bg.A + inst * bg.strideA; g.lda = bg.lda; g.rows = bg.rows; g.cols = bg.cols; g.vec_in = bg.vec_in;
+    int jb, kb;
+    sk_tri_unrank((int)blockIdx.x, bg.ntiles, jb, kb);
+    double acc[C::NACC];
+    sk_accumulate<TN, BK, 0>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, bg.rows, acc, lds, tid);
+    // stage through LDS so that each output row segment is written contiguously (8 bytes per entry)
+    double *tile = &lds[0][0][0];
+    const int wave = tid >> 6, lane = tid & 63, wr = wave / C::NWC;
+    const int64_t n = bg.cols, j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
+    double *out = bg.out + inst * bg.out_stride;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
+#pragma unroll
+            for (int r = 0; r < C::NACC; ++r) {
+                int row, col;
+                sk_acc_pos<TN>(tid, r, row, col);
+                tile[(row - h * 64) * EPITCH + col] = 2 * acc[r];
+            }
+        }
+        __syncthreads();
+        for (int row = wave; row < 64; row += C::NW) {
+            const int64_t j = j0 + h * 64 + row;
+            if (j >= n) break;
+            const int64_t kstart = j > k0 ? j : k0;
+            const int64_t kend = (k0 + ST < n) ? k0 + ST : n;
+            const int64_t term0 = j * n - (j * (j - 1)) / 2 + (kstart - j);
+            for (int64_t k = kstart + lane; k < kend; k += 64) out[term0 + (k - kstart)] = tile[row * EPITCH + (k - k0)];
+        }
+    }
+}
+
+// out[inst*out_stride + j] = 2 * sum_i c_i * A_inst[i,j], c_i = 0.0 (+|-) b_inst[i]; one wave per (instance, column)
+__global__ __launch_bounds__(256) void batch_gram_linear_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                                                int64_t strideA, const double *__restrict__ b, int64_t strideb, int sign,
+                                                                double *__restrict__ out, int64_t out_stride) {
+    const int64_t inst = blockIdx.y;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= cols) return;
+    const int lane = threadIdx.x & 63;
+    const double *a = A + inst * strideA + col * lda;
+    const double *bb = b + inst * strideb;
+    double acc = 0.0;
+    for (int64_t i = lane; i < rows; i += 64) acc += signed_const(bb[i], sign) * a[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) out[inst * out_stride + col] = 2 * acc;
+}
+
+// out[inst*out_stride] = ((0 + c_0^2) + c_1^2) + ... left to right (src/functions.jl:574); one thread per instance
+__global__ void batch_const_kernel(const double *__restrict__ b, int64_t strideb, int64_t rows, int sign, int64_t B,
+                                   double *__restrict__ out, int64_t out_stride) {
+    const int64_t inst = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= B) return;
+    const double *bb = b + inst * strideb;
+    double acc = 0.0;
+    for (int64_t i = 0; i < rows; ++i) {
+        const double c = signed_const(bb[i], sign);
+        const double p = c * c;
+        acc = acc + p;
+    }
+    out[inst * out_stride] = acc;
+}
+
+int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
+                      int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride, hipStream_t s) {
+    BatchGramArgs bg;
+    bg.A = A; bg.lda = lda; bg.rows = rows; bg.cols = cols; bg.strideA = strideA; bg.out = out_q; bg.out_stride = out_stride;
+    bg.ntiles = (int)cdiv(cols, ST);
+    bg.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (strideA & 1) == 0) ? 1 : 0;
+    const int T = bg.ntiles * (bg.ntiles + 1) / 2;
+    for (int64_t i0 = 0; i0 < B; i0 += 65535) {                 // gridDim.y limit
+        const unsigned nb = (unsigned)std::min<int64_t>(65535, B - i0);
+        BatchGramArgs part = bg;
+        part.A = A + i0 * strideA; part.out = out_q + i0 * out_stride;
+        PMT_LAUNCH(batch_gram_kernel, dim3((unsigned)T, nb), dim3(Cfg<2>::NT), 0, s, part);
+        PMT_LAUNCH(batch_gram_linear_kernel, dim3((unsigned)cdiv(cols, 4), nb), dim3(256), 0, s, A + i0 * strideA, lda, rows, cols, strideA,
+                   b + i0 * strideb, strideb, sign, out_lin + i0 * out_stride, out_stride);
+    }
+    PMT_LAUNCH(batch_const_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, s, b, strideb, rows, sign, B, out_const, out_stride);
+    return check_launch("batch_gram");
+}
+
+// ABL: ablation switch for profiling only; results are wrong for ABL != 0; selected with PMT_GRAM_SK_ABLATE.
 template <int TN, int BK, int WPS, int ABL>
 __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
     using C = Cfg<TN>;
     constexpr int GP = BK + 1;
-    constexpr int NREG = C::NLD * (BK / 16);
     __shared__ double lds[2][2][ST * GP];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / C::NWC, wc = wave % C::NWC;
-    const int lm = lane & 15, lk = lane >> 4;
     const int bid = blockIdx.x;
     const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
 
@@ -238,57 +397,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
         const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
 
         double acc[C::NACC];
-#pragma unroll
-        for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
-
-        const int nstage = (int)((iend - ibeg + BK - 1) / BK);
-        const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
-        f64x2 rj[NREG], rk[NREG];
-        __syncthreads();                                   // previous segment's readers are done with both buffers
-        if (nstage > 0) {
-            sk_load_panel<TN, BK>(g, j0, ibeg, iend, rj, tid, fast);
-            if (!diag) sk_load_panel<TN, BK>(g, k0, ibeg, iend, rk, tid, fast);
-            sk_store_panel<TN, BK>(lds[0][0], rj, tid);
-            if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
-        }
-        __syncthreads();
-        for (int s = 0; s < nstage; ++s) {
-            const int cur = s & 1;
-            if (ABL != 2 && s + 1 < nstage) {
-                const int64_t inext = ibeg + (int64_t)(s + 1) * BK;
-                sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
-                if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
-            }
-            const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
-            const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
-            // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
-            // a whole stage ahead (fully unrolled it spills ~100 VGPRs)
-#pragma unroll(TN == 4 ? 1 : BK / 4)
-            for (int ks = 0; ks < BK / 4; ++ks) {
-                double a[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a[t] = (ABL == 1) ? (double)(tid + t) : pj[t * 16 * GP + ks * 4];
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    double b[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
-                        b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
-                    }
-#pragma unroll
-                    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
-                }
-            }
-            if (ABL != 2 && s + 1 < nstage) {
-                sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
-                if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
-            }
-            __syncthreads();
-        }
+        sk_accumulate<TN, BK, ABL>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
 
         if (c0 == 0 && c1 == g.nchunk) {
             static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");

@@ -23,6 +23,20 @@ __global__ void fill_uniform_kernel(double *__restrict__ dst, int64_t n, uint64_
 
 using namespace pmt;
 
+// Same stream starting at element `index_offset`: dst[i] = scale * U(seed, index_offset + i).  Lets a shard of a larger
+// array be generated independently of how the array is partitioned across GPUs (batched instances, config 4).
+extern "C" int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed, uint64_t index_offset, double scale, void *stream) {
+    PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "fill_uniform: negative length");
+    if (n == 0) return PMT_OK;
+    PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform: null pointer");
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + index_offset;
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
+        PMT_LAUNCH(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
+        return check_launch("fill_uniform_kernel");
+    });
+}
+
 extern "C" int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, void *stream) {
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "fill_uniform: negative length");
     if (n == 0) return PMT_OK;

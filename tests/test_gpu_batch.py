@@ -1,0 +1,69 @@
+"""-m gpu: batched instances (BASELINE config 4) — every instance's slab expands to exactly the buffers the single-instance
+entry points produce for that instance (bit-exact: same contraction order), and to the oracle within 1e-12."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+
+def test_batch_slabs_match_single_instance_path_and_oracle():
+    import gpu_util as g
+    from parametron_jl_amd import batch
+    total, n, r, m = 12, 128, 96, 16
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.compute()
+    torch.cuda.synchronize()
+    off, L = batch.slab_layout(n, m)
+    assert L == g.lib().pmt_batch_lsq_slab_doubles(n, m)
+    xvar = torch.arange(1, n + 1, dtype=torch.int64, device=g.DEV)
+    varmap = torch.from_numpy(np.random.default_rng(0).permutation(n).astype(np.int64) + 1).to(g.DEV)
+    nq = n * (n + 1) // 2
+    for inst in (0, 5, total - 1):
+        A = wl.A[inst * r * n:(inst + 1) * r * n]
+        b = wl.b[inst * r:(inst + 1) * r]
+        Cm = wl.Cm[inst * m * n:(inst + 1) * m * n]
+        d = wl.d[inst * m:(inst + 1) * m]
+        # the data of instance k does not depend on the sharding: global element index drives the stream
+        assert g.same_bits(A.cpu().numpy(), O.fill_uniform((inst + 1) * r * n, 101)[inst * r * n:])
+        oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+        ov, ovc = g.empty_terms(m * n, g.VAT), g.empty_f64(m)
+        g.call("pmt_batch_expand_f64", g.ptr(wl.local[inst]), n, m, g.ptr(xvar), g.ptr(varmap), g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ov),
+               g.ptr(ovc), g.stream())
+        sq, sl, sc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+        ws = g.empty_f64(g.lib().pmt_quad_gram_workspace_bytes(r, n) // 8)
+        g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, 1, g.ptr(varmap), g.ptr(sq), g.ptr(sl), g.ptr(sc), g.ptr(ws), g.stream())
+        sv, svc = g.empty_terms(m * n, g.VAT), g.empty_f64(m)
+        g.call("pmt_affine_pack_vector_f64", g.ptr(Cm), m, m, n, g.ptr(xvar), g.ptr(d), -1, g.ptr(varmap), 0, g.ptr(sv), g.ptr(svc), g.stream())
+        g.assert_terms_equal(g.terms_to_host(oq, nq, g.QT), g.terms_to_host(sq, nq, g.QT))
+        g.assert_terms_equal(g.terms_to_host(ol, n, g.LT), g.terms_to_host(sl, n, g.LT))
+        assert g.same_bits(g.f64_to_host(oc, 1), g.f64_to_host(sc, 1))
+        g.assert_terms_equal(g.terms_to_host(ov, m * n, g.VAT), g.terms_to_host(sv, m * n, g.VAT))
+        assert g.same_bits(g.f64_to_host(ovc, m), g.f64_to_host(svc, m))
+        # and against numpy on the host copy (tolerance of north_star)
+        Ah = A.cpu().numpy().reshape(n, r).T
+        bh = b.cpu().numpy()
+        slab = wl.local[inst].cpu().numpy()
+        np.testing.assert_allclose(slab[:nq], (2 * Ah.T @ Ah)[np.triu_indices(n)], rtol=1e-12)
+        np.testing.assert_allclose(slab[off["q"]:off["q"] + n], -2 * Ah.T @ bh, rtol=1e-12)
+        assert slab[off["const"]] == pytest.approx(bh @ bh, rel=1e-14)
+        assert np.array_equal(slab[off["C"]:off["C"] + m * n].reshape(m, n), Cm.cpu().numpy().reshape(n, m).T)
+        assert np.array_equal(slab[off["dconst"]:], 0.0 - d.cpu().numpy())
+
+
+def test_batch_sharding_is_data_independent():
+    from parametron_jl_amd import batch
+    total, n, r, m = 8, 128, 128, 16
+    whole = batch.BatchLSQ(torch, total, n, r, m)
+    whole.compute()
+    parts = []
+    for rank in range(4):
+        p = batch.BatchLSQ(torch, total, n, r, m, rank=rank, world=4)
+        p.compute()
+        parts.append(p.local.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), whole.local)
