@@ -214,6 +214,9 @@ int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *host_colptr, 
 int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *perm, const int64_t *term_row, const int64_t *term_var,
                                int64_t nnz, const int64_t *varmap, int64_t row_offset,
                                pmt_vector_affine_term *out_terms, void *stream);
+/* native form of the same node (Vector{AffineFunction} with ragged rows): out[t] = (nzval[perm[t]], term_var[t]) */
+int pmt_sparse_assemble_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, int64_t nnz,
+                            pmt_linear_term *out_terms, void *stream);
 /* constants: out[i] = 0.0 (+|-) d[i] */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 

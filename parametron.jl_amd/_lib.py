@@ -66,6 +66,7 @@ SIGNATURES = {
     "pmt_pack_scalar_quadratic_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),
     "pmt_pack_vector_affine_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_sparse_assemble_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "pmt_batch_lsq_slab_doubles": (_i64, [_i64, _i64]),
     "pmt_batch_lsq_coeffs_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _i64, _vp]),

@@ -25,9 +25,33 @@ __global__ void sparse_pack_vector_kernel(const double *__restrict__ nzval, cons
     }
 }
 
+// native (LinearTerm) form of the same node: out[t] = (nzval[perm[t]], term_var[t]); rows are ragged (row_ptr from the plan)
+__global__ void sparse_assemble_kernel(const double *__restrict__ nzval, const int64_t *__restrict__ perm,
+                                       const int64_t *__restrict__ term_var, int64_t nnz, LT *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += stride) {
+        LT o;
+        o.coeff = nzval[perm[t]];
+        o.var = term_var[t];
+        out[t] = o;
+    }
+}
+
 }  // namespace pmt
 
 using namespace pmt;
+
+extern "C" int pmt_sparse_assemble_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, int64_t nnz,
+                                       pmt_linear_term *out_terms, void *stream) {
+    PMT_REQUIRE(nnz >= 0, PMT_DIMENSION_MISMATCH, "sparse_assemble: negative nnz");
+    if (nnz == 0) return PMT_OK;
+    PMT_REQUIRE(nzval && perm && term_var && out_terms, PMT_INVALID_ARGUMENT, "sparse_assemble: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(nnz, 256), 256 * 8);
+        PMT_LAUNCH(sparse_assemble_kernel, dim3(blocks), dim3(256), 0, s, nzval, perm, term_var, nnz, out_terms);
+        return check_launch("sparse_assemble_kernel");
+    });
+}
 
 extern "C" int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int64_t *perm,
                                          int64_t *rows_out, int64_t *cols_out, int64_t *row_ptr) {

@@ -234,6 +234,61 @@ class DVarsAff(DAffVec):
         return self.require_terms()
 
 
+class DSpMat(DV):
+    """SparseMatrixCSC{Float64,Int64} with a FIXED pattern: only nzval lives on the device per re-evaluation; the row-major
+    order of the structural non-zeros (perm, term_row, term_col, row_ptr) is computed once (pmt_sparse_rowmajor_order)."""
+    kind = "spmat"
+
+    def __init__(self, ctx, csc):
+        import ctypes as C
+        self.rows, self.cols = csc.shape
+        self.nnz = int(csc.nnz)
+        colptr = np.ascontiguousarray(csc.indptr, dtype=np.int64) + 1            # Julia 1-based
+        rowval = np.ascontiguousarray(csc.indices, dtype=np.int64) + 1
+        self.indptr, self.indices = csc.indptr.copy(), csc.indices.copy()
+        self.perm = np.empty(self.nnz, dtype=np.int64)
+        self.term_row = np.empty(self.nnz, dtype=np.int64)
+        self.term_col = np.empty(self.nnz, dtype=np.int64)
+        self.row_ptr = np.empty(self.rows + 1, dtype=np.int64)
+        vp = C.c_void_p
+        _lib.call("pmt_sparse_rowmajor_order", self.rows, self.cols, colptr.ctypes.data_as(vp), rowval.ctypes.data_as(vp),
+                  self.perm.ctypes.data_as(vp), self.term_row.ctypes.data_as(vp), self.term_col.ctypes.data_as(vp), self.row_ptr.ctypes.data_as(vp))
+        self.buf = ctx.alloc(8 * max(self.nnz, 1))                                # nzval
+        self.perm_buf = ctx.upload_new(self.perm) if self.nnz else ctx.alloc(8)
+        self.term_row_buf = ctx.upload_new(self.term_row) if self.nnz else ctx.alloc(8)
+
+    def same_pattern(self, csc):
+        return csc.shape == (self.rows, self.cols) and np.array_equal(csc.indptr, self.indptr) and np.array_equal(csc.indices, self.indices)
+
+
+class DSparseAff(DAffVec):
+    """C*x (+|-) d for a sparse C kept implicit; terms exist for the structural non-zeros only, in row-major order."""
+
+    def __init__(self, ctx, spmat, xvars, vec, sign):
+        super().__init__(ctx, spmat.rows, row_ptr=spmat.row_ptr.copy(), alloc=False)
+        if self.row_ptr is None:                      # DAffVec collapsed a uniform pattern: keep the explicit row_ptr semantics
+            self.row_ptr = spmat.row_ptr.copy()
+            self.row_len = 0
+            self.row_ptr_buf = ctx.upload_new(self.row_ptr)
+        self.spmat, self.xvars, self.vec, self.sign = spmat, xvars, vec, sign
+        self.term_var = xvars.vars[spmat.term_col - 1] if spmat.nnz else np.zeros(0, dtype=np.int64)
+        self.term_var_buf = ctx.upload_new(self.term_var) if spmat.nnz else ctx.alloc(8)
+        self.need_terms = False
+
+    def uniform(self):
+        return False
+
+    def require_terms(self):
+        if not self.need_terms:
+            self.need_terms = True
+            self.terms = self.ctx.alloc(16 * max(self.nterms, 1))
+            self.consts = self.ctx.alloc(8 * max(self.rows, 1))
+        return self
+
+    def materialized(self):
+        return self.require_terms()
+
+
 class DAff(DV):
     """AffineFunction{Float64}: LT[nterms] + f64[1]."""
     kind = "aff"
@@ -280,5 +335,5 @@ def fetch_f64(ctx, ptr, n):
     return out
 
 
-__all__ = ["DeviceContext", "DV", "DNum", "DVec", "DMat", "DVars", "DLinVec", "DAffVec", "DDenseAff", "DVarsAff", "DAff", "DQuad",
+__all__ = ["DeviceContext", "DV", "DNum", "DVec", "DMat", "DVars", "DLinVec", "DAffVec", "DDenseAff", "DVarsAff", "DSpMat", "DSparseAff", "DAff", "DQuad",
            "fetch_terms", "fetch_f64", "P", "LT", "QT", "VAT", "ArgumentError"]

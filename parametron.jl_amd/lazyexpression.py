@@ -15,7 +15,12 @@ import numpy as np
 
 from . import hostops
 from ._lib import LT, QT, ArgumentError, DimensionMismatch
-from .device import (DAff, DAffVec, DDenseAff, DLinVec, DMat, DNum, DQuad, DV, DVars, DVarsAff, DVec, P, fetch_f64, fetch_terms)
+from .device import (DAff, DAffVec, DDenseAff, DLinVec, DMat, DNum, DQuad, DSparseAff, DSpMat, DV, DVars, DVarsAff, DVec, P,
+                     fetch_f64, fetch_terms)
+
+
+def _is_sparse(v):
+    return hasattr(v, "indptr") and hasattr(v, "indices") and hasattr(v, "data") and getattr(v, "format", None) == "csc"
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
 from .hostops import Transpose, _RowTimesMatrix, elem_kind, is_vector
 from .parameter import Parameter
@@ -88,6 +93,8 @@ def kind_of(v):
         return "t" + kind_of(v.parent)
     if isinstance(v, (_RowTimesMatrix, _LazyRowTimesMatrix)):
         return "rowmat"
+    if _is_sparse(v):
+        return "spmat"                                  # scipy.sparse.csc_matrix ↔ Julia SparseMatrixCSC (config 5)
     if is_vector(v):
         k = elem_kind(v)
         return {"num": "vec", "var": "varvec", "lt": "ltvec", "aff": "affvec", "empty": "vec"}.get(k, "vector<%s>" % k)
@@ -140,6 +147,8 @@ def _alloc_like(ctx, val):
         return DVec(ctx, len(val))
     if k == "mat":
         return DMat(ctx, *np.shape(val))
+    if k == "spmat":
+        return DSpMat(ctx, val)
     raise ArgumentError("Parameters of type %s cannot be used in device expressions" % k)
 
 
@@ -156,6 +165,10 @@ def _upload_value(ctx, dv, val):
         if m.shape != (dv.rows, dv.cols):
             raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.rows, dv.cols), m.shape))
         ctx.upload(dv.buf, np.asfortranarray(m).reshape(-1, order="F"))     # Julia column-major
+    elif isinstance(dv, DSpMat):
+        if not dv.same_pattern(val):
+            raise DimensionMismatch("the sparsity pattern of a sparse Parameter must stay fixed across re-evaluations")
+        ctx.upload(dv.buf, np.asarray(val.data, dtype=np.float64))
     else:
         raise ArgumentError("cannot upload into %s" % type(dv).__name__)
 
@@ -223,7 +236,7 @@ class DeviceNode(LazyExpression):
         ctx = self.model.device()
         if isinstance(self.out, DQuad):
             self.out.materialize()
-        if isinstance(self.out, (DDenseAff, DVarsAff)):
+        if hasattr(self.out, "require_terms"):                   # implicit dense / bounds / sparse blocks
             self.out.require_terms()
         evaluate(ctx, [self])
         val = fetch_value(ctx, self.out)
@@ -343,6 +356,28 @@ def _row_lens(dv):
 
 
 # ---- A * x ------------------------------------------------------------------------------------------------
+def _emit_sparse_terms(c, out):
+    """materialise a DSparseAff as native LinearTerms + constants (only if some consumer asked for them)"""
+    if not out.need_terms:
+        return
+    sp = out.spmat
+    c.call("pmt_sparse_assemble_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf), sp.nnz, P(out.terms))
+    if out.vec is not None:
+        c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(out.consts))
+
+
+def _rule_spmatvec(model, ctx, A, x):
+    """C * x for a sparse C with a fixed pattern (BASELINE config 5): terms for the structural non-zeros only, in the
+    reference's row-major matvecmul! order (src/functions.jl:790-796 restricted to the pattern)."""
+    dA, dx = _dv(ctx, A), _dv(ctx, x)
+    if not isinstance(dx, DVars):
+        raise ArgumentError("sparse matrix * %s is not supported" % kind_of(dx))
+    if dA.cols != dx.n:
+        raise DimensionMismatch("matvecmul!: size(A, 2) != length(x)")
+    out = DSparseAff(ctx, dA, dx, None, 0)
+    return DeviceNode(model, "matvecmul!", _inputs(A, x), out, lambda c: _emit_sparse_terms(c, out))
+
+
 def _rule_matvec(model, ctx, A, x):
     dA, dx = _dv(ctx, A), _dv(ctx, x)
     if dA.cols != _vec_len(dx):
@@ -391,6 +426,10 @@ def _rule_vec_addsub(model, ctx, a, b, sign):                                   
                        P(out.terms), P(out.consts))
         inner = a.inputs if isinstance(a, DeviceNode) else _inputs(a)
         return DeviceNode(model, name, list(inner) + _inputs(b), out, emit)
+    if isinstance(da, DSparseAff) and da.vec is None and isinstance(db, DVec):
+        out = DSparseAff(ctx, da.spmat, da.xvars, db, sign)
+        inner = a.inputs if isinstance(a, DeviceNode) else _inputs(a)
+        return DeviceNode(model, name, list(inner) + _inputs(b), out, lambda c: _emit_sparse_terms(c, out))
     if isinstance(da, DVars) and isinstance(db, DVec):
         out = DVarsAff(ctx, da, db, sign)
 
@@ -683,6 +722,8 @@ def lazy(f, *args):
         ka, kb = kinds
         if ka == "mat" and kb in ("varvec", "affvec"):
             return _rule_matvec(model, ctx, a, b)
+        if ka == "spmat" and kb == "varvec":
+            return _rule_spmatvec(model, ctx, a, b)
         if ka == "tvarvec" and kb == "mat":
             return _LazyRowTimesMatrix(model, a.parent, b)
         if ka == "rowmat":

@@ -9,7 +9,7 @@ constant records are converted once on the host at setup, as in the reference (`
 import numpy as np
 
 from ._lib import LT, QT, VAT, ArgumentError
-from .device import DAff, DAffVec, DDenseAff, DQuad, DVarsAff, P
+from .device import DAff, DAffVec, DDenseAff, DQuad, DSparseAff, DVarsAff, P
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
 from .lazyexpression import DeviceNode, kind_of
 
@@ -205,6 +205,16 @@ class _Record:
 
             def emit(c):
                 c.call("pmt_vars_addsub_f64", P(out.xvars.buf), out.rows, P(out.vec.buf), out.sign, P(varmap_buf), 0, None, P(dt), P(dc))
+            return emit
+        if isinstance(out, DSparseAff) and not out.need_terms:
+            dc = ctx.alloc(8 * max(out.rows, 1))
+            self.dev = {"terms": dt, "consts": dc}
+            sp = out.spmat
+
+            def emit(c):
+                c.call("pmt_sparse_pack_vector_f64", P(sp.buf), P(sp.perm_buf), P(sp.term_row_buf), P(out.term_var_buf), sp.nnz, P(varmap_buf), 0, P(dt))
+                if out.vec is not None:
+                    c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
             return emit
         m = out.materialized()
         self.dev = {"terms": dt, "consts": m.consts}

@@ -1,0 +1,78 @@
+"""-m gpu: sparse constraint matrix (BASELINE config 5) through the host API: the constraint C*x - d with a sparse C yields the
+reference's dense matvecmul! output minus the structural zeros, in the reference's row-major order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sp = pytest.importorskip("scipy.sparse")
+
+import parametron_jl_amd as P  # noqa: E402
+from parametron_jl_amd import Variable  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def _model(m, n, density, seed):
+    rng = np.random.default_rng(seed)
+    Cs = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=lambda k: rng.random(k) + 0.1)
+    model = P.Model(P.MockOptimizer(variable_offset=5))
+    x = [Variable(model) for _ in range(n)]
+    def upd(C):
+        C.data[:] = rng.random(C.nnz) + 0.1                      # values change, pattern fixed
+    Cp = P.Parameter(upd, Cs, model)
+    d = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(m)), np.zeros(m), model)
+    return model, x, Cp, d
+
+
+def test_sparse_constraint_matches_dense_reference_without_structural_zeros():
+    m, n = 37, 61
+    model, x, Cp, d = _model(m, n, 0.08, 1)
+    expr = Cp * x - d
+    P.constraint(model, expr, "<=", np.zeros(m)) if False else P.constraint(model, Cp * x == d)
+    for _ in range(3):
+        P.solve(model)
+        f = list(model.constraints)[0].f
+        dense = O.AffVec(m).vecsubtract(O.AffVec(m).matvecmul_vars(Cp().toarray(), [v.index for v in x]), d())
+        terms, consts = dense.moi(model.model_var_to_optimizer)
+        want = terms[terms["coeff"] != 0.0]
+        assert np.array_equal(f.terms.view(np.int64), want.view(np.int64))
+        assert np.array_equal(f.constants, consts)
+    # native (LinearTerm) form of the same node
+    got = expr()
+    rows = O.AffVec(m).vecsubtract(O.AffVec(m).matvecmul_vars(Cp().toarray(), [v.index for v in x]), d()).as_tuples()
+    for g_, (t, c) in zip(got, rows):
+        assert [(tt.coeff, tt.var.index) for tt in g_.linear] == [p for p in t if p[0] != 0.0] and g_.constant == c
+
+
+def test_sparse_pattern_must_stay_fixed():
+    model, x, Cp, d = _model(8, 9, 0.3, 2)
+    P.constraint(model, Cp * x == d)
+    P.solve(model)
+    Cp.val = sp.random(8, 9, density=0.5, format="csc", random_state=np.random.default_rng(9))
+    Cp.f = lambda C: None
+    with pytest.raises(P.DimensionMismatch):
+        P.solve(model)
+
+
+def test_config5_size_properties():
+    # n = 16384, m = 4096, 5 % non-zeros: sortedness of (row, col) and a checksum instead of an oracle run
+    m, n = 4096, 16384
+    rng = np.random.default_rng(3)
+    nnz_per_col = int(0.05 * m)
+    indptr = np.arange(0, (n + 1) * nnz_per_col, nnz_per_col, dtype=np.int64)
+    indices = np.concatenate([np.sort(rng.choice(m, nnz_per_col, replace=False)) for _ in range(n)]).astype(np.int64)
+    data = rng.random(indices.size) + 0.1
+    Cs = sp.csc_matrix((data, indices, indptr), shape=(m, n))
+    model = P.Model(P.MockOptimizer())
+    x = [Variable(model) for _ in range(n)]
+    Cp = P.Parameter(model, val=Cs)
+    d = P.Parameter(model, val=rng.random(m))
+    P.constraint(model, Cp * x == d)
+    P.solve(model)
+    t = list(model.constraints)[0].f.terms
+    assert len(t) == Cs.nnz
+    key = t["out"].astype(np.int64) * (n + 1) + t["var"]
+    assert np.all(np.diff(key) > 0)                                  # strictly row-major, columns ascending within a row
+    assert t["coeff"].sum() == pytest.approx(data.sum(), rel=1e-12)
+    csr = Cs.tocsr()
+    assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
