@@ -203,6 +203,21 @@ int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const int64_t *row_
                                pmt_vector_affine_term *out_terms, void *stream);                /* :64-81 */
 
 /* ---------------------------------------------------------------------------------------
+ * Generic canonicalize! (src/functions.jl:269-272, 381-386; sort_and_combine! src/util.jl:9-26) for arbitrary term lists.
+ * Indices are static on this path, so the sort happens once on the host (pmt_canonical_order_*: permutation by canonical key,
+ * run boundaries seg_ptr[nseg+1], and the indices of the combined terms — a run of one keeps its original (row, col), util.jl:18-19);
+ * per re-evaluation pmt_segment_sum_f64 adds the coefficients of each run (duplicates in original order; the reference's order is
+ * that of its unstable QuickSort, so coefficients agree to rounding) and writes ONLY the coefficient field (offset 0) of each
+ * output term, whose index fields the host wrote when the node was created.
+ * ------------------------------------------------------------------------------------- */
+int pmt_canonical_order_affine(int64_t n, const int64_t *host_vars, int64_t *host_perm, int64_t *host_seg_ptr, int64_t *host_out_vars,
+                               int64_t *nseg);
+int pmt_canonical_order_quadratic(int64_t n, const int64_t *host_rows, const int64_t *host_cols, int64_t *host_perm, int64_t *host_seg_ptr,
+                                  int64_t *host_out_rows, int64_t *host_out_cols, int64_t *nseg);
+int pmt_segment_sum_f64(const void *in_terms, int64_t in_stride_bytes, const int64_t *perm, const int64_t *seg_ptr, int64_t nseg,
+                        void *out_terms, int64_t out_stride_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Sparse constraint matrix (BASELINE config 5): C given in CSC (Julia SparseMatrixCSC: colptr/rowval
  * 1-based Int64, nzval).  pmt_sparse_plan_* computes ONCE the row-major order of the structural non-zeros;
  * per re-evaluation pmt_sparse_pack_vector_f64 gathers nzval through it into MOI.VectorAffineTerms

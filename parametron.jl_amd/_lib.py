@@ -65,6 +65,9 @@ SIGNATURES = {
     "pmt_pack_scalar_affine_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),
     "pmt_pack_scalar_quadratic_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),
     "pmt_pack_vector_affine_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "pmt_canonical_order_affine": (_ci, [_i64, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pmt_canonical_order_quadratic": (_ci, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pmt_segment_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_sparse_assemble_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),

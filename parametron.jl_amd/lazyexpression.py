@@ -231,6 +231,10 @@ class DeviceNode(LazyExpression):
     def emit(self, ctx):
         self._emit(ctx)
 
+    def canonicalize(self):
+        """canonicalize(expr) as a lazy device node (sorted, duplicates combined; src/functions.jl:269-272, 381-386)."""
+        return lazy("canonicalize", self)
+
     def __call__(self):
         """expr(): evaluate the DAG below this node and return the native value (fetched from the device)."""
         ctx = self.model.device()
@@ -674,6 +678,69 @@ def _rule_vect(model, ctx, x):                                                  
     raise ArgumentError("[%s] is not supported on the device" % kind_of(dx))
 
 
+
+# ---- canonicalize! on the device ------------------------------------------------------------------------------------
+def _canonical_order(kind, *index_arrays):
+    """pmt_canonical_order_* (host, once): (perm, seg_ptr, out index arrays)."""
+    from . import _lib
+    n = len(index_arrays[0])
+    vp = C.c_void_p
+    perm = np.empty(max(n, 1), dtype=np.int64)
+    seg_ptr = np.empty(n + 1, dtype=np.int64)
+    outs = [np.empty(max(n, 1), dtype=np.int64) for _ in index_arrays]
+    nseg = C.c_int64()
+    arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in index_arrays]
+    name = "pmt_canonical_order_affine" if kind == "aff" else "pmt_canonical_order_quadratic"
+    _lib.call(name, n, *[a.ctypes.data_as(vp) for a in arrs], perm.ctypes.data_as(vp), seg_ptr.ctypes.data_as(vp),
+              *[o.ctypes.data_as(vp) for o in outs], C.byref(nseg))
+    s = nseg.value
+    return perm[:n], seg_ptr[:s + 1], [o[:s] for o in outs]
+
+
+def _rule_canonicalize(model, ctx, x):
+    """canonicalize(f) for an AffineFunction / QuadraticFunction node (src/functions.jl:269-272, 381-386).  The indices of
+    the operand are read back ONCE here (they never change afterwards); each re-evaluation is a segmented coefficient sum."""
+    dx = _dv(ctx, x)
+    if not isinstance(x, DeviceNode) or not isinstance(dx, (DAff, DQuad)):
+        raise ArgumentError("canonicalize on the device needs an AffineFunction or QuadraticFunction expression")
+    if isinstance(dx, DQuad):
+        dx.materialize()
+    x.prepare()
+    for inp in schedule([x]):
+        if isinstance(inp, DeviceNode):
+            inp.prepare()
+    evaluate(ctx, [x])                                                     # once, to learn the (static) indices
+
+    def order_affine(terms_ptr, nterms):
+        t = fetch_terms(ctx, terms_ptr, nterms, LT); ctx.synchronize()
+        perm, seg, (ov,) = _canonical_order("aff", t["var"])
+        out = np.zeros(len(ov), dtype=LT); out["var"] = ov
+        return perm, seg, out
+
+    if isinstance(dx, DAff):
+        perm, seg, init = order_affine(dx.terms, dx.nterms)
+        out = DAff(ctx, len(init)); ctx.upload(out.terms, init)
+        dperm, dseg = ctx.upload_new(perm), ctx.upload_new(seg)
+
+        def emit(c):
+            c.call("pmt_segment_sum_f64", P(dx.terms), 16, P(dperm), P(dseg), len(init), P(out.terms), 16)
+            c.call("pmt_copy_bytes", P(out.const), P(dx.const), 8)
+        return DeviceNode(model, "canonicalize!", [x], out, emit)
+    q = fetch_terms(ctx, dx.quad, dx.nq, QT); ctx.synchronize()
+    qperm, qseg, (orow, ocol) = _canonical_order("quad", q["row"], q["col"])
+    qinit = np.zeros(len(orow), dtype=QT); qinit["row"] = orow; qinit["col"] = ocol
+    lperm, lseg, linit = order_affine(dx.lin, dx.nl)
+    out = DQuad(ctx, len(qinit), len(linit))
+    ctx.upload(out.quad, qinit); ctx.upload(out.lin, linit)
+    dqperm, dqseg, dlperm, dlseg = ctx.upload_new(qperm), ctx.upload_new(qseg), ctx.upload_new(lperm), ctx.upload_new(lseg)
+
+    def emit(c):
+        c.call("pmt_segment_sum_f64", P(dx.quad), 24, P(dqperm), P(dqseg), len(qinit), P(out.quad), 24)
+        c.call("pmt_segment_sum_f64", P(dx.lin), 16, P(dlperm), P(dlseg), len(linit), P(out.lin), 16)
+        c.call("pmt_copy_bytes", P(out.const), P(dx.const), 8)
+    return DeviceNode(model, "canonicalize!", [x], out, emit)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # optimize_toplevel
 
@@ -759,6 +826,8 @@ def lazy(f, *args):
         if kinds[0] in VECTOR_KINDS:
             return Transpose(a)
         return a                                                                  # scalars are their own adjoints (:645)
+    if f == "canonicalize":
+        return _rule_canonicalize(model, ctx, args[0])
     if f == "vcat":
         return _rule_vcat(model, ctx, *args)
     if f == "vect":

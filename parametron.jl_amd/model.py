@@ -206,6 +206,12 @@ class Model:
             self._varmap_buf = ctx.alloc(8 * max(self.nvars, 1))
             ident = np.arange(1, self.nvars + 1, dtype=np.int64)     # IdentityVarMap until mapindices! (src/moi_interop.jl:32-33)
             ctx.upload(self._varmap_buf, ident)
+            if self.quadratic_mode == "canonical":
+                # any other quadratic objective: generic device canonicalize! (sorted, duplicates combined) before the MOI copy
+                for r in records:
+                    gram = getattr(r.expr, "gram_candidate", None)
+                    if r.kind == "quad" and not (gram is not None and gram.xvars.strictly_increasing()):
+                        r.expr = r.expr.canonicalize()
             emitters = [r.compile(ctx, self._varmap_buf, self.quadratic_mode) for r in records]
             self._order = schedule([r.expr for r in records])
             for x in self._order:
