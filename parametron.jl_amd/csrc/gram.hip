@@ -226,6 +226,31 @@ __global__ __launch_bounds__(256) void gram_linear_kernel(const double *__restri
 
 }  // namespace pmt
 
+namespace pmt {
+
+// one non-blocking side stream + fork/join events per device, created on first use (PMT_GRAM_SIDE_STREAM=0 disables)
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static SideStream *side_stream() {
+    static const bool enabled = [] { const char *e = getenv("PMT_GRAM_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+    if (!enabled) return nullptr;
+    static SideStream per_device[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    SideStream &ss = per_device[dev];
+    if (!ss.stream) {
+        if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ss.stream = nullptr;
+            return nullptr;
+        }
+    }
+    return &ss;
+}
+
+}  // namespace pmt
+
 using namespace pmt;
 
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
@@ -244,7 +269,26 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
     if (cols > 0) PMT_REQUIRE(xvar && out_quad && out_lin && (A || rows == 0), PMT_INVALID_ARGUMENT, "quad_gram: null pointer");
     PMT_REQUIRE(cols < (int64_t)GT * 46000, PMT_DIMENSION_MISMATCH, "quad_gram: too many columns");
     return dispatch(stream, [=](hipStream_t s) {
+        // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
+        // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.
+        SideStream *side = side_stream();
+        hipStream_t s2 = s;
+        if (side) {
+            PMT_HIP_CHECK(hipEventRecord(side->fork, s));
+            PMT_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+            s2 = side->stream;
+        }
+        int rc = PMT_OK;
         if (cols > 0) {
+            PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s2, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
+            rc = check_launch("gram_linear_kernel");
+        }
+        if (!rc) {
+            if (b && sign && rows > 0) rc = launch_seq_dot(b, sign, b, sign, rows, out_const, s2);
+            else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
+        }
+        if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        if (!rc && cols > 0) {
             GramArgs g;
             g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
             g.ntiles = (int)cdiv(cols, GT);
@@ -259,7 +303,6 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
                 if (e && !strcmp(e, "tiles4")) return 2;
                 return 0;
             }();
-            int rc;
             if (impl == 0) {
                 rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, workspace, s);
             } else {
@@ -267,13 +310,8 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
                 else PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
                 rc = check_launch("quad_gram_kernel");
             }
-            if (rc) return rc;
-            PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
-            rc = check_launch("gram_linear_kernel");
-            if (rc) return rc;
         }
-        if (b && sign && rows > 0) return launch_seq_dot(b, sign, b, sign, rows, out_const, s);
-        PMT_HIP_CHECK(hipMemsetAsync(out_const, 0, sizeof(double), s));
-        return PMT_OK;
+        if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+        return rc;
     });
 }
