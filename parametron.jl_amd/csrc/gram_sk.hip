@@ -39,7 +39,8 @@ struct SKArgs {
     const int64_t *xvar; const int64_t *varmap; int moi;
     QT *out_quad;
     int ntiles, nchunk, G;
-    int64_t U;
+    int tfull;        // whole tiles per workgroup (phase A); tiles [tfull*G, T) are split along the contraction (phase B)
+    int64_t U;        // number of (tile, chunk) units of phase B = (T - tfull*G) * nchunk
     int vec_in;
     double *ws;
 };
@@ -384,11 +385,22 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
     __shared__ double lds[2][2][ST * GP];
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
-    const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
 
+    // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
+    for (int t = 0; t < g.tfull; ++t) {
+        int jb, kb;
+        sk_tri_unrank(bid * g.tfull + t, g.ntiles, jb, kb);
+        double acc[C::NACC];
+        sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
+        sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+    }
+
+    // phase B: the remaining tiles (fewer than G) are split along the contraction: stream-K over their (tile, chunk) units
+    const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
     for (int64_t u = u0; u < u1;) {
-        const int tile = (int)(u / g.nchunk);
-        const int c0 = (int)(u - (int64_t)tile * g.nchunk);
+        const int rtile = (int)(u / g.nchunk);                       // index among the remainder tiles
+        const int tile = g.tfull * g.G + rtile;
+        const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
         const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
         int jb, kb;
         sk_tri_unrank(tile, g.ntiles, jb, kb);
@@ -417,9 +429,10 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
 template <int TN>
 __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     using C = Cfg<TN>;
-    const int tile = blockIdx.x;
+    const int rtile = blockIdx.x;                                              // index among the remainder (split) tiles
+    const int tile = g.tfull * g.G + rtile;
     const int tid = threadIdx.x;
-    const int64_t ub = (int64_t)tile * g.nchunk, ue = ub + g.nchunk - 1;       // first / last unit of this tile
+    const int64_t ub = (int64_t)rtile * g.nchunk, ue = ub + g.nchunk - 1;      // first / last remainder unit of this tile
     auto owner = [&](int64_t u) {
         int b = (int)((u * g.G) / g.U);
         if (b >= g.G) b = g.G - 1;
@@ -429,21 +442,25 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     };
     const int blo = owner(ub), bhi = owner(ue);
     if (blo == bhi) return;                                                   // one workgroup did the whole tile
-    double acc[C::NACC];
-#pragma unroll
-    for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
+    // blockIdx.y selects 4 of the NACC accumulators of every thread, so a tile split many ways is summed by NACC/4 workgroups
+    const int r0 = (int)blockIdx.y * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int b = blo; b <= bhi; ++b) {
         const int64_t bu0 = sk_unit_begin(g, b);
-        const int first_tile = (int)(bu0 / g.nchunk);
-        const int slot = 2 * b + (first_tile == tile ? 0 : 1);
-        const double *w = g.ws + (int64_t)slot * SLOT + tid;
+        const int first_rtile = (int)(bu0 / g.nchunk);
+        const int slot = 2 * b + (first_rtile == rtile ? 0 : 1);
+        const double *w = g.ws + (int64_t)slot * SLOT + (int64_t)r0 * C::NT + tid;
 #pragma unroll
-        for (int r = 0; r < C::NACC; ++r) acc[r] = acc[r] + w[r * C::NT];
+        for (int r = 0; r < 4; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
     sk_tri_unrank(tile, g.ntiles, jb, kb);
-    __shared__ double smem[EPI_DOUBLES];
-    sk_epilogue<TN>(g, jb, kb, acc, smem, tid);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int row, col;
+        sk_acc_pos<TN>(tid, r0 + r, row, col);
+        sk_store_term(g, jb, kb, row, col, acc[r]);
+    }
 }
 
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
@@ -463,14 +480,16 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.ntiles = (int)cdiv(cols, ST);
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
     const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;
-    g.U = T * g.nchunk;
     // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16;
     //          2 = wg512 with BK 32
     static const int variant = env_int("PMT_GRAM_SK_VARIANT", 1);   // measured equal within noise (profiles/r01b_gram_variants.txt)
     static const int abl = env_int("PMT_GRAM_SK_ABLATE", 0);
     static const int gdef = env_int("PMT_GRAM_SK_BLOCKS", 0);
     const int gwant = gdef > 0 ? gdef : (variant == 0 ? 512 : 256);
-    g.G = (int)std::min<int64_t>(g.U, std::min(gwant, MAXG));
+    g.G = (int)std::min<int64_t>(T * g.nchunk, std::min(gwant, MAXG));
+    g.tfull = (int)(T / g.G);                         // at n = r = 4096: 528 tiles = 2 per workgroup + 16 split 16 ways
+    const int64_t R = T - (int64_t)g.tfull * g.G;     // remainder tiles, < G
+    g.U = R * g.nchunk;
     g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
     g.ws = reinterpret_cast<double *>(workspace);
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
@@ -487,9 +506,9 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #undef SK_LAUNCH
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
-    if (g.nchunk > 1) {
-        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<4>, dim3((unsigned)T), dim3(Cfg<4>::NT), 0, s, g);
-        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<2>, dim3((unsigned)T), dim3(Cfg<2>::NT), 0, s, g);
+    if (g.nchunk > 1 && R > 0) {
+        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<4>, dim3((unsigned)R, Cfg<4>::NACC / 4), dim3(Cfg<4>::NT), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<2>, dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }
     return rc;
