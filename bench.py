@@ -31,6 +31,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 F64_MFMA_PEAK_TFLOPS = 78.6
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch of the kernel whose name starts with `prefix`, from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE/WRITE_SIZE, separate passes, gfx950 x2 read correction).  PMC counters cannot be
+    collected from inside this process; None when no measurement is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            data = json.load(fh)
+    except Exception:
+        return None
+    for name, v in data.items():
+        if name.startswith(prefix):
+            return v["read_bytes"] + v["write_bytes"]
+    return None
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -135,7 +150,7 @@ def affine_microbench(torch, _lib, wl, reps=20):
     nbytes = 24.0 * r * n
     gbs = nbytes / (k["avg_ms"] * 1e-3) / 1e9
     return {"kernel": "affine_tile_kernel<LT>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_ms": k["avg_ms"], "algorithmic_bytes": nbytes,
+            "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("pmt::affine_tile_kernel<0"), "avg_ms": k["avg_ms"], "algorithmic_bytes": nbytes,
             "shape": "A 4096x4096 -> 16.8M LinearTerms"}
 
 
@@ -242,11 +257,12 @@ def main():
                        "replay": "hipGraph" if args.graph else "tape"},
             "step_algorithmic_bytes": wl.step_bytes(), "step_flops": wl.gram_flops(),
         }
-        g = kernels.get("quad_gram_kernel")
+        gname = "gram_sk_kernel" if "gram_sk_kernel" in kernels else "quad_gram_kernel"   # PMT_GRAM_IMPL=tiles* uses the latter
+        g = kernels.get(gname)
         if g:
             tf = wl.gram_flops() / (g["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "quad_gram_kernel", "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+            out["roofline"] = {"kernel": gname, "bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": tf / F64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("pmt::" + gname),
                                "avg_ms": g["avg_ms"], "algorithmic_flops": wl.gram_flops(),
                                "peak_source": "MI355X datasheet FP64 matrix 78.6 TFLOP/s (not in the local guides); see DESIGN.md"}
         else:
@@ -256,7 +272,7 @@ def main():
             nb = 32.0 * wl.m * wl.n
             out["roofline_constraint_pack"] = {"kernel": "affine_tile_kernel<VAT>", "bound": "hbm", "achieved": nb / (v["avg_ms"] * 1e-3) / 1e9,
                                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                               "avg_ms": v["avg_ms"], "algorithmic_bytes": nb}
+                                               "traffic": pmc_traffic("pmt::affine_tile_kernel<1"), "avg_ms": v["avg_ms"], "algorithmic_bytes": nb}
         out["kernels"] = kernels
         if world == 1:
             out["roofline_affine"] = affine_microbench(torch, _lib, wl)

@@ -213,6 +213,15 @@ __device__ __forceinline__ void sk_store_panel(double *panel, const f64x2 (&reg)
     }
 }
 
+// lane i of every 16-lane row receives the value of lane (i - N) mod 16 of the same row (DPP row_ror:N), both halves of the double
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // acc = sum over rows [ibeg, iend) of A[i, j0 + .]' * A[i, k0 + .] for this thread's accumulators of the 128x128 tile.
 // K-contiguous column panels go global -> registers -> LDS (double buffered, one barrier per BK rows).
 // ABL: ablation switch for profiling only (0 = the kernel; 1 = no LDS operand reads; 2 = no global loads / LDS stores).
@@ -258,10 +267,18 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 double b[4];
+                if (ABL == 3) {
+                    // one LDS read + three in-register rotations of the 16-lane rows by 4/8/12 lanes (DPP row_ror) instead of four reads
+                    b[0] = pk[(tn * 16 + lm) * GP + ks * 4];
+                    b[1] = dpp_row_ror<12>(b[0]);
+                    b[2] = dpp_row_ror<8>(b[0]);
+                    b[3] = dpp_row_ror<4>(b[0]);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
-                    b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
+                    for (int r = 0; r < 4; ++r) {
+                        const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
+                        b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
+                    }
                 }
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
@@ -496,9 +513,10 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     const dim3 grid((unsigned)g.G);
 #define SK_LAUNCH(TN, BK, WPS)                                                                                              \
     do {                                                                                                                    \
-        if (abl == 1) PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
-        else if (abl == 2) PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
-        else PMT_LAUNCH_NAMED("quad_gram_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
+        if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
+        else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
     } while (0)
     if (variant == 0) SK_LAUNCH(4, 16, 2);
     else if (variant == 1) SK_LAUNCH(2, 16, 2);
