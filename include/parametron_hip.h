@@ -282,6 +282,9 @@ void *pmt_plan_stream(pmt_plan *plan);
 /* device allocation owned by the plan (zero-filled); freed by pmt_plan_destroy */
 int pmt_plan_alloc(pmt_plan *plan, size_t bytes, void **out_device_ptr);
 size_t pmt_plan_bytes_allocated(const pmt_plan *plan);
+/* page-locked host memory (e.g. for the MOI function buffers pmt_plan_fetch writes into); not tied to a plan */
+int pmt_host_alloc(size_t bytes, void **out_host_ptr);
+int pmt_host_free(void *host_ptr);
 /* asynchronous copies on the plan's stream */
 int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
 int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);

@@ -199,6 +199,23 @@ extern "C" int pmt_plan_alloc(pmt_plan *plan, size_t bytes, void **out_device_pt
     return PMT_OK;
 }
 
+// page-locked host memory for the MOI function buffers: D2H copies into it run at PCIe rate and are truly asynchronous
+extern "C" int pmt_host_alloc(size_t bytes, void **out_host_ptr) {
+    PMT_REQUIRE(out_host_ptr, PMT_INVALID_ARGUMENT, "host_alloc: null argument");
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    memset(p, 0, bytes ? bytes : 16);
+    *out_host_ptr = p;
+    return PMT_OK;
+}
+
+extern "C" int pmt_host_free(void *host_ptr) {
+    if (!host_ptr) return PMT_OK;
+    PMT_HIP_CHECK(hipHostFree(host_ptr));
+    return PMT_OK;
+}
+
 extern "C" int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_upload: null plan");
     if (bytes == 0) return PMT_OK;

@@ -27,6 +27,22 @@ class DeviceContext:
         if self.plan:
             self.lib.pmt_plan_destroy(self.plan)
             self.plan = C.c_void_p()
+            for p in getattr(self, "_pinned", []):
+                self.lib.pmt_host_free(C.c_void_p(p))
+            self._pinned = []
+
+    def pinned_array(self, n, dtype):
+        """numpy array of `n` elements in page-locked host memory (the MOI function buffers the device results are copied into).
+        The memory lives until close(); the array must not be used after that."""
+        dtype = np.dtype(dtype)
+        nbytes = max(int(n) * dtype.itemsize, 16)
+        p = C.c_void_p()
+        _lib.call("pmt_host_alloc", nbytes, C.byref(p))
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p.value)
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(n))
 
     def __del__(self):
         try:

@@ -42,23 +42,28 @@ class ZeroOne(_Set): pass
 
 
 # ---- functions (MOI.AbstractFunction)
+def _zeros(n, dtype):
+    return np.zeros(n, dtype=dtype)
+
+
+# `alloc(n, dtype)` lets the device path place the term buffers in page-locked host memory (DeviceContext.pinned_array)
 class ScalarAffineFunction:
-    def __init__(self, nterms=0):
-        self.terms = np.zeros(nterms, dtype=LT)
+    def __init__(self, nterms=0, alloc=_zeros):
+        self.terms = alloc(nterms, LT)
         self.constant = 0.0
 
 
 class ScalarQuadraticFunction:
-    def __init__(self, naff=0, nquad=0):
-        self.affine_terms = np.zeros(naff, dtype=LT)
-        self.quadratic_terms = np.zeros(nquad, dtype=QT)
+    def __init__(self, naff=0, nquad=0, alloc=_zeros):
+        self.affine_terms = alloc(naff, LT)
+        self.quadratic_terms = alloc(nquad, QT)
         self.constant = 0.0
 
 
 class VectorAffineFunction:
-    def __init__(self, nterms=0, nrows=0):
-        self.terms = np.zeros(nterms, dtype=VAT)
-        self.constants = np.zeros(nrows, dtype=np.float64)
+    def __init__(self, nterms=0, nrows=0, alloc=_zeros):
+        self.terms = alloc(nterms, VAT)
+        self.constants = alloc(nrows, np.float64)
 
 
 class SingleVariable:
@@ -151,7 +156,7 @@ class _Record:
         out = self.expr.out
         if self.kind == "aff":
             n = out.nterms
-            self.f = ScalarAffineFunction(n)
+            self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
             dev_terms = ctx.alloc(16 * max(n, 1))
             self.dev = {"terms": dev_terms, "const": out.const}
 
@@ -166,7 +171,7 @@ class _Record:
             if use_gram:
                 n = gram.mat.cols
                 nq = n * (n + 1) // 2
-                self.f = ScalarQuadraticFunction(n, nq)
+                self.f = ScalarQuadraticFunction(n, nq, alloc=ctx.pinned_array)
                 dq, dl, dc = ctx.alloc(24 * max(nq, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
                 ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(gram.mat.rows, n))))
                 self.dev = {"quad": dq, "lin": dl, "const": dc}
@@ -179,7 +184,7 @@ class _Record:
                 return emit
             self.mode = "literal"
             out.materialize()
-            self.f = ScalarQuadraticFunction(out.nl, out.nq)
+            self.f = ScalarQuadraticFunction(out.nl, out.nq, alloc=ctx.pinned_array)
             dq, dl = ctx.alloc(24 * max(out.nq, 1)), ctx.alloc(16 * max(out.nl, 1))
             self.dev = {"quad": dq, "lin": dl, "const": out.const}
 
@@ -188,7 +193,7 @@ class _Record:
                 c.call("pmt_pack_scalar_affine_f64", P(out.lin), out.nl, P(varmap_buf), P(dl))
             return emit
         # Vector{AffineFunction}
-        self.f = VectorAffineFunction(out.nterms, out.rows)
+        self.f = VectorAffineFunction(out.nterms, out.rows, alloc=ctx.pinned_array)
         dt = ctx.alloc(24 * max(out.nterms, 1))
         if isinstance(out, DDenseAff) and not out.need_terms:
             dc = ctx.alloc(8 * max(out.rows, 1))
