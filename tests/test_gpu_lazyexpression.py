@@ -1,0 +1,152 @@
+"""-m gpu: transcription of test/lazyexpression.jl — every rewrite rule evaluated on the device equals the out-of-place
+expression (computed by the host algebra exactly as Julia would), and steady-state evaluation allocates nothing."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import parametron_jl_amd as P  # noqa: E402
+from parametron_jl_amd import Variable, hostops  # noqa: E402
+
+
+def V(*idx):
+    return [Variable(i) for i in idx]
+
+
+def no_alloc(model, expr):
+    expr()
+    before = model.device().bytes_allocated()
+    model.setdirty()
+    expr()
+    return model.device().bytes_allocated() == before
+
+
+def test_mul_optimization():                                   # test/lazyexpression.jl:138-148
+    m = P.mock_model()
+    weight = P.Parameter(lambda: 3, m)
+    x = V(1, 2, 3)
+    expr = weight * hostops.vecdot(x, x)                       # @expression weight * (x ⋅ x)
+    vals = {x[0]: 1, x[1]: 2, x[2]: 3}
+    assert expr()(vals) == 3 * (1 + 4 + 9)
+    assert expr() == 3 * hostops.vecdot(x, x)
+    assert no_alloc(m, expr)
+
+
+def test_scale_optimization():                                 # test/lazyexpression.jl:150-185
+    model = P.mock_model()
+    x = [Variable(model) for _ in range(3)]
+    dt = P.Parameter(lambda: 2.0, model)
+    e = dt * np.array([1.0, 2, 3, 4, 5])                        # numbers only
+    assert np.array_equal(e(), 2.0 * np.array([1.0, 2, 3, 4, 5]))
+    for expr in (dt * x, x * dt):
+        assert expr() == hostops.scale(2.0, x)
+        assert no_alloc(model, expr)
+    Ax = hostops.matvecmul(np.ones((3, 3)), x)
+    for expr in (dt * Ax, Ax * dt):
+        assert expr() == hostops.scale(2.0, Ax)
+        assert no_alloc(model, expr)
+
+
+def test_vcat_optimization():                                  # test/lazyexpression.jl:188-245
+    rng = np.random.default_rng(42)
+    m = P.mock_model()
+    A = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((3, 4)), m)
+    B = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((3, 3)), m)
+    x, y, z = V(1, 2, 3, 4), V(5, 6, 7), V(8, 9)
+    Cm = P.Parameter(lambda: np.array([[1.0, 2.0], [3.0, 4.0]]), m)
+    f1, f2, f3 = A * x, B * y, Cm * z
+    v1 = P.vcat(f1, f2)
+    assert v1() == f1() + f2()
+    assert no_alloc(m, v1)
+    v3 = P.vcat(f3, f3)
+    assert v3() == f3() + f3() and len(v3()) == 4
+    v4 = P.vcat(f3)
+    assert v4() == f3()
+    v5 = P.vcat(f1, f2, f3)                                    # ragged rows: 4, 3 and 2 terms
+    m.setdirty()
+    assert v5() == f1() + f2() + f3()
+    assert no_alloc(m, v5)
+    assert f1() == hostops.matvecmul(A(), x)
+
+
+def test_vect_optimization():                                  # test/lazyexpression.jl:247-263
+    m = P.mock_model()
+    x = V(1, 2)
+    p = P.Parameter(lambda: np.array([1.0, 2.0]), m)
+    expr = P.vect(P.dot(p, x))
+    assert expr() == [hostops.vecdot(p(), x)]
+    assert no_alloc(m, expr)
+
+
+def test_adjoint_optimization():                               # test/lazyexpression.jl:300-314, :406-414
+    rng = np.random.default_rng(0)
+    m = P.mock_model()
+    x = V(1, 2)
+    p = P.Parameter(lambda: np.array([[1.0, 2.0], [3.0, 4.0]]), m)
+    ex = P.adjoint(p) * x
+    assert ex() == hostops.matvecmul(p().T, x)
+    p2 = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((2, 2)), m)
+    ex2 = p2.T * x
+    assert ex2() == hostops.matvecmul(p2().T, x)
+    assert no_alloc(m, ex2)
+    n, mm = 5, 15
+    Adata = rng.standard_normal((n, mm))
+    A = P.Parameter(m, val=Adata)
+    xs = V(*range(1, n + 1))
+    assert (A.T * xs)() == hostops.matvecmul(Adata.T, xs)
+
+
+def test_issue_26():                                           # test/lazyexpression.jl:316-328
+    model = P.mock_model()
+    n = 2
+    x = V(1, 2)
+    rng = np.random.default_rng(1)
+    vals = {x[0]: rng.random(), x[1]: rng.random()}
+    def upd(q):
+        q[0] = 1; q[1] = 2
+    q = P.Parameter(upd, np.zeros(n), model)
+    expr1 = P.transpose(x) * np.eye(n) * x + q.T * x
+    expr2 = q.T * x + P.transpose(x) * np.eye(2) * x
+    assert expr1()(vals) == pytest.approx(expr2()(vals), abs=1e-14)
+    want = vals[x[0]] ** 2 + vals[x[1]] ** 2 + vals[x[0]] + 2 * vals[x[1]]
+    assert expr1()(vals) == pytest.approx(want, abs=1e-14)
+
+
+def test_issue_32():                                           # test/lazyexpression.jl:330-347
+    rng = np.random.default_rng(2)
+    model = P.mock_model()
+    v = [Variable(model) for _ in range(2)]
+    v0 = np.zeros(2)
+    dt = 0.01
+    u = [Variable(model) for _ in range(2)]
+    def updH(H):
+        H[0, 0] = rng.random(); H[1, 1] = rng.random()
+    H = P.Parameter(updH, np.zeros((2, 2)), model)
+    def updc(c):
+        c[0] = rng.random(); c[1] = rng.random()
+    c = P.Parameter(updc, np.zeros(2), model)
+    vmv0 = hostops.vecaddsub(v, v0, -1)                         # v - v0: no Parameter -> evaluated immediately
+    expr = H * vmv0 - dt * (u - c)
+    for _ in range(2):
+        model.setdirty()
+        got = expr()
+        want = hostops.vecaddsub(hostops.matvecmul(H(), vmv0), hostops.scale(dt, hostops.vecaddsub(u, c(), -1)), -1)
+        assert got == want
+    assert no_alloc(model, expr)
+
+
+def test_issue_23_numbers_only():                              # test/lazyexpression.jl:349-354
+    model = P.mock_model()
+    p = P.Parameter(lambda: 2, model)
+    assert (2 + p)() == 4
+
+
+def test_bad_syntax_raises_argument_error():                   # test/lazyexpression.jl:21-23
+    model = P.mock_model()
+    x = V(1, 2)
+    p = P.Parameter(lambda: np.eye(2), model)
+    with pytest.raises(P.ArgumentError):
+        P.lazy("hcat", p, x)
+    with pytest.raises(P.DimensionMismatch):
+        p * V(1, 2, 3)
