@@ -280,3 +280,43 @@ def test_hipgraph_replay_gives_identical_buffers():
     for a, b_ in zip(outs[0], outs[1]):
         assert np.array_equal(np.asarray(a).view(np.int64) if hasattr(a, "dtype") and a.dtype.fields else np.asarray(a),
                               np.asarray(b_).view(np.int64) if hasattr(b_, "dtype") and b_.dtype.fields else np.asarray(b_))
+
+
+# ------------------------------------------------------------------ BASELINE config 3 at full size (n = 4096): <= constraints, bounds, val= Parameters
+def test_config3_full_size_inequalities_bounds_and_manual_parameters():
+    n, r, mi = 4096, 4096, 512
+    rng = np.random.default_rng(5)
+    model = P.Model(P.MockOptimizer(variable_offset=100), quadratic_mode="canonical")
+    x = [Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model, advance=False)
+    b = P.DeviceUniformParameter((r,), 2, model, advance=False)
+    Gd, hd = np.asfortranarray(rng.random((mi, n))), rng.random(mi)
+    ld, ud = -rng.random(n), rng.random(n)
+    G, h = P.Parameter(model, val=Gd), P.Parameter(model, val=hd)       # manually updated work buffers (src/parameter.jl:88)
+    l, u = P.Parameter(model, val=ld), P.Parameter(model, val=ud)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, G * x, "<=", h)
+    P.constraint(model, x, ">=", l)
+    P.constraint(model, x, "<=", u)
+    P.solve(model)
+    hd[:] = rng.random(mi); ud[:] = rng.random(n)                        # user overwrites the buffers between solves
+    P.solve(model)
+    cons = list(model.constraints)
+    assert [c.spec for c in cons] == ["vectoraffinefunction_in_nonnegatives", "vectoraffinefunction_in_nonpositives", "vectoraffinefunction_in_nonpositives"]
+    lo, gc, up = cons[0].f, cons[1].f, cons[2].f
+    vm = model.model_var_to_optimizer
+    assert np.array_equal(vm, np.arange(1, n + 1) + 100)
+    assert np.array_equal(gc.terms["coeff"].reshape(mi, n), Gd) and np.array_equal(gc.constants, 0.0 - hd)
+    assert np.array_equal(gc.terms["out"].reshape(mi, n), np.repeat(np.arange(1, mi + 1), n).reshape(mi, n))
+    assert np.array_equal(gc.terms["var"].reshape(mi, n)[7], vm)
+    assert np.array_equal(lo.terms["coeff"], np.ones(n)) and np.array_equal(lo.terms["var"], vm) and np.array_equal(lo.constants, 0.0 - ld)
+    assert np.array_equal(up.constants, 0.0 - ud) and np.array_equal(up.terms["out"], np.arange(1, n + 1))
+    f = model.objective.f
+    assert model.objective.mode == "canonical" and len(f.quadratic_terms) == n * (n + 1) // 2
+    Ah = A()
+    iu = np.triu_indices(n)
+    rows = rng.integers(0, len(iu[0]), 2000)
+    want = 2 * np.einsum("ij,ij->j", Ah[:, iu[0][rows]], Ah[:, iu[1][rows]])
+    np.testing.assert_allclose(f.quadratic_terms["coeff"][rows], want, rtol=1e-12)
+    assert np.array_equal(f.quadratic_terms["row"][rows], vm[iu[0][rows]]) and np.array_equal(f.quadratic_terms["col"][rows], vm[iu[1][rows]])
