@@ -175,8 +175,8 @@ int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
 
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
  * bilinearmul! src/functions.jl:840-858 (the Q' pairing quirk is reproduced).
- * Q must be contiguous (lda == rows).  moi as above. */
-int pmt_bilinear_f64(const double *Q, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar,
+ * The linear index k is that of the rows x cols matrix; ldq is the leading dimension of its device copy.  moi as above. */
+int pmt_bilinear_f64(const double *Q, int64_t ldq, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar,
                      int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream);
 
 /* x . y for Variable/LinearTerm vectors: quad[i] = (xc[i]*yc[i], xvar[i], yvar[i]); xc/yc NULL = Variables (coeff 1)
@@ -256,6 +256,10 @@ int pmt_batch_expand_f64(const double *slab, int64_t n, int64_t m, const int64_t
  * dst[i] = scale * U[0,1)(seed, i)   — the analogue of `Parameter(rand!, zeros(n, n), model)` README.md:36-43
  * ------------------------------------------------------------------------------------- */
 int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, void *stream);
+/* column-major rows x cols matrix with leading dimension lda: dst[c*lda + i] = scale * U(seed, c*rows + i) — same values as the
+ * contiguous stream.  Device copies of Parameter matrices whose column stride would be a multiple of 4 KiB are kept with a padded
+ * lda: a power-of-two stride puts every column segment of a tile on the same memory channel. */
+int pmt_fill_uniform_matrix_f64(double *dst, int64_t rows, int64_t cols, int64_t lda, uint64_t seed, double scale, void *stream);
 /* the same stream from element index_offset on: dst[i] = scale * U(seed, index_offset + i) (shard of a larger array) */
 int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed, uint64_t index_offset, double scale, void *stream);
 
@@ -288,6 +292,11 @@ int pmt_host_free(void *host_ptr);
 /* asynchronous copies on the plan's stream */
 int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
 int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
+/* pitched variants (hipMemcpy2DAsync): `height` rows of `width_bytes`, e.g. the columns of a matrix whose device copy is padded */
+int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes,
+                       size_t height);
+int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
+                      size_t height);
 int pmt_plan_synchronize(pmt_plan *plan);
 
 /* recording: between begin_record and end_record every pmt_*_f64 call issued with stream ==

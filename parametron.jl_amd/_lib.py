@@ -59,7 +59,10 @@ SIGNATURES = {
     "pmt_quad_expand_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_fill_uniform_matrix_f64": (_ci, [_vp, _i64, _i64, _i64, _u64, _f64, _vp]),
+    "pmt_plan_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    "pmt_plan_fetch_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "pmt_vecdot_terms_f64": (_ci, [_i64, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_vecdot_affs_vars_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
     "pmt_pack_scalar_affine_f64": (_ci, [_vp, _i64, _vp, _vp, _vp]),

@@ -239,22 +239,28 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
 
     const int nstage = (int)((iend - ibeg + BK - 1) / BK);
     const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
+    // (A per-workgroup stagger of the contraction order and a padded lda were both tried against channel hot-spotting of the
+    // 32 KiB column stride: neither changes this kernel's time once the GPU is warm — profiles/r01c_lda_padding.txt.)
+    auto stage_row = [&](int s) { return ibeg + (int64_t)s * BK; };
     f64x2 rj[NREG], rk[NREG];
     __syncthreads();                                   // previous users of the LDS buffers are done
     if (nstage > 0) {
-        sk_load_panel<TN, BK>(g, j0, ibeg, iend, rj, tid, fast);
-        if (!diag) sk_load_panel<TN, BK>(g, k0, ibeg, iend, rk, tid, fast);
+        sk_load_panel<TN, BK>(g, j0, stage_row(0), iend, rj, tid, fast);
+        if (!diag) sk_load_panel<TN, BK>(g, k0, stage_row(0), iend, rk, tid, fast);
         sk_store_panel<TN, BK>(lds[0][0], rj, tid);
         if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
     }
     __syncthreads();
+    long long tphase[4] = {0, 0, 0, 0};      // ABL == 4 only: cycles in {load issue, MFMA block issue, LDS stores, barrier}
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
+        const long long t0 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         if (ABL != 2 && s + 1 < nstage) {
-            const int64_t inext = ibeg + (int64_t)(s + 1) * BK;
+            const int64_t inext = stage_row(s + 1);
             sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
             if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
         }
+        const long long t1 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
         const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
         // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
@@ -287,11 +293,22 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
                         acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
             }
         }
+        const long long t2 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         if (ABL != 2 && s + 1 < nstage) {
             sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
             if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
         }
+        const long long t3 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (ABL == 4) {
+            const long long t4 = (long long)__builtin_readcyclecounter();
+            tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3;
+        }
+    }
+    if (ABL == 4 && blockIdx.x == 0 && lane == 0 && g.ws) {       // profiling aid: per-wave phase totals of workgroup 0 (last segment wins)
+        double *dbg = g.ws + (int64_t)1000 * SLOT + wave * 8;
+        for (int k = 0; k < 4; ++k) dbg[k] = (double)tphase[k];
+        dbg[4] = (double)nstage;
     }
 }
 
@@ -516,6 +533,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
         else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else if (abl == 4) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 4>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
     } while (0)
     if (variant == 0) SK_LAUNCH(4, 16, 2);

@@ -232,6 +232,25 @@ extern "C" int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device
     return PMT_OK;
 }
 
+// strided (pitched) copies: a column-major matrix whose device copy has a padded leading dimension
+extern "C" int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes,
+                                  size_t height) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_upload_2d: null plan");
+    if (width_bytes == 0 || height == 0) return PMT_OK;
+    PMT_REQUIRE(device_dst && host_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_upload_2d: bad argument");
+    PMT_HIP_CHECK(hipMemcpy2DAsync(device_dst, dst_pitch, host_src, src_pitch, width_bytes, height, hipMemcpyHostToDevice, plan->stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
+                                 size_t height) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch_2d: null plan");
+    if (width_bytes == 0 || height == 0) return PMT_OK;
+    PMT_REQUIRE(host_dst && device_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_fetch_2d: bad argument");
+    PMT_HIP_CHECK(hipMemcpy2DAsync(host_dst, dst_pitch, device_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, plan->stream));
+    return PMT_OK;
+}
+
 extern "C" int pmt_plan_synchronize(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_synchronize: null plan");
     PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));

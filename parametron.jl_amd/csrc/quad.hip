@@ -126,7 +126,7 @@ int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int
 }
 
 // ---- bilinearmul!: one block row per x index
-__global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict__ Q, int64_t nxr, int64_t ny,
+__global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict__ Q, int64_t ldq, int64_t nxr, int64_t ny,
                                                        const int64_t *__restrict__ xvar, const int64_t *__restrict__ yvar,
                                                        int moi, const int64_t *__restrict__ varmap, u64 *__restrict__ out_quad) {
     __shared__ double qc[QE_BT];
@@ -141,7 +141,11 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict_
     }
     for (int64_t r = blockIdx.y; r < nxr; r += gridDim.y) {
         __syncthreads();
-        for (int k = threadIdx.x; k < bt; k += blockDim.x) qc[k] = Q[r * ny + b0 + k];   // Q[k]: column-major linear index (:853)
+        for (int k = threadIdx.x; k < bt; k += blockDim.x) {
+            const int64_t lin = r * ny + b0 + k;                 // Q[k]: column-major LINEAR index of the nxr x ny matrix (:853)
+            const int64_t qc_col = lin / nxr, qc_row = lin - qc_col * nxr;
+            qc[k] = Q[qc_col * ldq + qc_row];
+        }
         __syncthreads();
         const int64_t xv = xvar[r];
         const u64 xvm = (u64)(moi ? map_var(varmap, xv) : xv);
@@ -231,14 +235,15 @@ extern "C" int pmt_quad_expand_f64(int64_t rows, const pmt_linear_term *x_terms,
     });
 }
 
-extern "C" int pmt_bilinear_f64(const double *Q, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar, int moi,
+extern "C" int pmt_bilinear_f64(const double *Q, int64_t ldq, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar, int moi,
                                 const int64_t *varmap, pmt_quadratic_term *out_quad, void *stream) {
     PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "bilinear: negative dimension");
+    PMT_REQUIRE(ldq >= rows, PMT_DIMENSION_MISMATCH, "bilinear: ldq < rows");
     if (rows == 0 || cols == 0) return PMT_OK;
     PMT_REQUIRE(Q && xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "bilinear: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         dim3 grid((unsigned)cdiv(cols, QE_BT), (unsigned)std::min<int64_t>(rows, 65535));
-        PMT_LAUNCH(bilinear_kernel, grid, dim3(256), 0, s, Q, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
+        PMT_LAUNCH(bilinear_kernel, grid, dim3(256), 0, s, Q, ldq, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
         return check_launch("bilinear_kernel");
     });
 }

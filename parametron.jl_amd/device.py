@@ -136,13 +136,39 @@ class DVec(DV):
         self.buf = ctx.alloc(8 * max(self.n, 1))
 
 
+def padded_lda(rows):
+    """Leading dimension of the DEVICE copy of a column-major matrix with `rows` rows.  A column stride that is a multiple of
+    4 KiB (e.g. 4096 doubles = 32 KiB, the BASELINE shape) maps every column segment of a tile onto the same memory channel;
+    measured on MI355X (warm GPU): +64 doubles takes the affine-assembly kernel from 6.05 to 6.69 TB/s; the MFMA-bound Gram
+    kernel is indifferent (profiles/r01c_lda_padding.txt).  The values and their (row, column) meaning are unchanged — only the
+    placement in HBM."""
+    rows = int(rows)
+    return rows + 64 if rows >= 512 and rows % 512 == 0 else rows
+
+
 class DMat(DV):
-    """Matrix{Float64}, column-major, lda == rows."""
+    """Matrix{Float64}, column-major with leading dimension lda >= rows (padded_lda)."""
     kind = "mat"
 
     def __init__(self, ctx, rows, cols):
         self.rows, self.cols = int(rows), int(cols)
-        self.buf = ctx.alloc(8 * max(self.rows * self.cols, 1))
+        self.lda = padded_lda(self.rows)
+        self.buf = ctx.alloc(8 * max(self.lda * self.cols, 1))
+
+    def upload(self, ctx, m):
+        """host ndarray (rows, cols) -> device copy (column j at buf + j*lda*8)"""
+        m = np.asfortranarray(np.asarray(m, dtype=np.float64))
+        ctx._keep.append(m)
+        if self.rows and self.cols:
+            _lib.call("pmt_plan_upload_2d", ctx.plan, C.c_void_p(self.buf), 8 * self.lda, m.ctypes.data_as(C.c_void_p), 8 * self.rows,
+                      8 * self.rows, self.cols)
+
+    def fetch(self, ctx):
+        out = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
+        if self.rows and self.cols:
+            _lib.call("pmt_plan_fetch_2d", ctx.plan, out.ctypes.data_as(C.c_void_p), 8 * self.rows, C.c_void_p(self.buf), 8 * self.lda,
+                      8 * self.rows, self.cols)
+        return out
 
 
 class DVars(DV):

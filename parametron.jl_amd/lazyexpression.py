@@ -130,8 +130,11 @@ def device_value_of(x, ctx=None):
                 x._dev = _alloc_like(ctx, val)
         if x._dev_version != x.version:
             if getattr(x, "device_resident", False):
-                n = int(np.prod(x.shape))
-                ctx.call("pmt_fill_uniform_f64", P(x._dev.buf), n, C.c_uint64(x.current_seed()), x.scale)
+                if isinstance(x._dev, DMat):
+                    ctx.call("pmt_fill_uniform_matrix_f64", P(x._dev.buf), x._dev.rows, x._dev.cols, x._dev.lda,
+                             C.c_uint64(x.current_seed()), x.scale)
+                else:
+                    ctx.call("pmt_fill_uniform_f64", P(x._dev.buf), int(x.shape[0]), C.c_uint64(x.current_seed()), x.scale)
             else:
                 _upload_value(ctx, x._dev, val)
             x._dev_version = x.version
@@ -164,7 +167,7 @@ def _upload_value(ctx, dv, val):
         m = np.asarray(val, dtype=np.float64)
         if m.shape != (dv.rows, dv.cols):
             raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.rows, dv.cols), m.shape))
-        ctx.upload(dv.buf, np.asfortranarray(m).reshape(-1, order="F"))     # Julia column-major
+        dv.upload(ctx, m)                                                   # Julia column-major, padded leading dimension
     elif isinstance(dv, DSpMat):
         if not dv.same_pattern(val):
             raise DimensionMismatch("the sparsity pattern of a sparse Parameter must stay fixed across re-evaluations")
@@ -288,7 +291,7 @@ def fetch_value(ctx, dv):
     if isinstance(dv, DVec):
         v = fetch_f64(ctx, dv.buf, dv.n); ctx.synchronize(); return v
     if isinstance(dv, DMat):
-        v = fetch_f64(ctx, dv.buf, dv.rows * dv.cols); ctx.synchronize(); return v.reshape((dv.rows, dv.cols), order="F")
+        v = dv.fetch(ctx); ctx.synchronize(); return v
     if isinstance(dv, DLinVec):
         t = fetch_terms(ctx, dv.terms, dv.n, LT); ctx.synchronize()
         return [LinearTerm(float(c), Variable(int(v))) for c, v in zip(t["coeff"], t["var"])]
@@ -391,7 +394,7 @@ def _rule_matvec(model, ctx, A, x):
 
         def emit(c):
             if out.need_terms:
-                c.call("pmt_affine_assemble_f64", P(dA.buf), dA.rows, dA.rows, dA.cols, P(dx.buf), None, 0, P(out.terms), P(out.consts))
+                c.call("pmt_affine_assemble_f64", P(dA.buf), dA.lda, dA.rows, dA.cols, P(dx.buf), None, 0, P(out.terms), P(out.consts))
         return DeviceNode(model, "matvecmul!", _inputs(A, x), out, emit)
     if isinstance(dx, DAffVec):                                                  # builder :800-822
         X = dx.materialized()
@@ -400,7 +403,7 @@ def _rule_matvec(model, ctx, A, x):
         out = DAffVec(ctx, dA.rows, row_len=dA.cols * X.row_len)
 
         def emit(c):
-            c.call("pmt_matvecmul_affs_f64", P(dA.buf), dA.rows, dA.rows, dA.cols, P(X.terms), X.row_len, P(X.consts), P(out.terms), P(out.consts))
+            c.call("pmt_matvecmul_affs_f64", P(dA.buf), dA.lda, dA.rows, dA.cols, P(X.terms), X.row_len, P(X.consts), P(out.terms), P(out.consts))
         return DeviceNode(model, "matvecmul!", _inputs(A, x), out, emit)
     raise ArgumentError("matrix * %s is not supported" % kind_of(dx))
 
@@ -410,7 +413,7 @@ def _rule_adjoint_matrix(model, ctx, A):                                        
     out = DMat(ctx, dA.cols, dA.rows)
 
     def emit(c):
-        c.call("pmt_transpose_f64", P(dA.buf), dA.rows, dA.rows, dA.cols, P(out.buf), dA.cols)
+        c.call("pmt_transpose_f64", P(dA.buf), dA.lda, dA.rows, dA.cols, P(out.buf), out.lda)
     return DeviceNode(model, "adjoint", _inputs(A), out, emit)
 
 
@@ -426,7 +429,7 @@ def _rule_vec_addsub(model, ctx, a, b, sign):                                   
 
         def emit(c):
             if out.need_terms:
-                c.call("pmt_affine_assemble_f64", P(out.mat.buf), out.mat.rows, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(db.buf), sign,
+                c.call("pmt_affine_assemble_f64", P(out.mat.buf), out.mat.lda, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(db.buf), sign,
                        P(out.terms), P(out.consts))
         inner = a.inputs if isinstance(a, DeviceNode) else _inputs(a)
         return DeviceNode(model, name, list(inner) + _inputs(b), out, emit)
@@ -538,7 +541,7 @@ def _rule_bilinear(model, ctx, x, Q, y):                                        
     out = DQuad(ctx, dx.n * dy.n, 0)
 
     def emit(c):
-        c.call("pmt_bilinear_f64", P(dQ.buf), dQ.rows, dQ.cols, P(dx.buf), P(dy.buf), 0, None, P(out.quad))
+        c.call("pmt_bilinear_f64", P(dQ.buf), dQ.lda, dQ.rows, dQ.cols, P(dx.buf), P(dy.buf), 0, None, P(out.quad))
     return DeviceNode(model, "bilinearmul!", _inputs(x, Q, y), out, emit)
 
 

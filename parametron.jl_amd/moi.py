@@ -179,7 +179,7 @@ class _Record:
                 vec = gram.vec.buf if gram.vec is not None else None
 
                 def emit(c):
-                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.rows, gram.mat.rows, n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
+                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.lda, gram.mat.rows, n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
                            1, P(varmap_buf), P(dq), P(dl), P(dc), P(ws))
                 return emit
             self.mode = "literal"
@@ -201,7 +201,7 @@ class _Record:
             vec = out.vec.buf if out.vec is not None else None
 
             def emit(c):
-                c.call("pmt_affine_pack_vector_f64", P(out.mat.buf), out.mat.rows, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec),
+                c.call("pmt_affine_pack_vector_f64", P(out.mat.buf), out.mat.lda, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec),
                        out.sign if vec else 0, P(varmap_buf), 0, P(dt), P(dc))
             return emit
         if isinstance(out, DVarsAff) and not out.need_terms:

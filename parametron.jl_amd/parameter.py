@@ -117,11 +117,14 @@ class DeviceUniformParameter(Parameter):
         from .lazyexpression import device_value_of
         dv = device_value_of(self)                       # uploads / regenerates if stale
         if getattr(self, "_host_stale", True):
-            n = int(np.prod(self.shape))
-            host = np.empty(n, dtype=np.float64)
             ctx = self.model.device()
-            ctx.fetch(host, dv.buf, host.nbytes)
-            ctx.synchronize()
-            self.val = host.reshape(self.shape, order="F") if len(self.shape) == 2 else host
+            if len(self.shape) == 2:
+                self.val = dv.fetch(ctx)                              # pitched copy out of the padded device layout
+                ctx.synchronize()
+            else:
+                host = np.empty(int(self.shape[0]), dtype=np.float64)
+                ctx.fetch(host, dv.buf, host.nbytes)
+                ctx.synchronize()
+                self.val = host
             self._host_stale = False
         return self.val

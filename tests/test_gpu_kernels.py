@@ -247,9 +247,14 @@ def test_bilinear_and_vecdot_terms():
     dQ, dx, dvm = g.colmajor(Q), g.to_dev(xvar), g.to_dev(varmap)
     oq = g.empty_terms(n * n, g.QT)
     ref = O.Quad().bilinearmul(Q, xvar, xvar)
-    g.call("pmt_bilinear_f64", g.ptr(dQ), n, n, g.ptr(dx), g.ptr(dx), 0, None, g.ptr(oq), g.stream())
+    g.call("pmt_bilinear_f64", g.ptr(dQ), n, n, n, g.ptr(dx), g.ptr(dx), 0, None, g.ptr(oq), g.stream())
     g.assert_terms_equal(g.terms_to_host(oq, n * n, g.QT), ref.terms())
-    g.call("pmt_bilinear_f64", g.ptr(dQ), n, n, g.ptr(dx), g.ptr(dx), 1, g.ptr(dvm), g.ptr(oq), g.stream())
+    g.call("pmt_bilinear_f64", g.ptr(dQ), n, n, n, g.ptr(dx), g.ptr(dx), 1, g.ptr(dvm), g.ptr(oq), g.stream())
+    # padded leading dimension of the device copy: same terms
+    ldq = n + 5
+    Qpad = np.zeros((ldq, n)); Qpad[:n] = Q
+    dQp = g.colmajor(Qpad)
+    g.call("pmt_bilinear_f64", g.ptr(dQp), ldq, n, n, g.ptr(dx), g.ptr(dx), 1, g.ptr(dvm), g.ptr(oq), g.stream())
     g.assert_terms_equal(g.terms_to_host(oq, n * n, g.QT), ref.moi(varmap)[1])
     # x . x  (Variable . Variable) and (a .* x) . x
     a = O.fill_uniform(n, 42)

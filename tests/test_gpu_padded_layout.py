@@ -1,0 +1,61 @@
+"""-m gpu: the padded device layout of Parameter matrices (device.padded_lda) changes placement in HBM only — values, indices
+and every MOI buffer are identical to the contiguous layout."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import parametron_jl_amd as P  # noqa: E402
+from parametron_jl_amd import Variable  # noqa: E402
+from parametron_jl_amd.device import padded_lda  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def test_padded_lda_policy():
+    assert padded_lda(4096) == 4160 and padded_lda(512) == 576 and padded_lda(8) == 8 and padded_lda(4000) == 4000 and padded_lda(1024) % 2 == 0
+
+
+def test_matrix_fill_places_the_contiguous_stream_with_a_leading_dimension():
+    import gpu_util as g
+    rows, cols, lda = 37, 11, 44
+    d = g.empty_f64(lda * cols)
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(d), rows, cols, lda, C.c_uint64(5), 2.0, g.stream())
+    got = g.f64_to_host(d, lda * cols).reshape(cols, lda)[:, :rows]
+    assert g.same_bits(np.ascontiguousarray(got).reshape(-1), O.fill_uniform(rows * cols, 5, 2.0))
+
+
+def test_model_with_512_row_matrices_uses_padded_copies_and_matches_oracle():
+    n, r, m = 24, 512, 512                              # 512 rows -> column stride 4 KiB -> padded device copies
+    rng = np.random.default_rng(0)
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    x = [Variable(model) for _ in range(n)]
+    A = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((r, n)), model)
+    b = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(r)), np.zeros(r), model)
+    Cd = P.DeviceUniformParameter((m, n), 3, model)
+    d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, Cd * x == d)
+    for _ in range(2):
+        P.solve(model)
+        assert A._dev.lda == 576 and Cd._dev.lda == 576
+        xi = np.arange(1, n + 1, dtype=np.int64)
+        w = O.LsqWorkspace(n, r, m)
+        w.eval_objective(np.asfortranarray(A()).reshape(-1, order="F"), b(), xi)
+        w.objective.canonicalize()
+        at, qt, const = w.objective.moi()
+        f = model.objective.f
+        assert np.array_equal(f.quadratic_terms["row"], qt["row"]) and np.array_equal(f.quadratic_terms["col"], qt["col"])
+        np.testing.assert_allclose(f.quadratic_terms["coeff"], qt["coeff"], rtol=1e-12)
+        np.testing.assert_allclose(f.affine_terms["coeff"], at["coeff"], rtol=1e-12)
+        Ch = O.fill_uniform(m * n, 3 + 1000 * Cd.epoch).reshape(n, m).T
+        assert np.array_equal(Cd(), Ch)                                    # fetched back through the pitched copy
+        w.eval_constraint(np.ascontiguousarray(Ch.T).reshape(-1), d(), xi)
+        ct, cc = w.constraint.moi()
+        cf = list(model.constraints)[0].f
+        assert np.array_equal(cf.terms.view(np.int64), ct.view(np.int64)) and np.array_equal(cf.constants, cc)
+    assert [([(t.coeff, t.var.index) for t in fn.linear], fn.constant) for fn in res()] == \
+        O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(A(), xi), b()).as_tuples()
