@@ -66,6 +66,41 @@ __device__ __forceinline__ void sk_tri_unrank(int t, int nt, int &jb, int &kb) {
     kb = j + (t - (j * nt - j * (j - 1) / 2));
 }
 
+// L2-friendly enumeration of the upper-triangular tile grid: super-rows of 4 tile rows, each traversed column by column
+// (kb-major), so 32 consecutive tiles form a ~4 x 8 block that needs only ~12 distinct column panels.  Workgroups round-robin
+// over the 8 XCDs (bid % 8), each XCD with its own L2: at every time step the 32 workgroups of one XCD get 32 CONSECUTIVE tiles
+// of this sequence, so most panel reads hit the XCD's L2 instead of going to the fabric.
+__device__ __forceinline__ void sk_seq_unrank(int idx, int nt, int &jb, int &kb) {
+    int base = 0;
+    for (int R = 0; R * 4 < nt; ++R) {
+        const int j0 = R * 4;
+        const int h = min(4, nt - j0);                  // tile rows in this super-row
+        const int W = nt - j0;                          // columns (kb = j0 .. nt-1)
+        const int tri = h * (h + 1) / 2;                // the first h columns hold 1, 2, .., h tiles
+        const int count = tri + (W - h) * h;
+        if (idx < base + count) {
+            int p = idx - base;
+            if (p < tri) {
+                int c = 0;
+                while (p >= c + 1) { p -= c + 1; ++c; }
+                kb = j0 + c; jb = j0 + p;
+            } else {
+                p -= tri;
+                kb = j0 + h + p / h; jb = j0 + p % h;
+            }
+            return;
+        }
+        base += count;
+    }
+    jb = kb = nt - 1;
+}
+
+// sequence index of the t-th whole tile of workgroup bid (phase A)
+__device__ __forceinline__ int sk_phase_a_index(const SKArgs &g, int bid, int t) {
+    if ((g.G & 7) == 0) return (t * 8 + (bid & 7)) * (g.G >> 3) + (bid >> 3);
+    return bid * g.tfull + t;
+}
+
 __device__ __forceinline__ int64_t sk_unit_begin(const SKArgs &g, int b) { return (int64_t)b * g.U / g.G; }
 
 // (row, col) inside the 128x128 tile of accumulator r = (tm*TN + tn)*4 + s of thread tid
@@ -251,22 +286,22 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
         if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
     }
     __syncthreads();
-    long long tphase[4] = {0, 0, 0, 0};      // ABL == 4 only: cycles in {load issue, MFMA block issue, LDS stores, barrier}
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
-        const long long t0 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
-        if (ABL != 2 && s + 1 < nstage) {
-            const int64_t inext = stage_row(s + 1);
-            sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
-            if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
-        }
-        const long long t1 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
         const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
         // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
         // a whole stage ahead (fully unrolled it spills ~100 VGPRs)
 #pragma unroll(TN == 4 ? 1 : BK / 4)
         for (int ks = 0; ks < BK / 4; ++ks) {
+            // The global loads of the NEXT stage are issued after the first k-step's MFMAs are queued, not at the top of the
+            // stage: right after the barrier both waves of a SIMD would otherwise spend ~450 cycles issuing loads with the
+            // matrix pipe idle (in-kernel s_memtime stamps, profiles/r01c_gram_phases.txt).
+            if (ks == (BK / 4 > 1 ? 1 : 0) && ABL != 2 && s + 1 < nstage) {
+                const int64_t inext = stage_row(s + 1);
+                sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
+                if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
+            }
             double a[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) a[t] = (ABL == 1) ? (double)(tid + t) : pj[t * 16 * GP + ks * 4];
@@ -293,22 +328,11 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
                         acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
             }
         }
-        const long long t2 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         if (ABL != 2 && s + 1 < nstage) {
             sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
             if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
         }
-        const long long t3 = (ABL == 4) ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
-        if (ABL == 4) {
-            const long long t4 = (long long)__builtin_readcyclecounter();
-            tphase[0] += t1 - t0; tphase[1] += t2 - t1; tphase[2] += t3 - t2; tphase[3] += t4 - t3;
-        }
-    }
-    if (ABL == 4 && blockIdx.x == 0 && lane == 0 && g.ws) {       // profiling aid: per-wave phase totals of workgroup 0 (last segment wins)
-        double *dbg = g.ws + (int64_t)1000 * SLOT + wave * 8;
-        for (int k = 0; k < 4; ++k) dbg[k] = (double)tphase[k];
-        dbg[4] = (double)nstage;
     }
 }
 
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
-        sk_tri_unrank(bid * g.tfull + t, g.ntiles, jb, kb);
+        sk_seq_unrank(sk_phase_a_index(g, bid, t), g.ntiles, jb, kb);
         double acc[C::NACC];
         sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
         sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
         const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
         const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
         int jb, kb;
-        sk_tri_unrank(tile, g.ntiles, jb, kb);
+        sk_seq_unrank(tile, g.ntiles, jb, kb);
         const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
         const bool diag = (jb == kb);
         const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
@@ -488,7 +512,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         for (int r = 0; r < 4; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
-    sk_tri_unrank(tile, g.ntiles, jb, kb);
+    sk_seq_unrank(tile, g.ntiles, jb, kb);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         int row, col;
@@ -533,7 +557,6 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
         else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
-        else if (abl == 4) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 4>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
     } while (0)
     if (variant == 0) SK_LAUNCH(4, 16, 2);

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collects the round's measurement artefacts on the GPU box into gpurun_out/<tag>/ (copy the summaries into profiles/ afterwards):
+#   bench JSON (default run), rocprofv3 --kernel-trace --stats of the same command, PMC FETCH_SIZE / WRITE_SIZE in separate passes.
+# usage: gpurun -- 'bash tools/collect_profiles.sh r01c'
+set -u
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+python bench.py --workload batch > "$OUT/bench_batch.json" 2> /dev/null
+python - "$OUT" <<'PY'
+import csv, collections, glob, json, sys
+out = sys.argv[1]
+f = collections.defaultdict(list); w = collections.defaultdict(list)
+for r in csv.DictReader(open(glob.glob(out + "/pmc_fetch/*/*counter_collection.csv")[0])):
+    f[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+for r in csv.DictReader(open(glob.glob(out + "/pmc_write/*/*counter_collection.csv")[0])):
+    w[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+res = {"_note": "per-launch HBM-side bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950 correction) x1024, "
+                "WRITE_SIZE x1024; `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; tag " + out}
+for k in f:
+    if "pmt::" in k and k in w:
+        res[k] = {"read_bytes": 2 * 1024 * sum(f[k]) / len(f[k]), "write_bytes": 1024 * sum(w[k]) / len(w[k]), "launches": len(f[k])}
+json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
+b = json.load(open(out + "/bench.json"))
+print("bench:", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], b["roofline_affine"]["achieved"], b["roofline_affine"]["frac"])
+print(open(glob.glob(out + "/stats/*/*kernel_stats.csv")[0]).read()[:1200])
+for k, v in res.items():
+    if k != "_note": print(k, round(v["read_bytes"] / 1e6, 1), round(v["write_bytes"] / 1e6, 1))
+PY
