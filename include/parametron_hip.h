@@ -172,6 +172,14 @@ int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
                       int moi, const int64_t *varmap,
                       pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
                       void *workspace, void *stream);
+/* The same node with the solver hand-off fused into the epilogue (see "Solver hand-off" below): the values of P's upper
+ * triangle in CSC order, out_P_values[k(k+1)/2 + j] = alpha * 2 * sum_i A[i,j]*A[i,k] (j <= k) — valid as the CSC value array
+ * whenever j -> vm[xvar[j]] is strictly increasing (col_ptr[c] counts the variables below, row indices follow).  out_quad
+ * (MOI terms, as above with moi = 1) is optional here: NULL skips the 24-byte term structs entirely.  out_lin / out_const as above. */
+int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                          const int64_t *xvar, const double *b, int sign, const int64_t *varmap,
+                          double alpha, double *out_P_values, pmt_quadratic_term *out_quad,
+                          pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
 
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
  * bilinearmul! src/functions.jl:840-858 (the Q' pairing quirk is reproduced).
@@ -216,6 +224,28 @@ int pmt_canonical_order_quadratic(int64_t n, const int64_t *host_rows, const int
                                   int64_t *host_out_rows, int64_t *host_out_cols, int64_t *nseg);
 int pmt_segment_sum_f64(const void *in_terms, int64_t in_stride_bytes, const int64_t *perm, const int64_t *seg_ptr, int64_t nseg,
                         void *out_terms, int64_t out_stride_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Solver hand-off: what happens AFTER MOI.set(optimizer, ...) (src/moi_interop.jl:134,171) — in the
+ * reference third-party code (MathOptInterface 0.8 + the OSQP wrapper) on the host.  Here the MOI buffers stay in HBM and
+ *     minimize 1/2 x'Px + q'x   subject to   l <= Ax <= u      (P upper triangular; P, A in CSC with 0-based Int64 indices)
+ * is rebuilt on the device: the CSC structure depends only on the static indices (pmt_csc_order, host, once), the values are
+ * per-run sums of MOI coefficients (pmt_csc_values_f64, per re-evaluation), the bounds come from the constants and the set.
+ *   pmt_csc_order: rows/cols are the 1-BASED optimizer indices as they stand in the MOI terms; `upper` folds (i,j) onto
+ *     (min,max) (ScalarQuadraticTerm: Q_ij = Q_ji).  Outputs: perm[nnz_in] (terms sorted by column, then row, stable), seg_ptr[nnz_out+1]
+ *     (runs of equal (row, col)), col_ptr[ncols+1], row_idx[nnz_out] (0-based), *nnz_out.  Arrays sized for nnz_in suffice.
+ *   pmt_csc_values_f64: dst[dst_index ? dst_index[s] : s] = alpha * sum_{p in run s} coeff(perm[p]); src_coeff points at the
+ *     coefficient field of term 0 (offset 0 for linear/quadratic terms, 8 for pmt_vector_affine_term), stride = sizeof(term).
+ *     dst_index places a block's entries inside a larger matrix (several constraint blocks stacked) or scatters q.
+ *   pmt_qp_bounds_f64: row i of `f(x) in set`, f = a'x + c:  l = u = v - c (EQUAL) | l = v - c, u = +infty (GREATER) | l = -infty, u = v - c (LESS).
+ * ------------------------------------------------------------------------------------- */
+enum { PMT_SET_EQUAL = 0, PMT_SET_GREATER = 1, PMT_SET_LESS = 2 };
+int pmt_csc_order(int64_t nnz_in, const int64_t *host_rows, const int64_t *host_cols, int64_t nrows, int64_t ncols, int upper,
+                  int64_t *host_perm, int64_t *host_seg_ptr, int64_t *host_col_ptr, int64_t *host_row_idx, int64_t *nnz_out);
+int pmt_csc_values_f64(const void *src_coeff, int64_t src_stride_bytes, int64_t nnz_in, const int64_t *perm, const int64_t *seg_ptr,
+                       int64_t nnz_out, double alpha, const int64_t *dst_index, double *dst_values, void *stream);
+int pmt_qp_bounds_f64(const double *consts, int64_t rows, int set_kind, double set_value, double infty, double *l, double *u,
+                      void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse constraint matrix (BASELINE config 5): C given in CSC (Julia SparseMatrixCSC: colptr/rowval

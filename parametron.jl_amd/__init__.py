@@ -16,6 +16,7 @@ from . import moi  # noqa: F401
 from .model import (AbstractOptimizer, Maximize, Minimize, MockOptimizer, Model, constraint, dualstatus, initialize,  # noqa: F401
                     mock_model, objective, objectivevalue, primalstatus, setdirty, setobjective, solve,
                     terminationstatus, update, value)
+from .handoff import DeviceQP  # noqa: F401
 
 findallocs = None  # the reference's per-node allocation report (src/debug.jl) has a device analogue: profile_report()
 

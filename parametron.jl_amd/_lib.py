@@ -59,6 +59,7 @@ SIGNATURES = {
     "pmt_quad_expand_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_quad_gram_csc_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_fill_uniform_matrix_f64": (_ci, [_vp, _i64, _i64, _i64, _u64, _f64, _vp]),
     "pmt_plan_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
@@ -71,6 +72,9 @@ SIGNATURES = {
     "pmt_canonical_order_affine": (_ci, [_i64, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pmt_canonical_order_quadratic": (_ci, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pmt_segment_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "pmt_csc_order": (_ci, [_i64, _vp, _vp, _i64, _i64, _ci, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pmt_csc_values_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
+    "pmt_qp_bounds_f64": (_ci, [_vp, _i64, _ci, _f64, _f64, _vp, _vp, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_sparse_assemble_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),

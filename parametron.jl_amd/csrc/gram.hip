@@ -22,7 +22,7 @@ namespace pmt {
 int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s);
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, void *workspace, hipStream_t s);
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s);
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -257,16 +257,17 @@ extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
     return gram_sk_workspace_bytes(rows, cols);
 }
 
-extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
-                                 int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
-                                 void *workspace, void *stream) {
-    (void)workspace;
+// the whole node: contraction on the main stream, q = 2A'c and c'c on a side stream.  out_quad (term structs) and out_csc (solver
+// values, alpha-scaled) are independent optional outputs of the same contraction.
+static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                     int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
+                     double *out_const, void *workspace, void *stream) {
     PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "quad_gram: negative dimension");
     PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "quad_gram: lda < rows");
     PMT_REQUIRE(sign >= -1 && sign <= 1, PMT_INVALID_ARGUMENT, "quad_gram: sign must be -1, 0 or +1");
     PMT_REQUIRE(out_const, PMT_INVALID_ARGUMENT, "quad_gram: null out_const");
     PMT_REQUIRE(sign == 0 || b || rows == 0, PMT_INVALID_ARGUMENT, "quad_gram: sign != 0 needs b");
-    if (cols > 0) PMT_REQUIRE(xvar && out_quad && out_lin && (A || rows == 0), PMT_INVALID_ARGUMENT, "quad_gram: null pointer");
+    if (cols > 0) PMT_REQUIRE(xvar && (out_quad || out_csc) && out_lin && (A || rows == 0), PMT_INVALID_ARGUMENT, "quad_gram: null pointer");
     PMT_REQUIRE(cols < (int64_t)GT * 46000, PMT_DIMENSION_MISMATCH, "quad_gram: too many columns");
     return dispatch(stream, [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
@@ -304,7 +305,9 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
                 return 0;
             }();
             if (impl == 0) {
-                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, workspace, s);
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, s);
+            } else if (out_csc) {
+                rc = fail(PMT_INVALID_ARGUMENT, "quad_gram_csc: only the stream-K implementation writes CSC values (unset PMT_GRAM_IMPL)");
             } else {
                 if (impl == 1) PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
                 else PMT_LAUNCH_NAMED("quad_gram_kernel", quad_gram_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
@@ -314,4 +317,18 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
         return rc;
     });
+}
+
+extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                                 int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
+                                 void *workspace, void *stream) {
+    if (cols > 0) PMT_REQUIRE(out_quad, PMT_INVALID_ARGUMENT, "quad_gram: null out_quad");
+    return gram_node(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, nullptr, 1.0, out_lin, out_const, workspace, stream);
+}
+
+extern "C" int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                                     const int64_t *varmap, double alpha, double *out_P_values, pmt_quadratic_term *out_quad,
+                                     pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream) {
+    if (cols > 0) PMT_REQUIRE(out_P_values, PMT_INVALID_ARGUMENT, "quad_gram_csc: null out_P_values");
+    return gram_node(A, lda, rows, cols, xvar, b, sign, 1, varmap, out_quad, out_P_values, alpha, out_lin, out_const, workspace, stream);
 }

@@ -37,7 +37,9 @@ constexpr int SLOT = ST * ST;      // doubles per partial-tile slot
 struct SKArgs {
     const double *A; int64_t lda, rows, cols;
     const int64_t *xvar; const int64_t *varmap; int moi;
-    QT *out_quad;
+    QT *out_quad;     // MOI / native QuadraticTerms at the canonical row-major upper-triangular position, or null
+    double *out_csc;  // solver form: alpha * (MOI coefficient) at k(k+1)/2 + j (CSC of the upper triangle, values only), or null
+    double alpha;
     int ntiles, nchunk, G;
     int tfull;        // whole tiles per workgroup (phase A); tiles [tfull*G, T) are split along the contraction (phase B)
     int64_t U;        // number of (tile, chunk) units of phase B = (T - tfull*G) * nchunk
@@ -119,9 +121,11 @@ __device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, i
     const int64_t n = g.cols;
     const int64_t j = (int64_t)jb * ST + row, k = (int64_t)kb * ST + col;
     if (k >= n || j >= n || j > k) return;
-    const int64_t jv = g.xvar[j], kv = g.xvar[k];
     double c = v;
     if (g.moi || j != k) c = 2 * c;          // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
+    if (g.out_csc) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
+    if (!g.out_quad) return;
+    const int64_t jv = g.xvar[j], kv = g.xvar[k];
     const int64_t pos = j * n - (j * (j - 1)) / 2 + (k - j);
     u64 *p = reinterpret_cast<u64 *>(g.out_quad) + pos * 3;
     p[0] = (u64)__double_as_longlong(c);
@@ -151,12 +155,12 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
     u64 *out = reinterpret_cast<u64 *>(g.out_quad);
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
-        if (h == 0 && tid < 128) {
+        if (g.out_quad && h == 0 && tid < 128) {
             const int64_t k = k0 + tid;
             const int64_t kv = k < n ? g.xvar[k] : 1;
             cmap[tid] = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
         }
-        if (tid >= 128 && tid < 192) {
+        if (g.out_quad && tid >= 128 && tid < 192) {
             const int64_t j = j0 + h * 64 + (tid - 128);
             const int64_t jv = j < n ? g.xvar[j] : 1;
             rmap[tid - 128] = (u64)(g.moi ? map_var(g.varmap, jv) : jv);
@@ -172,7 +176,16 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
             }
         }
         __syncthreads();
-        for (int row = wave; row < 64; row += C::NW) {
+        if (g.out_csc) {
+            // column k of the tile holds rows j0+64h .. of CSC column k: 64 lanes = 64 consecutive doubles (LDS pitch 129: conflict-free)
+            const int64_t j = j0 + h * 64 + lane;
+            for (int col = wave; col < ST; col += C::NW) {
+                const int64_t k = k0 + col;
+                if (k >= n) break;
+                if (j <= k) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * tile[lane * EPITCH + col];
+            }
+        }
+        for (int row = wave; g.out_quad && row < 64; row += C::NW) {
             const int64_t j = j0 + h * 64 + row;
             if (j >= n) break;
             const int64_t kstart = j > k0 ? j : k0;
@@ -532,9 +545,10 @@ static int env_int(const char *name, int dflt) {
 }
 
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, void *workspace, hipStream_t s) {
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s) {
     SKArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
+    g.out_csc = out_csc; g.alpha = alpha;
     g.ntiles = (int)cdiv(cols, ST);
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
     const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;

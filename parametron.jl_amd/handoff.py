@@ -1,0 +1,217 @@
+"""Device-resident solver hand-off.
+
+In the reference the data leaves Parametron at `MOI.set(optimizer, ObjectiveFunction / ConstraintFunction, f)`
+(src/moi_interop.jl:134,171); MathOptInterface 0.8 and the solver wrapper (OSQP.jl, ...) then rebuild the solver's
+matrices from the term lists on the host.  `DeviceQP` does that step in HBM, so a GPU QP solver — or a host solver that
+wants 67 MB of CSC values instead of 252 MB of term structs — reads
+
+    minimize 1/2 x'Px + q'x + r   subject to   l <= Ax <= u
+
+with P upper triangular and P, A in CSC (0-based Int64 indices, OSQP's C layout).  The CSC structure depends only on the
+static indices and is computed once (pmt_csc_order, host); `refresh()` rebuilds the values from the model's device MOI
+buffers (pmt_csc_values_f64, pmt_qp_bounds_f64) after `update!(model)`.  Constraint rows are stacked in the reference's
+update order (src/moi_interop.jl:236-247).  Maximize is handed over as minimize of the negated objective.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, moi
+from ._lib import ArgumentError, ErrorException
+from .device import P
+
+_SET_KIND = {moi.EqualTo: 0, moi.Zeros: 0, moi.GreaterThan: 1, moi.Nonnegatives: 1, moi.LessThan: 2, moi.Nonpositives: 2}
+DEFAULT_INFTY = 1e20
+
+
+def _csc_order(rows, cols, nrows, ncols, upper):
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    n = len(rows)
+    perm, seg = np.zeros(max(n, 1), dtype=np.int64), np.zeros(n + 1, dtype=np.int64)
+    col_ptr, row_idx = np.zeros(ncols + 1, dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+    nnz = C.c_int64(0)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.call("pmt_csc_order", n, vp(rows), vp(cols), int(nrows), int(ncols), int(bool(upper)), vp(perm), vp(seg), vp(col_ptr), vp(row_idx),
+              C.byref(nnz))
+    k = nnz.value
+    return perm[:n], seg[:k + 1], col_ptr, row_idx[:k]
+
+
+class _Block:
+    """One source of matrix entries: a device term buffer (or host values for constant functions) and where its runs go."""
+
+    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None):
+        self.rows, self.cols, self.coeff_ptr, self.stride, self.host_coeff = rows, cols, coeff_ptr, stride, host_coeff
+
+
+class CSC:
+    def __init__(self, nrows, ncols, col_ptr, row_idx, values_ptr):
+        self.shape = (nrows, ncols)
+        self.col_ptr, self.row_idx, self.values_ptr = col_ptr, row_idx, values_ptr
+        self.nnz = len(row_idx)
+
+
+class DeviceQP:
+    def __init__(self, model, infty=DEFAULT_INFTY):
+        if not model.initialized:
+            raise ErrorException("DeviceQP needs an initialized model (initialize!(model) / solve!(model) first)")
+        self.model, self.infty = model, float(infty)
+        ctx = self.ctx = model.device()
+        if model._records:
+            model._run_tape()                     # host MOI buffers now carry the optimizer's indices (after mapindices!)
+        vm = model.model_var_to_optimizer
+        self.nvars = n = int(vm.max()) if len(vm) else 0
+        self.sign = -1.0 if model.sense == "Maximize" else 1.0
+        self._launches = []
+
+        # ---- objective: P (upper triangular), q, r
+        obj = model.objective
+        f = obj.f
+        qblocks, lblocks = [], []
+        direct_P = None
+        if obj.kind == "quad" and not obj.isconstant and "P_values" in obj.dev:
+            # the plan was specialised (moi._Record.compile): the Gram epilogue already writes sign * P in CSC order;
+            # column c of P belongs to the variable with optimizer index c+1, its rows are the variables before it
+            pv = obj.dev["P_vars"] - 1                                   # 0-based optimizer indices, strictly increasing
+            k = len(pv)
+            col_ptr = np.zeros(n + 1, dtype=np.int64)
+            col_ptr[pv + 1] = np.arange(1, k + 1)
+            col_ptr = np.cumsum(col_ptr)
+            direct_P = CSC(n, n, col_ptr, pv[np.tril_indices(k)[1]].astype(np.int64), obj.dev["P_values"])
+            at = f.affine_terms
+            lblocks.append(_Block(at["var"].copy(), None, obj.dev["lin"], 16))
+        elif obj.kind == "quad":
+            qt, at = f.quadratic_terms, f.affine_terms
+            if obj.isconstant:
+                qblocks.append(_Block(vm[qt["row"] - 1], vm[qt["col"] - 1], host_coeff=qt["coeff"].copy()))
+                lblocks.append(_Block(vm[at["var"] - 1], None, host_coeff=at["coeff"].copy()))
+            else:
+                qblocks.append(_Block(qt["row"].copy(), qt["col"].copy(), obj.dev["quad"], 24))
+                lblocks.append(_Block(at["var"].copy(), None, obj.dev["lin"], 16))
+        else:
+            at = f.terms
+            if obj.isconstant:
+                lblocks.append(_Block(vm[at["var"] - 1], None, host_coeff=at["coeff"].copy()))
+            else:
+                lblocks.append(_Block(at["var"].copy(), None, obj.dev["terms"], 16))
+        self.P = direct_P if direct_P is not None else self._build_matrix(qblocks, n, n, upper=True, alpha=self.sign)
+        self.q_ptr = ctx.alloc(8 * max(n, 1))
+        ctx.upload(self.q_ptr, np.zeros(max(n, 1)))
+        for b in lblocks:
+            self._add_vector_block(b, n, self.q_ptr, self.sign)
+        self._obj_const = (None if obj.isconstant else obj.dev["const"], float(f.constant) if obj.isconstant else 0.0)
+
+        # ---- constraints: A, l, u (rows stacked in update! order)
+        ablocks, bounds, row0 = [], [], 0
+        for c in model.constraints:
+            if c.kind == "single":
+                raise ArgumentError("DeviceQP: integer / binary constraints have no place in a QP hand-off")
+            if c.kind == "quad":
+                raise ArgumentError("DeviceQP: quadratic constraints are not part of the OSQP form")
+            kind = _SET_KIND[type(c.set)]
+            value = float(c.set.value) if isinstance(c.set, (moi.EqualTo, moi.GreaterThan, moi.LessThan)) and c.set.value is not None else 0.0
+            if c.kind == "aff":
+                t = c.f.terms
+                rows = np.full(len(t), row0 + 1, dtype=np.int64)
+                if c.isconstant:
+                    ablocks.append(_Block(rows, vm[t["var"] - 1], host_coeff=t["coeff"].copy()))
+                    bounds.append((row0, 1, kind, value, None, np.array([c.f.constant], dtype=np.float64)))
+                else:
+                    ablocks.append(_Block(rows, t["var"].copy(), c.dev["terms"], 16))
+                    bounds.append((row0, 1, kind, value, c.dev["const"], None))
+            else:
+                t = c.f.terms
+                if c.isconstant:
+                    ablocks.append(_Block(t["out"] + row0, vm[t["var"] - 1], host_coeff=t["coeff"].copy()))
+                    bounds.append((row0, c.nrows, kind, value, None, np.asarray(c.f.constants, dtype=np.float64).copy()))
+                else:
+                    ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8, 24))
+                    bounds.append((row0, c.nrows, kind, value, c.dev["consts"], None))
+            row0 += c.nrows
+        self.nrows = m = row0
+        self.A = self._build_matrix(ablocks, m, n, upper=False, alpha=1.0)
+        self.l_ptr, self.u_ptr = ctx.alloc(8 * max(m, 1)), ctx.alloc(8 * max(m, 1))
+        for (r0, nr, kind, value, dev_consts, host_consts) in bounds:
+            if dev_consts is None:                                     # constant function: bounds never change
+                b = value - host_consts
+                lo = np.full(nr, -self.infty) if kind == 2 else b
+                hi = np.full(nr, self.infty) if kind == 1 else b
+                ctx.upload(self.l_ptr + 8 * r0, lo); ctx.upload(self.u_ptr + 8 * r0, hi)
+            else:
+                self._launches.append(("pmt_qp_bounds_f64", (P(dev_consts), nr, kind, value, self.infty, P(self.l_ptr + 8 * r0), P(self.u_ptr + 8 * r0))))
+        ctx.synchronize()
+        self.refresh()
+
+    # ---- structure
+    def _build_matrix(self, blocks, nrows, ncols, upper, alpha):
+        ctx = self.ctx
+        local = []
+        for b in blocks:
+            perm, seg, col_ptr, row_idx = _csc_order(b.rows, b.cols, nrows, ncols, upper)
+            cols = np.repeat(np.arange(ncols, dtype=np.int64), np.diff(col_ptr))
+            local.append((b, perm, seg, cols, row_idx))
+        # union of the blocks' entries in CSC order; entries of different blocks never coincide for A (disjoint rows), and P has one block
+        allc = np.concatenate([l[3] for l in local]) if local else np.zeros(0, dtype=np.int64)
+        allr = np.concatenate([l[4] for l in local]) if local else np.zeros(0, dtype=np.int64)
+        key = allc * max(nrows, 1) + allr
+        ukey, inverse = np.unique(key, return_inverse=True)
+        if len(ukey) != len(key):
+            raise ArgumentError("DeviceQP: two blocks contribute to the same matrix entry")
+        ucols, urows = ukey // max(nrows, 1), ukey % max(nrows, 1)
+        col_ptr = np.zeros(ncols + 1, dtype=np.int64)
+        np.add.at(col_ptr, ucols + 1, 1)
+        col_ptr = np.cumsum(col_ptr)
+        values = ctx.alloc(8 * max(len(ukey), 1))
+        static = np.zeros(max(len(ukey), 1))
+        pos = 0
+        for (b, perm, seg, cols, row_idx) in local:
+            k = len(row_idx)
+            dst = np.ascontiguousarray(inverse[pos:pos + k], dtype=np.int64)
+            pos += k
+            if b.host_coeff is not None:
+                sums = np.add.reduceat(b.host_coeff[perm], seg[:-1]) if k else np.zeros(0)
+                static[dst] = alpha * sums
+            elif k:
+                identity = len(local) == 1
+                self._launches.append(("pmt_csc_values_f64", (P(b.coeff_ptr), b.stride, len(perm), P(ctx.upload_new(perm)), P(ctx.upload_new(seg)), k,
+                                                              alpha, None if identity else P(ctx.upload_new(dst)), P(values))))
+        ctx.upload(values, static)
+        return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), values)
+
+    def _add_vector_block(self, b, n, q_ptr, alpha):
+        ctx = self.ctx
+        k = len(b.rows)
+        if k == 0:
+            return
+        perm, seg, _, row_idx = _csc_order(b.rows, np.ones(k, dtype=np.int64), n, 1, False)
+        if b.host_coeff is not None:
+            q = np.zeros(n); q[row_idx] = alpha * np.add.reduceat(b.host_coeff[perm], seg[:-1])
+            ctx.upload(q_ptr, q)
+        else:
+            self._launches.append(("pmt_csc_values_f64", (P(b.coeff_ptr), b.stride, k, P(ctx.upload_new(perm)), P(ctx.upload_new(seg)), len(row_idx),
+                                                          alpha, P(ctx.upload_new(row_idx)), P(q_ptr))))
+
+    # ---- per re-evaluation
+    def refresh(self):
+        """Rebuild P.x, q, A.x, l, u from the model's current device MOI buffers (call after update!(model) / solve!(model))."""
+        for name, args in self._launches:
+            self.ctx.call(name, *args)
+
+    # ---- host views (tests, host solvers)
+    def _f64(self, ptr, n):
+        out = np.empty(n)
+        self.ctx.fetch(out, ptr, 8 * n)
+        self.ctx.synchronize()
+        return out
+
+    def fetch(self):
+        """dict(P=(x, i, p), q, r, A=(x, i, p), l, u) on the host; r is the objective constant."""
+        cptr, cval = self._obj_const
+        r = float(self._f64(cptr, 1)[0]) if cptr else cval
+        return {
+            "P": (self._f64(self.P.values_ptr, self.P.nnz), self.P.row_idx, self.P.col_ptr),
+            "q": self._f64(self.q_ptr, self.nvars), "r": self.sign * r,
+            "A": (self._f64(self.A.values_ptr, self.A.nnz), self.A.row_idx, self.A.col_ptr),
+            "l": self._f64(self.l_ptr, self.nrows), "u": self._f64(self.u_ptr, self.nrows),
+        }

@@ -83,6 +83,9 @@ class MockOptimizer(AbstractOptimizer):
             self.sets[i] = c.set
         return {"variables": np.arange(1, backend.nvars + 1, dtype=np.int64) + self.variable_offset, "constraints": cmap}
 
+    def set_device_qp(self, qp):
+        self.device_qp = qp
+
     def set_objective_function(self, f):
         self.objective = f
         self.set_calls += 1
@@ -118,9 +121,13 @@ class _Backend:
 
 
 class Model:
-    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False):       # src/model.jl:10-22
+    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False, handoff="moi"):       # src/model.jl:10-22
         if quadratic_mode not in ("auto", "literal", "canonical"):
             raise ArgumentError("quadratic_mode must be 'auto', 'literal' or 'canonical'")
+        if handoff not in ("moi", "device"):
+            raise ArgumentError("handoff must be 'moi' (host MOI functions, the reference's boundary) or 'device' (CSC data in HBM)")
+        self.handoff = handoff
+        self.device_qp = None
         self.params = []
         self.optimizer = optimizer
         self.initialized = False
@@ -201,18 +208,26 @@ class Model:
         backend = _Backend(self.nvars, self.sense, self.objective, list(self.constraints))
         records = [r for r in [self.objective] + list(self.constraints) if not r.isconstant]
         self._records = records
+        early = self.handoff == "device"
+        if early:
+            # device hand-off: the optimizer never sees host MOI functions, so the index map is fixed BEFORE the plan is recorded and
+            # the plan can be specialised on it (P's CSC values straight from the contraction when the variable order is preserved)
+            indexmap = self.optimizer.copy_to(backend)
+            for c in self.constraints:
+                c.optimizerindex = indexmap["constraints"][c]
+            self.model_var_to_optimizer = np.asarray(indexmap["variables"], dtype=np.int64).copy()
         if records:
             ctx = self.device()
             self._varmap_buf = ctx.alloc(8 * max(self.nvars, 1))
             ident = np.arange(1, self.nvars + 1, dtype=np.int64)     # IdentityVarMap until mapindices! (src/moi_interop.jl:32-33)
-            ctx.upload(self._varmap_buf, ident)
+            ctx.upload(self._varmap_buf, self.model_var_to_optimizer if early else ident)
             if self.quadratic_mode == "canonical":
                 # any other quadratic objective: generic device canonicalize! (sorted, duplicates combined) before the MOI copy
                 for r in records:
                     gram = getattr(r.expr, "gram_candidate", None)
                     if r.kind == "quad" and not (gram is not None and gram.xvars.strictly_increasing()):
                         r.expr = r.expr.canonicalize()
-            emitters = [r.compile(ctx, self._varmap_buf, self.quadratic_mode) for r in records]
+            emitters = [r.compile(ctx, self._varmap_buf, self.quadratic_mode, self.model_var_to_optimizer if early else None) for r in records]
             self._order = schedule([r.expr for r in records])
             for x in self._order:
                 if isinstance(x, DeviceNode):
@@ -228,11 +243,15 @@ class Model:
                 ctx.end_record()
             # first evaluation with the identity map so that copy_to sees sized, filled functions (src/moi_interop.jl:127,157)
             self._run_tape()
-        indexmap = self.optimizer.copy_to(backend)
-        self._mapindices(indexmap)
+        if not early:
+            indexmap = self.optimizer.copy_to(backend)
+            self._mapindices(indexmap)
         if records and self._use_graph:
             self.device().instantiate_graph()
         self.initialized = True
+        if self.handoff == "device":
+            from .handoff import DeviceQP
+            self.device_qp = DeviceQP(self)
 
     def _mapindices(self, indexmap):                                   # src/model.jl:100-107
         for c in self.constraints:
@@ -248,10 +267,12 @@ class Model:
             if isinstance(x, Parameter):
                 device_value_of(x, ctx)
 
-    def _run_tape(self):
+    def _run_tape(self, fetch=True):
         ctx = self.device()
         self._refresh_parameters()
         ctx.replay()
+        if not fetch:
+            return
         for r in self._records:
             r.fetch(ctx)
         ctx.synchronize()
@@ -260,6 +281,15 @@ class Model:
 
     def update(self):                                                  # src/model.jl:132-143
         self.setdirty()
+        if self.device_qp is not None:
+            # device hand-off: the MOI buffers never leave HBM; the solver's CSC data is rebuilt right behind the tape
+            if self._records:
+                self._run_tape(fetch=False)
+            self.device_qp.refresh()
+            self.device().synchronize()
+            if hasattr(self.optimizer, "set_device_qp"):
+                self.optimizer.set_device_qp(self.device_qp)
+            return
         if self._records:
             self._run_tape()
         if not self.objective.isconstant:                              # src/moi_interop.jl:131-137

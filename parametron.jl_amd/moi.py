@@ -151,8 +151,10 @@ class _Record:
             self.nrows = expr.out.rows if self.kind == "affvec" else 1
 
     # ---- device side of update!(moi_f, expr(), varmap)
-    def compile(self, ctx, varmap_buf, quadratic_mode):
-        """Allocate the MOI buffers (host + device twin) and return the emitter of the MOI copy."""
+    def compile(self, ctx, varmap_buf, quadratic_mode, handoff_varmap=None):
+        """Allocate the MOI buffers (host + device twin) and return the emitter of the MOI copy.  `handoff_varmap` (host array,
+        device hand-off only): the final model_var_to_optimizer; a Gram objective whose variables stay in increasing order under it
+        writes the solver's CSC values of P directly from the contraction's epilogue and no quadratic term structs at all."""
         out = self.expr.out
         if self.kind == "aff":
             n = out.nterms
@@ -168,6 +170,20 @@ class _Record:
             literal_terms = out.nq
             use_gram = gram is not None and gram.xvars.strictly_increasing() and (
                 quadratic_mode == "canonical" or (quadratic_mode == "auto" and literal_terms > (1 << 24)))
+            if use_gram and handoff_varmap is not None and np.all(np.diff(handoff_varmap[gram.xvars.vars - 1]) > 0):
+                n = gram.mat.cols
+                self.f = ScalarQuadraticFunction(n, 0, alloc=ctx.pinned_array)
+                dp, dl, dc = ctx.alloc(8 * max(n * (n + 1) // 2, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
+                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(gram.mat.rows, n))))
+                self.dev = {"P_values": dp, "P_vars": handoff_varmap[gram.xvars.vars - 1], "lin": dl, "const": dc}
+                self.mode = "canonical-csc"
+                vec = gram.vec.buf if gram.vec is not None else None
+                alpha = -1.0 if self.model.sense == "Maximize" else 1.0
+
+                def emit(c):
+                    c.call("pmt_quad_gram_csc_f64", P(gram.mat.buf), gram.mat.lda, gram.mat.rows, n, P(gram.xvars.buf), P(vec),
+                           gram.sign if vec else 0, P(varmap_buf), alpha, P(dp), None, P(dl), P(dc), P(ws))
+                return emit
             if use_gram:
                 n = gram.mat.cols
                 nq = n * (n + 1) // 2
@@ -235,7 +251,8 @@ class _Record:
             ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
             self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
         elif self.kind == "quad":
-            ctx.fetch(f.quadratic_terms, d["quad"], f.quadratic_terms.nbytes)
+            if "quad" in d:                                               # absent when P's CSC values are written directly
+                ctx.fetch(f.quadratic_terms, d["quad"], f.quadratic_terms.nbytes)
             ctx.fetch(f.affine_terms, d["lin"], f.affine_terms.nbytes)
             self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
         else:

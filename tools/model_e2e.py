@@ -10,7 +10,8 @@ import parametron_jl_amd as P  # noqa: E402
 
 def main():
     n, r, m = 4096, 4096, 512
-    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", use_graph="--graph" in sys.argv)
+    device = "--device-handoff" in sys.argv
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", use_graph="--graph" in sys.argv, handoff="device" if device else "moi")
     x = [P.Variable(model) for _ in range(n)]
     A = P.DeviceUniformParameter((r, n), 1, model)
     b = P.DeviceUniformParameter((r,), 2, model)
@@ -27,6 +28,13 @@ def main():
     for _ in range(k):
         P.solve(model)
     dt = (time.perf_counter() - t0) / k
+    if device:
+        qp = model.device_qp
+        t0 = time.perf_counter(); got = qp.fetch(); t_fetch = time.perf_counter() - t0
+        nb = 8 * (qp.P.nnz + qp.A.nnz + qp.nvars + 2 * qp.nrows)
+        print("device hand-off: first solve! (initialize + CSC structure) %.1f ms; steady solve! (tape + CSC values, nothing crosses PCIe) %.3f ms = %.1f /s;"
+              " P nnz %d, A nnz %d; fetching the CSC values (pageable) %.1f MB in %.1f ms" % (t_first * 1e3, dt * 1e3, 1 / dt, qp.P.nnz, qp.A.nnz, nb / 1e6, t_fetch * 1e3))
+        return
     f = model.objective.f
     nbytes = f.quadratic_terms.nbytes + f.affine_terms.nbytes + list(model.constraints)[0].f.terms.nbytes
     print("first solve! (initialize + record) %.1f ms; steady solve! %.3f ms = %.1f /s; MOI bytes fetched %.1f MB (%.1f GB/s incl. compute)"
