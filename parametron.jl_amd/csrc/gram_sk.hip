@@ -219,9 +219,9 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
     }
 }
 
-template <int TN, int BK>
+template <int TN, int BK, bool fast>
 __device__ __forceinline__ void sk_load_panel(const SKArgs &g, int64_t c0, int64_t i0, int64_t iend,
-                                              f64x2 (&reg)[Cfg<TN>::NLD * (BK / 16)], int tid, bool fast) {
+                                              f64x2 (&reg)[Cfg<TN>::NLD * (BK / 16)], int tid) {
     constexpr int KP = BK / 2;                         // 16-byte pieces per column
     constexpr int CPP = Cfg<TN>::NT / KP;              // columns covered per pass
     const int kp = tid % KP, cc = tid / KP;
@@ -273,36 +273,39 @@ __device__ __forceinline__ double dpp_row_ror(double v) {
 // acc = sum over rows [ibeg, iend) of A[i, j0 + .]' * A[i, k0 + .] for this thread's accumulators of the 128x128 tile.
 // K-contiguous column panels go global -> registers -> LDS (double buffered, one barrier per BK rows).
 // ABL: ablation switch for profiling only (0 = the kernel; 1 = no LDS operand reads; 2 = no global loads / LDS stores).
-template <int TN, int BK, int ABL>
-__device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64_t k0, bool diag, int64_t ibeg, int64_t iend,
-                                              double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
+// FAST: whole 128-column panels, aligned 16-byte loads, a multiple of BK rows — no bounds checks and no conditionals, so the stage
+// body is ONE basic block and the compiler interleaves the global loads and LDS traffic with the MFMA stream and sinks half of a
+// stage's MFMAs below the barrier (1.29 -> 1.20 ms at n = r = 4096; with the bounds-checked loads the body was ~40 blocks).
+template <int TN, int BK, int ABL, bool FAST>
+__device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, int64_t k0, bool diag, int64_t ibeg, int64_t iend,
+                                                   double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
     using C = Cfg<TN>;
     constexpr int GP = BK + 1;
     constexpr int NREG = C::NLD * (BK / 16);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave / C::NWC, wc = wave % C::NWC;
     const int lm = lane & 15, lk = lane >> 4;
+    (void)diag;   // diagonal tiles load their one panel twice (6 % of the tiles, L2 hits) rather than branch inside the stage loop
 #pragma unroll
     for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
 
     const int nstage = (int)((iend - ibeg + BK - 1) / BK);
-    const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
     // (A per-workgroup stagger of the contraction order and a padded lda were both tried against channel hot-spotting of the
     // 32 KiB column stride: neither changes this kernel's time once the GPU is warm — profiles/r01c_lda_padding.txt.)
     auto stage_row = [&](int s) { return ibeg + (int64_t)s * BK; };
     f64x2 rj[NREG], rk[NREG];
     __syncthreads();                                   // previous users of the LDS buffers are done
     if (nstage > 0) {
-        sk_load_panel<TN, BK>(g, j0, stage_row(0), iend, rj, tid, fast);
-        if (!diag) sk_load_panel<TN, BK>(g, k0, stage_row(0), iend, rk, tid, fast);
+        sk_load_panel<TN, BK, FAST>(g, j0, stage_row(0), iend, rj, tid);
+        sk_load_panel<TN, BK, FAST>(g, k0, stage_row(0), iend, rk, tid);
         sk_store_panel<TN, BK>(lds[0][0], rj, tid);
-        if (!diag) sk_store_panel<TN, BK>(lds[0][1], rk, tid);
+        sk_store_panel<TN, BK>(lds[0][1], rk, tid);
     }
     __syncthreads();
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
         const double *pj = lds[cur][0] + (wr * 64 + lm) * GP + lk;
-        const double *pk = lds[cur][diag ? 0 : 1] + (wc * C::WCOLS) * GP + lk;
+        const double *pk = lds[cur][1] + (wc * C::WCOLS) * GP + lk;
         // TN == 4 (128 accumulator VGPRs, 256-VGPR budget): keep the k-step loop rolled so operand reads are not hoisted
         // a whole stage ahead (fully unrolled it spills ~100 VGPRs)
 #pragma unroll(TN == 4 ? 1 : BK / 4)
@@ -310,10 +313,11 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
             // The global loads of the NEXT stage are issued after the first k-step's MFMAs are queued, not at the top of the
             // stage: right after the barrier both waves of a SIMD would otherwise spend ~450 cycles issuing loads with the
             // matrix pipe idle (in-kernel s_memtime stamps, profiles/r01c_gram_phases.txt).
-            if (ks == (BK / 4 > 1 ? 1 : 0) && ABL != 2 && s + 1 < nstage) {
-                const int64_t inext = stage_row(s + 1);
-                sk_load_panel<TN, BK>(g, j0, inext, iend, rj, tid, fast);
-                if (!diag) sk_load_panel<TN, BK>(g, k0, inext, iend, rk, tid, fast);
+            // (FAST: unconditional — the last stage re-loads itself — so the stage body stays one basic block)
+            if (ks == (BK / 4 > 1 ? 1 : 0) && ABL != 2 && (FAST || s + 1 < nstage)) {
+                const int64_t inext = stage_row(FAST ? min(s + 1, nstage - 1) : s + 1);
+                sk_load_panel<TN, BK, FAST>(g, j0, inext, iend, rj, tid);
+                sk_load_panel<TN, BK, FAST>(g, k0, inext, iend, rk, tid);
             }
             double a[4];
 #pragma unroll
@@ -341,12 +345,20 @@ __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64
                         acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
             }
         }
-        if (ABL != 2 && s + 1 < nstage) {
+        if (ABL != 2 && (FAST || s + 1 < nstage)) {
             sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
-            if (!diag) sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
+            sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
         }
         __syncthreads();
     }
+}
+
+template <int TN, int BK, int ABL>
+__device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64_t k0, bool diag, int64_t ibeg, int64_t iend,
+                                              double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
+    const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
+    if (fast) sk_accumulate_impl<TN, BK, ABL, true>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
+    else sk_accumulate_impl<TN, BK, ABL, false>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
 }
 
 // ---- batched instances (BASELINE config 4): one workgroup per (instance, tile), coefficient-only output ----------------

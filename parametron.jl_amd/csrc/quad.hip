@@ -101,27 +101,47 @@ __global__ void quad_expand_linear_kernel(int64_t rows, const LT *__restrict__ x
 
 // out = ((0 + a0*b0) + a1*b1) + ...  strictly left to right (src/functions.jl:574 under the loop of :705-707).
 // sign_a / sign_b: 2 = use the array as is; -1/0/+1 = use 0.0 (+|-) value (constants of a fused A*x (+|-) b node).
-__global__ __launch_bounds__(256) void seq_dot_kernel(const double *__restrict__ a, int sign_a, const double *__restrict__ b, int sign_b,
-                                                      int64_t n, double *__restrict__ out) {
-    __shared__ double prod[1024];
+// One wave, at most 16 VGPRs: the persistent Gram kernel holds 2 x 248 of a SIMD's 512 VGPRs, so only a kernel this small is
+// CO-RESIDENT with it on the side stream (anything bigger waits for its workgroups to drain and lands on the critical path —
+// profiles/r01d_side_stream.txt).  Lane l holds the product of element base + l; the chain runs over v_readlane broadcasts, the
+// next 64 products are loaded while the current 64 are added.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool SAME>
+__global__ __launch_bounds__(64) void seq_dot_kernel(const double *__restrict__ a, int sign_a, const double *__restrict__ b, int sign_b,
+                                                     int n, double *__restrict__ out) {
+    const int lane = threadIdx.x;
+    auto product = [&](int i) -> double {                  // 32-bit indices: uniform base pointer + lane offset, few registers
+        if (i >= n) return 0.0;
+        const double av = sign_a == 2 ? a[i] : signed_const(a[i], sign_a);
+        if (SAME) return av * av;
+        const double bv = sign_b == 2 ? b[i] : signed_const(b[i], sign_b);
+        return av * bv;
+    };
     double acc = 0.0;
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int cnt = (int)min((int64_t)1024, n - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
-            const double av = sign_a == 2 ? a[base + k] : signed_const(a[base + k], sign_a);
-            const double bv = sign_b == 2 ? b[base + k] : signed_const(b[base + k], sign_b);
-            prod[k] = av * bv;
+    double p = product(lane);
+    for (int base = 0; base < n; base += 64) {
+        const double cur = p;
+        p = product(base + 64 + lane);                      // in flight during the chain below
+        const int left = n - base;
+        if (left >= 64) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc = acc + readlane_f64(cur, j);
+        } else {
+            for (int j = 0; j < left; ++j) acc = acc + readlane_f64(cur, j);
         }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int k = 0; k < cnt; ++k) acc = acc + prod[k];
     }
-    if (threadIdx.x == 0) *out = acc;
+    if (lane == 0) *out = acc;
 }
 
 int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s) {
-    PMT_LAUNCH(seq_dot_kernel, dim3(1), dim3(256), 0, s, a, sign_a, b, sign_b, n, out);
+    if (n >= ((int64_t)1 << 31) - 64) return fail(PMT_DIMENSION_MISMATCH, "seq_dot: vector too long");
+    if (a == b && sign_a == sign_b) PMT_LAUNCH_NAMED("seq_dot_kernel", seq_dot_kernel<true>, dim3(1), dim3(64), 0, s, a, sign_a, b, sign_b, (int)n, out);
+    else PMT_LAUNCH_NAMED("seq_dot_kernel", seq_dot_kernel<false>, dim3(1), dim3(64), 0, s, a, sign_a, b, sign_b, (int)n, out);
     return check_launch("seq_dot_kernel");
 }
 

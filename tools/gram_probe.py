@@ -31,11 +31,11 @@ def main():
 
         def run():
             _lib.call("pmt_quad_gram_f64", dptr(A), r, r, n, dptr(xvar), dptr(b), -1, 1, dptr(xvar), dptr(Q), dptr(q), dptr(c), dptr(ws), stream)
-        for _ in range(2):
+        for _ in range(int(os.environ.get('GRAM_PROBE_WARM', '25'))):
             run()
         torch.cuda.synchronize()
         P.profile_enable(True)
-        for _ in range(5):
+        for _ in range(10):
             run()
         torch.cuda.synchronize()
         rep = P.profile_report()
