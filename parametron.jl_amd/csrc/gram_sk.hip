@@ -528,11 +528,30 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     // blockIdx.y selects 4 of the NACC accumulators of every thread, so a tile split many ways is summed by NACC/4 workgroups
     const int r0 = (int)blockIdx.y * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int b = blo; b <= bhi; ++b) {
+    auto slot_ptr = [&](int b) {
         const int64_t bu0 = sk_unit_begin(g, b);
         const int first_rtile = (int)(bu0 / g.nchunk);
         const int slot = 2 * b + (first_rtile == rtile ? 0 : 1);
-        const double *w = g.ws + (int64_t)slot * SLOT + (int64_t)r0 * C::NT + tid;
+        return g.ws + (int64_t)slot * SLOT + (int64_t)r0 * C::NT + tid;
+    };
+    // partials are ADDED in ascending workgroup order (deterministic) but LOADED four workgroups at a time, so the kernel is not a
+    // chain of dependent L2 round trips
+    int b = blo;
+    for (; b + 3 <= bhi; b += 4) {
+        double v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double *w = slot_ptr(b + q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[q][r] = w[r * C::NT];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = acc[r] + v[q][r];
+    }
+    for (; b <= bhi; ++b) {
+        const double *w = slot_ptr(b);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
