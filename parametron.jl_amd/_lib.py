@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libparametron_hip.so")
+LIB_PATH = os.environ.get("PMT_LIB_PATH") or os.path.join(HERE, "lib", "libparametron_hip.so")   # override: A/B builds of the library
 
 # Julia isbits layouts as numpy structured dtypes
 LT = np.dtype([("coeff", "<f8"), ("var", "<i8")])

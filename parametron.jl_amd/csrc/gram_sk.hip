@@ -24,6 +24,22 @@
 // acc[tm][tn][s] of lane l = C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
 #include "common.h"
 
+// Codegen knobs (tools/tune_gram.sh).  The compiler's schedule of the stage loop — how many of a stage's 128 MFMAs it sinks below the
+// barrier, where it puts the operand reads — moves by +-5 % with source changes that do not touch the loop (even wrapping phase B
+// in a lambda), so the knob combination AND this exact source shape are the ones that measured best:
+//   PMT_SK_ORDER 1   MFMA issue order (tn, r, tm): consecutive MFMAs share the B operand   (0: (tn, tm, r))
+//   PMT_SK_LOADKS 1  the next stage's global loads are issued after the first k-step
+// gram_sk_kernel at n = r = 4096: 1.177 ms (58.4 TFLOP/s); the sweep is in profiles/r01d_side_stream.txt.
+#ifndef PMT_GRAM_SK_STAGGER
+#define PMT_GRAM_SK_STAGGER 0
+#endif
+#ifndef PMT_SK_LOADKS
+#define PMT_SK_LOADKS 1
+#endif
+#ifndef PMT_SK_ORDER
+#define PMT_SK_ORDER 1
+#endif
+
 namespace pmt {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -314,7 +330,7 @@ __device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, 
             // stage: right after the barrier both waves of a SIMD would otherwise spend ~450 cycles issuing loads with the
             // matrix pipe idle (in-kernel s_memtime stamps, profiles/r01c_gram_phases.txt).
             // (FAST: unconditional — the last stage re-loads itself — so the stage body stays one basic block)
-            if (ks == (BK / 4 > 1 ? 1 : 0) && ABL != 2 && (FAST || s + 1 < nstage)) {
+            if (ks == (BK / 4 > PMT_SK_LOADKS ? PMT_SK_LOADKS : 0) && ABL != 2 && (FAST || s + 1 < nstage)) {
                 const int64_t inext = stage_row(FAST ? min(s + 1, nstage - 1) : s + 1);
                 sk_load_panel<TN, BK, FAST>(g, j0, inext, iend, rj, tid);
                 sk_load_panel<TN, BK, FAST>(g, k0, inext, iend, rk, tid);
@@ -338,11 +354,19 @@ __device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, 
                         b[r] = (ABL == 1) ? (double)(rc + r) : pk[(tn * 16 + rc) * GP + ks * 4];
                     }
                 }
+#if PMT_SK_ORDER == 0
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
+#else
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+                        acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
+#endif
             }
         }
         if (ABL != 2 && (FAST || s + 1 < nstage)) {
@@ -469,6 +493,42 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
 
+    // Optional (PMT_GRAM_SK_STAGGER): half of the XCDs (workgroup b runs on XCD b % 8) do their stream-K share FIRST and their
+    // whole tiles afterwards, so the two halves of the chip reach their tile epilogues ~1/16 of a tile apart and the 200 MB of output
+    // are not written in two chip-wide bursts.  Measured: no gain (profiles/r01d_side_stream.txt); off.
+    const bool b_first = PMT_GRAM_SK_STAGGER && (bid & 4);
+    auto phase_b = [&]() __attribute__((always_inline)) {
+        // phase B: the remaining tiles (fewer than G) are split along the contraction: stream-K over their (tile, chunk) units
+        const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
+        for (int64_t u = u0; u < u1;) {
+            const int rtile = (int)(u / g.nchunk);                       // index among the remainder tiles
+            const int tile = g.tfull * g.G + rtile;
+            const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
+            const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
+            int jb, kb;
+            sk_seq_unrank(tile, g.ntiles, jb, kb);
+            const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
+            const bool diag = (jb == kb);
+            const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
+
+            double acc[C::NACC];
+            sk_accumulate<TN, BK, ABL>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
+
+            if (c0 == 0 && c1 == g.nchunk) {
+                static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
+                sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+            } else {
+                // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
+                const int slot = 2 * bid + (u == u0 ? 0 : 1);
+                double *w = g.ws + (int64_t)slot * SLOT + tid;
+    #pragma unroll
+                for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+            }
+            u += (c1 - c0);
+        }
+    };
+    if (b_first) phase_b();
+
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
@@ -478,34 +538,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
         sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
     }
 
-    // phase B: the remaining tiles (fewer than G) are split along the contraction: stream-K over their (tile, chunk) units
-    const int64_t u0 = sk_unit_begin(g, bid), u1 = sk_unit_begin(g, bid + 1);
-    for (int64_t u = u0; u < u1;) {
-        const int rtile = (int)(u / g.nchunk);                       // index among the remainder tiles
-        const int tile = g.tfull * g.G + rtile;
-        const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
-        const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
-        int jb, kb;
-        sk_seq_unrank(tile, g.ntiles, jb, kb);
-        const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
-        const bool diag = (jb == kb);
-        const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
-
-        double acc[C::NACC];
-        sk_accumulate<TN, BK, ABL>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
-
-        if (c0 == 0 && c1 == g.nchunk) {
-            static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
-            sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
-        } else {
-            // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
-            const int slot = 2 * bid + (u == u0 ? 0 : 1);
-            double *w = g.ws + (int64_t)slot * SLOT + tid;
-#pragma unroll
-            for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
-        }
-        u += (c1 - c0);
-    }
+    if (!b_first) phase_b();
 }
 
 // one workgroup per tile: if the tile was split, add its partials in ascending workgroup order and write the terms
