@@ -39,6 +39,9 @@
 #ifndef PMT_SK_ORDER
 #define PMT_SK_ORDER 1
 #endif
+#ifndef PMT_SK_WPS
+#define PMT_SK_WPS 2          // __launch_bounds__ waves-per-SIMD hint of the shipped instantiation
+#endif
 
 namespace pmt {
 
@@ -638,7 +641,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
     } while (0)
     if (variant == 0) SK_LAUNCH(4, 16, 2);
-    else if (variant == 1) SK_LAUNCH(2, 16, 2);
+    else if (variant == 1) SK_LAUNCH(2, 16, PMT_SK_WPS);
     else SK_LAUNCH(2, 32, 2);
 #undef SK_LAUNCH
     int rc = check_launch("gram_sk_kernel");
