@@ -468,8 +468,26 @@ __global__ void batch_const_kernel(const double *__restrict__ b, int64_t strideb
     out[inst * out_stride] = acc;
 }
 
+int launch_batch_const(const double *b, int64_t strideb, int64_t rows, int sign, int64_t B, double *out_const, int64_t out_stride, hipStream_t s) {
+    PMT_LAUNCH(batch_const_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, s, b, strideb, rows, sign, B, out_const, out_stride);
+    return check_launch("batch_const_kernel");
+}
+
+bool batch_small_enabled();
+int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
+                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride,
+                       const double *Cm, int64_t m, const double *d, int sign_d, double *out_C, double *out_d, hipStream_t s);
+int launch_batch_const(const double *b, int64_t strideb, int64_t rows, int sign, int64_t B, double *out_const, int64_t out_stride, hipStream_t s);
+
 int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride, hipStream_t s) {
+    // instances of at most 128 columns: one workgroup per instance, everything from one pass over A (batch_small.hip)
+    if (cols <= 128 && batch_small_enabled()) {
+        int rc = launch_batch_small(A, lda, rows, cols, strideA, b, strideb, sign, B, out_q, out_lin, out_const, out_stride,
+                                    nullptr, 0, nullptr, 0, nullptr, nullptr, s);
+        if (rc) return rc;
+        return launch_batch_const(b, strideb, rows, sign, B, out_const, out_stride, s);
+    }
     BatchGramArgs bg;
     bg.A = A; bg.lda = lda; bg.rows = rows; bg.cols = cols; bg.strideA = strideA; bg.out = out_q; bg.out_stride = out_stride;
     bg.ntiles = (int)cdiv(cols, ST);
