@@ -151,6 +151,17 @@ class Model:
             self._ctx = DeviceContext(self._device_index)            # raises loudly without a GPU / built library
         return self._ctx
 
+    def parameter_array(self, *shape):
+        """Page-locked, column-major float64 array for the value of a host-updated Parameter (`Parameter(f, val, model)`,
+        `Parameter(model, val=val)`, src/parameter.jl:57,88).  Uploads from it are asynchronous and run at PCIe speed; an ordinary
+        numpy array works too, but a pageable source is staged by the driver and a row-major matrix is first converted to Julia's
+        column-major order on the host.  The memory lives until close()."""
+        shape = tuple(int(s) for s in (shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape))
+        n = int(np.prod(shape)) if shape else 1
+        flat = self.device().pinned_array(n, np.float64)
+        flat[:] = 0.0
+        return flat.reshape(shape, order="F")
+
     def close(self):
         if self._ctx is not None:
             self._ctx.close()

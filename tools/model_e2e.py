@@ -13,10 +13,21 @@ def main():
     device = "--device-handoff" in sys.argv
     model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", use_graph="--graph" in sys.argv, handoff="device" if device else "moi")
     x = [P.Variable(model) for _ in range(n)]
-    A = P.DeviceUniformParameter((r, n), 1, model)
-    b = P.DeviceUniformParameter((r,), 2, model)
-    Cm = P.DeviceUniformParameter((m, n), 3, model)
-    d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    if "--host-params" in sys.argv:
+        # host-updated Parameters in the reference's `val=` form (buffers overwritten externally between solves, src/parameter.jl:88):
+        # every solve! uploads A, b, C, d (151 MB).  --pinned: page-locked column-major buffers from model.parameter_array
+        import numpy as np
+        alloc = model.parameter_array if "--pinned" in sys.argv else (lambda *s: np.zeros(s, order="C" if "--row-major" in sys.argv else "F"))
+        rng = np.random.default_rng(0)
+        bufs = [alloc(r, n), alloc(r), alloc(m, n), alloc(m)]
+        for a in bufs:
+            a[...] = rng.random(a.shape)
+        A, b, Cm, d = (P.Parameter(model, val=a) for a in bufs)
+    else:
+        A = P.DeviceUniformParameter((r, n), 1, model)
+        b = P.DeviceUniformParameter((r,), 2, model)
+        Cm = P.DeviceUniformParameter((m, n), 3, model)
+        d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
     residual = A * x - b
     P.objective(model, P.Minimize, P.dot(residual, residual))
     P.constraint(model, Cm * x == d)
@@ -32,8 +43,8 @@ def main():
         qp = model.device_qp
         t0 = time.perf_counter(); got = qp.fetch(); t_fetch = time.perf_counter() - t0
         nb = 8 * (qp.P.nnz + qp.A.nnz + qp.nvars + 2 * qp.nrows)
-        print("device hand-off: first solve! (initialize + CSC structure) %.1f ms; steady solve! (tape + CSC values, nothing crosses PCIe) %.3f ms = %.1f /s;"
-              " P nnz %d, A nnz %d; fetching the CSC values (pageable) %.1f MB in %.1f ms" % (t_first * 1e3, dt * 1e3, 1 / dt, qp.P.nnz, qp.A.nnz, nb / 1e6, t_fetch * 1e3))
+        print("device hand-off: first solve! (initialize + CSC structure) %.1f ms; steady solve! (tape + CSC values; %s) %.3f ms = %.1f /s;"
+              " P nnz %d, A nnz %d; fetching the CSC values (pageable) %.1f MB in %.1f ms" % (t_first * 1e3, "151 MB of Parameter values uploaded per solve" if "--host-params" in sys.argv else "nothing crosses PCIe", dt * 1e3, 1 / dt, qp.P.nnz, qp.A.nnz, nb / 1e6, t_fetch * 1e3))
         return
     f = model.objective.f
     nbytes = f.quadratic_terms.nbytes + f.affine_terms.nbytes + list(model.constraints)[0].f.terms.nbytes
