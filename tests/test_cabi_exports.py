@@ -61,3 +61,19 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(src), "product source %s references the oracle" % os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_layouts_hold_for_a_c_compiler(tmp_path):
+    """include/parametron_hip.h must be consumable by a C compiler (the boundary a cgo / ccall / ctypes host binds): compile a
+    translation unit that includes it as C11 and checks the struct layouts the Julia side relies on."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stddef.h>\n#include "parametron_hip.h"\n'
+                   '_Static_assert(sizeof(pmt_linear_term) == 16 && offsetof(pmt_linear_term, var) == 8, "LinearTerm");\n'
+                   '_Static_assert(sizeof(pmt_quadratic_term) == 24 && offsetof(pmt_quadratic_term, col) == 16, "QuadraticTerm");\n'
+                   '_Static_assert(sizeof(pmt_vector_affine_term) == 24 && offsetof(pmt_vector_affine_term, coeff) == 8, "VectorAffineTerm");\n'
+                   'int (*probe)(const double *, int64_t, int64_t, int64_t, const int64_t *, const double *, int, pmt_linear_term *, double *, void *)'
+                   ' = pmt_affine_assemble_f64;\nint main(void) { return PMT_OK; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -59,3 +59,34 @@ def test_model_with_512_row_matrices_uses_padded_copies_and_matches_oracle():
         assert np.array_equal(cf.terms.view(np.int64), ct.view(np.int64)) and np.array_equal(cf.constants, cc)
     assert [([(t.coeff, t.var.index) for t in fn.linear], fn.constant) for fn in res()] == \
         O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(A(), xi), b()).as_tuples()
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 5), (64, 33), (512, 9)])
+def test_row_major_column_major_and_page_locked_parameter_values_upload_identically(rows, cols):
+    """A Parameter matrix may live in a row-major numpy array (transposed on the device), a column-major one (copied as is) or in
+    page-locked memory from Model.parameter_array: the device copy and every MOI buffer are the same bits."""
+    rng = np.random.default_rng(rows)
+    ref = rng.random((rows, cols)) - 0.5
+    results = []
+    for kind in ("row-major", "column-major", "pinned"):
+        model = P.Model(P.MockOptimizer())
+        x = [Variable(model) for _ in range(cols)]
+        if kind == "pinned":
+            val = model.parameter_array(rows, cols)
+            assert val.flags.f_contiguous and val.shape == (rows, cols) and not val.any()
+        else:
+            val = np.zeros((rows, cols), order="C" if kind == "row-major" else "F")
+        val[...] = ref
+        A = P.Parameter(model, val=val)                                    # the reference's manual `val=` form (src/parameter.jl:88)
+        d = P.Parameter(model, val=np.arange(rows, dtype=np.float64))
+        P.constraint(model, A * x == d)
+        P.solve(model)
+        assert np.array_equal(A._dev.fetch(model.device()), ref)
+        val[...] = 2 * ref                                                 # overwrite the buffer between solves, as README Example 2 does
+        P.solve(model)
+        f = list(model.constraints)[0].f
+        results.append((f.terms.copy(), f.constants.copy()))
+        assert np.array_equal(f.terms["coeff"].reshape(rows, cols), 2 * ref)
+        model.close()
+    for t, c in results[1:]:
+        assert np.array_equal(t.view(np.int64), results[0][0].view(np.int64)) and np.array_equal(c, results[0][1])
