@@ -23,7 +23,7 @@ def _is_sparse(v):
     return hasattr(v, "indptr") and hasattr(v, "indices") and hasattr(v, "data") and getattr(v, "format", None) == "csc"
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
 from .hostops import Transpose, _RowTimesMatrix, elem_kind, is_vector
-from .parameter import Parameter
+from .parameter import DerivedParameter, Parameter
 
 
 class Relation:
@@ -770,6 +770,10 @@ def lazy(f, *args):
     model = _model_of(args)
     if model is None:
         raise ArgumentError("expression contains no Parameter with a model")
+    if f == "getproperty":                                                       # rule :300-302 (GetField): p.x as plain derived data
+        obj, name = args
+        return DerivedParameter(lambda: getattr(obj() if isinstance(obj, Parameter) else fetch_value(obj.model.device(), obj.out), name),
+                                [obj], model)
     kinds = [_arg_kind(a) for a in args]
     if f in ("+", "-") and len(args) > 2 and f == "+":                           # rule :234-236
         return lazy("+", lazy("+", args[0], args[1]), *args[2:])
@@ -783,7 +787,7 @@ def lazy(f, *args):
             vals = [a() if isinstance(a, Parameter) else (fetch_value(a.model.device(), a.out) if isinstance(a, DeviceNode) else a)
                     for a in host_args]
             return hostops.apply(f, *vals)
-        return Parameter(recompute, model)
+        return DerivedParameter(recompute, args, model)
     ctx = model.device()
     if f == "*":
         if len(args) == 3 and kinds[0] == "tvarvec":
@@ -869,6 +873,11 @@ def expression(thunk):
     """@expression <code>: in Python the operators of Parameter / LazyExpression already build the lazy DAG, so the
     'macro' simply evaluates the thunk (or returns its argument)."""
     return thunk() if callable(thunk) and not _is_lazy(thunk) else thunk
+
+
+def getproperty(x, name):
+    """@expression p.name (src/lazyexpression.jl:144, 300-302)"""
+    return lazy("getproperty", x, name)
 
 
 def wrap(expr):

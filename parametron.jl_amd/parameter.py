@@ -91,6 +91,30 @@ class Parameter:
         return Relation(self, ">=", o)
 
 
+class DerivedParameter(Parameter):
+    """Plain data computed from other Parameters by a Parameter-only expression (`p ⋅ p`, `p.x`, `p.x + 1`; test/model.jl:161,
+    test/lazyexpression.jl:364-381).  In the reference such an expression is a LazyExpression that re-evaluates its arguments on every
+    call; here the value is cached like any Parameter's but also recomputed whenever a source is dirty or was updated since."""
+
+    def __init__(self, f, sources, model):
+        super().__init__(f, model)
+        self.sources = [s for s in sources if isinstance(s, Parameter)]
+        self._seen = None
+
+    def __call__(self):
+        for s in self.sources:
+            if isinstance(s, DerivedParameter):
+                s()                                      # refresh the chain first: its version tells whether anything below changed
+        stale = self.dirty or any(s.dirty for s in self.sources)
+        if not stale:
+            stale = self._seen != tuple(s.version for s in self.sources)
+        if stale:
+            self.update()
+            self.dirty = False
+            self._seen = tuple(s.version for s in self.sources)
+        return self.val
+
+
 class DeviceUniformParameter(Parameter):
     """A Parameter whose value is regenerated ON THE DEVICE at every update: val[i] = scale * U[0,1)(seed + 1000*epoch, i),
     the counter-based stream of SURVEY.md §8(d) — the device-resident analogue of `Parameter(rand!, zeros(n, n), model)`

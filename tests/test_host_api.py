@@ -203,3 +203,25 @@ def test_device_expressions_fail_loudly_without_gpu():
     A = P.Parameter(model, val=np.eye(2))
     with pytest.raises(P.ErrorException):
         A * x                                                                    # needs HBM: no CPU fallback
+
+
+def test_getfield_optimization_and_derived_parameters_track_their_sources():
+    """test/lazyexpression.jl:364-381: `@expression p.x` and `@expression p.x + 1` follow the Parameter through setdirty!(p) alone
+    (the reference re-evaluates its arguments on every call; a derived Parameter recomputes when a source is dirty or was updated)."""
+    import random
+
+    class MyWrapper:
+        def __init__(self, x):
+            self.x = x
+    model = P.mock_model()
+    p = P.Parameter(lambda: MyWrapper(random.random()), model)
+    ex1 = P.getproperty(p, "x")
+    assert ex1() == p().x
+    P.setdirty(p)
+    assert ex1() == p().x
+    ex2 = ex1 + 1
+    assert ex2() == p().x + 1
+    P.setdirty(p)
+    assert ex2() == p().x + 1 and ex1() == p().x
+    before = p().x
+    assert ex1() == before and ex2() == before + 1                         # nothing dirty: cached, the callback does not run again
