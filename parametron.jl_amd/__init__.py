@@ -9,7 +9,7 @@ from ._lib import ArgumentError, DimensionMismatch, ErrorException  # noqa: F401
 from .functions import (AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, canonicalize,  # noqa: F401
                         prune_zero)
 from .parameter import DerivedParameter, DeviceUniformParameter, Parameter  # noqa: F401
-from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, getproperty, lazy, transpose, vcat,  # noqa: F401
+from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, getindex, getproperty, lazy, transpose, vcat,  # noqa: F401
                              vect, wrap)
 from .hostops import Transpose  # noqa: F401
 from . import moi  # noqa: F401

@@ -766,10 +766,19 @@ def _arg_kind(a):
 def lazy(f, *args):
     """optimize_toplevel(LazyExpression(f, args...)) — src/lazyexpression.jl:184-193."""
     if not any(_is_lazy(a) or isinstance(a, _LazyRowTimesMatrix) or (isinstance(a, Transpose) and _is_lazy(a.parent)) for a in args):
-        return hostops.apply(f, *args)                                           # :189-192
+        return f(*args) if callable(f) else hostops.apply(f, *args)             # :189-192
     model = _model_of(args)
     if model is None:
         raise ArgumentError("expression contains no Parameter with a model")
+    if callable(f):
+        # any other function of Parameters (user functions, hcat, getindex, reshape, ...: test/lazyexpression.jl:63-82, 384-404):
+        # the generic rule :198 keeps the call as it is — host data preparation, re-evaluated when a source changed
+        fn, fargs = f, args
+
+        def call():
+            return fn(*[a() if isinstance(a, Parameter) else (fetch_value(a.model.device(), a.out) if isinstance(a, DeviceNode) else a)
+                        for a in fargs])
+        return DerivedParameter(call, args, model)
     if f == "getproperty":                                                       # rule :300-302 (GetField): p.x as plain derived data
         obj, name = args
         return DerivedParameter(lambda: getattr(obj() if isinstance(obj, Parameter) else fetch_value(obj.model.device(), obj.out), name),
@@ -873,6 +882,11 @@ def expression(thunk):
     """@expression <code>: in Python the operators of Parameter / LazyExpression already build the lazy DAG, so the
     'macro' simply evaluates the thunk (or returns its argument)."""
     return thunk() if callable(thunk) and not _is_lazy(thunk) else thunk
+
+
+def getindex(x, *idx):
+    """@expression p[i, j] / p[:, j]"""
+    return lazy(lambda v: v[idx if len(idx) > 1 else idx[0]], x)
 
 
 def getproperty(x, name):

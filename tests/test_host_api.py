@@ -225,3 +225,38 @@ def test_getfield_optimization_and_derived_parameters_track_their_sources():
     assert ex2() == p().x + 1 and ex1() == p().x
     before = p().x
     assert ex1() == before and ex2() == before + 1                         # nothing dirty: cached, the callback does not run again
+
+
+def test_generic_functions_of_parameters_user_functions_hcat_getindex_reshape():
+    """test/lazyexpression.jl:63-82 (user functions), :384-393 (hcat), :395-404 (getindex), :416-419 (tuple arguments)."""
+    import numpy as np
+    model = P.mock_model()
+    rng = np.random.default_rng(0)
+    p = P.Parameter(lambda: rng.random((3, 3)), model)
+    hcat_expr = P.lazy(lambda a, b: np.hstack([a, b]), p, p)
+    assert np.array_equal(hcat_expr(), np.hstack([p(), p()]))
+    P.setdirty(p)
+    assert np.array_equal(hcat_expr(), np.hstack([p(), p()]))
+    col = P.getindex(p, slice(None), 1)
+    assert np.array_equal(col(), p()[:, 1])
+    P.setdirty(p)
+    assert np.array_equal(col(), p()[:, 1])
+
+    class SpatialMat:
+        def __init__(self):
+            self.angular, self.linear = np.zeros((3, 4)), np.zeros((3, 4))
+    scalar = [1.0]
+    mat = SpatialMat()
+
+    def updatemat(m):
+        m.angular[...] = scalar[0]
+        m.linear[...] = scalar[0]
+    pmat = P.Parameter(updatemat, mat, model)
+    pmat_angular = P.lazy(lambda m: m.angular, pmat)
+    result = pmat_angular()
+    assert result is mat.angular and np.all(result == scalar[0])            # aliasing, not a copy (=== in the reference)
+    scalar[0] = 2.0
+    P.setdirty(model)
+    assert np.all(pmat_angular() == 2.0)
+    A = [1, 2, 3, 4]
+    assert np.array_equal(P.lazy(np.reshape, A, (2, 2)), np.reshape(A, (2, 2)))   # no Parameter involved: evaluated on the spot
