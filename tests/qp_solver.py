@@ -26,13 +26,27 @@ class DenseQPOptimizer(P.AbstractOptimizer):
         if self.permute_seed is not None:
             idx = np.random.default_rng(self.permute_seed).permutation(self.n).astype(np.int64) + 1
         self.varidx = idx + self.offset                     # optimizer index of Variable k
-        self.objective = backend.objective.f
+        # MOI.copy_to translates the indices of the functions it copies (src/model.jl:118); functions set later through
+        # set_*_function already carry optimizer indices (update! applies model_var_to_optimizer)
+        self.objective = self._translated(backend.objective.f)
         self.cons, self.sets = {}, {}
         cmap = {}
         for i, c in enumerate(backend.constraints):
             cmap[c] = i
-            self.cons[i], self.sets[i] = c.f, c.set
+            self.cons[i], self.sets[i] = self._translated(c.f), c.set
         return {"variables": self.varidx, "constraints": cmap}
+
+    def _translated(self, f):
+        import copy
+        g = copy.copy(f)
+        for attr, fields in (("terms", ["var"]), ("affine_terms", ["var"]), ("quadratic_terms", ["row", "col"])):
+            arr = getattr(f, attr, None)
+            if arr is not None and len(arr):
+                arr = arr.copy()
+                for fld in fields:
+                    arr[fld] = self.varidx[arr[fld] - 1]
+                setattr(g, attr, arr)
+        return g
 
     def set_objective_function(self, f):
         self.objective = f
