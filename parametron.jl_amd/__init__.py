@@ -18,7 +18,6 @@ from .model import (AbstractOptimizer, Maximize, Minimize, MockOptimizer, Model,
                     terminationstatus, update, value)
 from .handoff import DeviceQP  # noqa: F401
 
-findallocs = None  # the reference's per-node allocation report (src/debug.jl) has a device analogue: profile_report()
 
 
 def profile_enable(on=True):
@@ -38,3 +37,29 @@ def profile_report():
         name, cnt, tot, mn, mx = line.split("\t")
         out[name] = {"launches": int(cnt), "avg_ms": float(tot) / max(1, int(cnt)), "min_ms": float(mn), "max_ms": float(mx)}
     return out
+
+
+def findallocs(io, expr):
+    """findallocs(io, expr) (src/debug.jl:4-23): re-evaluate `expr` and report what it costs.  The reference prints the heap bytes each
+    node of the expression tree allocates (they must be 0); on the device the analogue of an allocation is growth of the plan's
+    memory (must be 0 after the first evaluation) and the cost of a node is the time of the kernels it launches."""
+    from .lazyexpression import DeviceNode, evaluate, schedule
+    if not isinstance(expr, DeviceNode):
+        value = expr() if callable(expr) else expr
+        io.write("%s: host value (%s), no device work\n" % (type(expr).__name__, type(value).__name__))
+        return
+    ctx = expr.model.device()
+    evaluate(ctx, [expr]); ctx.synchronize()                              # first evaluation may size buffers
+    before = ctx.bytes_allocated()
+    profile_enable(True)
+    try:
+        expr.model.setdirty()
+        evaluate(ctx, [expr]); ctx.synchronize()
+        report = profile_report()
+    finally:
+        profile_enable(False)
+    nodes = [x for x in schedule([expr]) if isinstance(x, DeviceNode)]
+    io.write("%d device node(s): %s\n" % (len(nodes), ", ".join(x.builder for x in nodes)))
+    for name, r in report.items():
+        io.write("  %-40s %d launch(es)  %.4f ms\n" % (name, r["launches"], r["avg_ms"] * r["launches"]))
+    io.write("plan memory growth during re-evaluation: %d bytes\n" % (ctx.bytes_allocated() - before))

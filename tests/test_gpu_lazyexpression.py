@@ -150,3 +150,19 @@ def test_bad_syntax_raises_argument_error():                   # test/lazyexpres
         P.lazy("hcat", p, x)
     with pytest.raises(P.DimensionMismatch):
         p * V(1, 2, 3)
+
+
+def test_findallocs_reports_kernels_and_no_plan_growth():         # test/debug.jl:8-14
+    import io
+    model = P.mock_model()
+    x = Variable(model)
+    p = P.Parameter(lambda: 3, model)
+    expr = p * 4 + x
+    model.setdirty()
+    out = io.StringIO()
+    P.findallocs(out, expr)
+    text = out.getvalue()
+    assert "device node" in text and "plan memory growth during re-evaluation: 0 bytes" in text
+    out2 = io.StringIO()
+    P.findallocs(out2, p)
+    assert "no device work" in out2.getvalue()
