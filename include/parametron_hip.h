@@ -262,6 +262,16 @@ int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *perm, const i
 /* native form of the same node (Vector{AffineFunction} with ragged rows): out[t] = (nzval[perm[t]], term_var[t]) */
 int pmt_sparse_assemble_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, int64_t nnz,
                             pmt_linear_term *out_terms, void *stream);
+/* XCD-aware form of the two entry points above (same outputs, bit for bit): columns are cut into `nslab` slabs, workgroup b works on
+ * slab b % nslab, so with nslab = 8 (the XCD count) each XCD's L2 only sees one eighth of nzval.  slab_ptr[row*(nslab+1) + s] = index of
+ * the first term of `row` whose column is in slab s (host helper, once per pattern; term_col from pmt_sparse_rowmajor_order). */
+int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const int64_t *host_row_ptr, const int64_t *host_term_col,
+                        int64_t *host_slab_ptr);
+int pmt_sparse_pack_vector_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
+                                     int64_t rows, int nslab, const int64_t *varmap, int64_t row_offset,
+                                     pmt_vector_affine_term *out_terms, void *stream);
+int pmt_sparse_assemble_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
+                                  int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream);
 /* constants: out[i] = 0.0 (+|-) d[i] */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 

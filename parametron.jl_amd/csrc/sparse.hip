@@ -37,6 +37,68 @@ __global__ void sparse_assemble_kernel(const double *__restrict__ nzval, const i
     }
 }
 
+// ---- XCD-aware form of the same scatter --------------------------------------------------------------------------------------
+// The gather nzval[perm[t]] of the kernels above walks the CSC value array at random (row-major order of CSC storage): every 8-byte
+// read pulls a whole cache line through the fabric (~8x amplification; 2.5 TB/s algorithmic at config 5).  Here the columns are cut
+// into `nslab` slabs and workgroup b works on slab b % nslab: workgroups are dispatched round-robin over the 8 XCDs, so with
+// nslab = 8 each XCD only ever touches one eighth of nzval (3.4 MB at config 5 — inside its 4 MB L2) and every line it pulls is
+// eventually used in full.  Within a row the terms of a slab are contiguous in the row-major output, so a wave owns a (row, slab)
+// segment: it stages 64 coefficients and variable indices in LDS and writes the 24-byte terms as 16-byte chunks.
+// slab_ptr[row * (nslab + 1) + s] = index of the first term of `row` whose column lies in slab s (host, once: pmt_sparse_slab_ptr).
+constexpr int SP_ROWS_PER_WAVE = 4;
+
+template <bool VAT_OUT>
+__global__ __launch_bounds__(256) void sparse_slab_kernel(const double *__restrict__ nzval, const int64_t *__restrict__ perm,
+                                                          const int64_t *__restrict__ term_var, const int64_t *__restrict__ slab_ptr,
+                                                          int64_t rows, int nslab, const int64_t *__restrict__ varmap, int64_t row_offset,
+                                                          unsigned long long *__restrict__ out) {
+    typedef unsigned long long u64;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    constexpr int W = VAT_OUT ? 3 : 2;                           // 8-byte words per term
+    __shared__ u64 s_coeff[4][64];
+    __shared__ u64 s_var[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slab = blockIdx.x % nslab;
+    const int64_t rowbase = ((int64_t)(blockIdx.x / nslab) * 4 + wave) * SP_ROWS_PER_WAVE;
+    for (int i = 0; i < SP_ROWS_PER_WAVE; ++i) {
+        const int64_t row = rowbase + i;
+        if (row >= rows) break;
+        const int64_t t0 = slab_ptr[row * (nslab + 1) + slab], t1 = slab_ptr[row * (nslab + 1) + slab + 1];
+        const u64 rowword = (u64)(row_offset + row + 1);
+        for (int64_t ts = t0; ts < t1; ts += 64) {
+            const int cnt = (int)min((int64_t)64, t1 - ts);
+            if (lane < cnt) {
+                const int64_t t = ts + lane;
+                s_coeff[wave][lane] = (u64)__double_as_longlong(nzval[perm[t]]);
+                const int64_t v = term_var[t];
+                s_var[wave][lane] = (u64)(VAT_OUT ? map_var(varmap, v) : v);
+            }
+            __builtin_amdgcn_wave_barrier();                      // one wave: LDS writes above are visible to its own reads below
+            u64 *seg = out + ts * W;
+            const int nwords = cnt * W;
+            auto word = [&](int q) -> u64 {
+                const int t = q / W, f = q - W * t;
+                if (VAT_OUT) return f == 0 ? rowword : (f == 1 ? s_coeff[wave][t] : s_var[wave][t]);
+                return f == 0 ? s_coeff[wave][t] : s_var[wave][t];
+            };
+            const int lead = (int)((reinterpret_cast<uintptr_t>(seg) >> 3) & 1);
+            if (lead && lane == 0) seg[0] = word(0);
+            for (int c = lane; lead + 2 * c < nwords; c += 64) {
+                const int q0 = lead + 2 * c;
+                if (q0 + 1 < nwords) {
+                    u64x2 v;
+                    v.x = word(q0);
+                    v.y = word(q0 + 1);
+                    *reinterpret_cast<u64x2 *>(seg + q0) = v;
+                } else {
+                    seg[q0] = word(q0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 }  // namespace pmt
 
 using namespace pmt;
@@ -92,4 +154,45 @@ extern "C" int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *pe
         PMT_LAUNCH(sparse_pack_vector_kernel, dim3(blocks), dim3(256), 0, s, nzval, perm, term_row, term_var, nnz, varmap, row_offset, out_terms);
         return check_launch("sparse_pack_vector_kernel");
     });
+}
+
+extern "C" int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const int64_t *row_ptr, const int64_t *term_col, int64_t *slab_ptr) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0 && nslab >= 1, PMT_DIMENSION_MISMATCH, "sparse_slab_ptr: bad dimensions");
+    PMT_REQUIRE(row_ptr && slab_ptr, PMT_INVALID_ARGUMENT, "sparse_slab_ptr: null pointer");
+    for (int64_t r = 0; r < rows; ++r) {
+        int64_t t = row_ptr[r];
+        const int64_t tend = row_ptr[r + 1];
+        for (int s = 0; s <= nslab; ++s) {
+            const int64_t first_col = (int64_t)s * cols / nslab + 1;            // 1-based first column of slab s (slab nslab: past the end)
+            while (t < tend && term_col[t] < first_col) ++t;
+            slab_ptr[r * (nslab + 1) + s] = (s == nslab) ? tend : t;
+        }
+    }
+    return PMT_OK;
+}
+
+static int launch_sparse_slab(bool vat, const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr, int64_t rows,
+                              int nslab, const int64_t *varmap, int64_t row_offset, void *out, void *stream) {
+    PMT_REQUIRE(rows >= 0 && nslab >= 1 && nslab <= 64, PMT_DIMENSION_MISMATCH, "sparse_pack_slabs: bad dimensions");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE(nzval && perm && term_var && slab_ptr && out, PMT_INVALID_ARGUMENT, "sparse_pack_slabs: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        const unsigned blocks = (unsigned)(cdiv(rows, 4 * SP_ROWS_PER_WAVE) * nslab);
+        if (vat) PMT_LAUNCH_NAMED("sparse_slab_kernel<VAT>", sparse_slab_kernel<true>, dim3(blocks), dim3(256), 0, s, nzval, perm, term_var, slab_ptr, rows, nslab,
+                                  varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
+        else PMT_LAUNCH_NAMED("sparse_slab_kernel<LT>", sparse_slab_kernel<false>, dim3(blocks), dim3(256), 0, s, nzval, perm, term_var, slab_ptr, rows, nslab,
+                              varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
+        return check_launch("sparse_slab_kernel");
+    });
+}
+
+extern "C" int pmt_sparse_pack_vector_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
+                                                int64_t rows, int nslab, const int64_t *varmap, int64_t row_offset,
+                                                pmt_vector_affine_term *out_terms, void *stream) {
+    return launch_sparse_slab(true, nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream);
+}
+
+extern "C" int pmt_sparse_assemble_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
+                                             int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream) {
+    return launch_sparse_slab(false, nzval, perm, term_var, slab_ptr, rows, nslab, nullptr, 0, out_terms, stream);
 }

@@ -309,6 +309,13 @@ class DSpMat(DV):
         self.buf = ctx.alloc(8 * max(self.nnz, 1))                                # nzval
         self.perm_buf = ctx.upload_new(self.perm) if self.nnz else ctx.alloc(8)
         self.term_row_buf = ctx.upload_new(self.term_row) if self.nnz else ctx.alloc(8)
+        # XCD-aware scatter: per-row boundaries of 8 column slabs (one per XCD), see sparse.hip
+        self.nslab = 8
+        self.slab_ptr = np.zeros(max(self.rows, 1) * (self.nslab + 1), dtype=np.int64)
+        if self.rows:
+            _lib.call("pmt_sparse_slab_ptr", self.rows, self.cols, self.nslab, self.row_ptr.ctypes.data_as(vp), self.term_col.ctypes.data_as(vp),
+                      self.slab_ptr.ctypes.data_as(vp))
+        self.slab_ptr_buf = ctx.upload_new(self.slab_ptr)
 
     def same_pattern(self, csc):
         return csc.shape == (self.rows, self.cols) and np.array_equal(csc.indptr, self.indptr) and np.array_equal(csc.indices, self.indices)

@@ -233,7 +233,8 @@ class _Record:
             sp = out.spmat
 
             def emit(c):
-                c.call("pmt_sparse_pack_vector_f64", P(sp.buf), P(sp.perm_buf), P(sp.term_row_buf), P(out.term_var_buf), sp.nnz, P(varmap_buf), 0, P(dt))
+                c.call("pmt_sparse_pack_vector_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf), P(sp.slab_ptr_buf), sp.rows, sp.nslab,
+                       P(varmap_buf), 0, P(dt))
                 if out.vec is not None:
                     c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
             return emit

@@ -76,3 +76,43 @@ def test_config5_size_properties():
     assert t["coeff"].sum() == pytest.approx(data.sum(), rel=1e-12)
     csr = Cs.tocsr()
     assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
+
+
+@pytest.mark.parametrize("m,n,density,nslab", [(37, 61, 0.08, 8), (5, 3, 0.9, 8), (200, 1000, 0.3, 8), (64, 500, 0.02, 3), (9, 40, 0.0, 8)])
+def test_xcd_aware_slab_kernels_equal_the_flat_scatter(m, n, density, nslab):
+    """pmt_sparse_pack_vector_slabs_f64 / pmt_sparse_assemble_slabs_f64 (one column slab per XCD, 16-byte chunk writes) write the same
+    bytes as the flat gather kernels — rows with no entry in a slab, slabs wider than the matrix, segments longer than one wave
+    (> 64 terms) and an empty matrix included."""
+    import ctypes as C
+    import gpu_util as g
+    rng = np.random.default_rng(m * n)
+    csc = sp.random(m, n, density=density, format="csc", random_state=rng, data_rvs=lambda k: rng.random(k) - 0.5)
+    nnz = csc.nnz
+    colptr, rowval = csc.indptr.astype(np.int64) + 1, csc.indices.astype(np.int64) + 1
+    perm, trow, tcol = (np.zeros(max(nnz, 1), dtype=np.int64) for _ in range(3))
+    rptr = np.zeros(m + 1, dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    g.call("pmt_sparse_rowmajor_order", m, n, vp(colptr), vp(rowval), vp(perm), vp(trow), vp(tcol), vp(rptr))
+    slab = np.zeros(m * (nslab + 1), dtype=np.int64)
+    g.call("pmt_sparse_slab_ptr", m, n, nslab, vp(rptr), vp(tcol), vp(slab))
+    sl = slab.reshape(m, nslab + 1)
+    assert np.array_equal(sl[:, 0], rptr[:-1]) and np.array_equal(sl[:, -1], rptr[1:]) and np.all(np.diff(sl, axis=1) >= 0)
+    xvar = np.arange(n, 0, -1, dtype=np.int64)                             # any variables
+    tvar = xvar[tcol[:nnz] - 1] if nnz else np.zeros(1, dtype=np.int64)
+    varmap = np.random.default_rng(1).permutation(n).astype(np.int64) + 1
+    d_nz, d_perm, d_row, d_var = g.to_dev(csc.data if nnz else np.zeros(1)), g.to_dev(perm), g.to_dev(trow), g.to_dev(tvar)
+    d_slab, d_vm = g.to_dev(slab), g.to_dev(varmap)
+    flat_v, slab_v = g.empty_terms(max(nnz, 1), g.VAT), g.empty_terms(max(nnz, 1), g.VAT)
+    flat_l, slab_l = g.empty_terms(max(nnz, 1), g.LT), g.empty_terms(max(nnz, 1), g.LT)
+    g.call("pmt_sparse_pack_vector_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_row), g.ptr(d_var), nnz, g.ptr(d_vm), 7, g.ptr(flat_v), g.stream())
+    g.call("pmt_sparse_pack_vector_slabs_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), g.ptr(d_slab), m, nslab, g.ptr(d_vm), 7, g.ptr(slab_v), g.stream())
+    g.call("pmt_sparse_assemble_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), nnz, g.ptr(flat_l), g.stream())
+    g.call("pmt_sparse_assemble_slabs_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), g.ptr(d_slab), m, nslab, g.ptr(slab_l), g.stream())
+    if nnz:
+        g.assert_terms_equal(g.terms_to_host(slab_v, nnz, g.VAT), g.terms_to_host(flat_v, nnz, g.VAT))
+        g.assert_terms_equal(g.terms_to_host(slab_l, nnz, g.LT), g.terms_to_host(flat_l, nnz, g.LT))
+        t = g.terms_to_host(slab_v, nnz, g.VAT)
+        model_var = np.argsort(varmap)[t["var"] - 1] + 1                   # undo varmap; column c carries Variable n - c
+        dense = np.zeros((m, n))
+        dense[t["out"] - 8, n - model_var] = t["coeff"]                     # row_offset 7, 1-based rows
+        assert np.array_equal(dense, csc.toarray())
