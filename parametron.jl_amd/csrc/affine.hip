@@ -153,31 +153,68 @@ __global__ void pack_scalar_affine_kernel(const LT *__restrict__ in, int64_t n, 
     t.var = map_var(varmap, t.var);
     out[i] = t;
 }
-__global__ void pack_scalar_quadratic_kernel(const QT *__restrict__ in, int64_t n, const int64_t *__restrict__ varmap, QT *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    QT t = in[i];
-    QT o;
-    o.coeff = (t.row == t.col) ? 2 * t.coeff : t.coeff;     // moi_interop.jl:58
-    o.row = map_var(varmap, t.row);
-    o.col = map_var(varmap, t.col);
-    out[i] = o;
+// 256 consecutive terms per workgroup: the 24-byte structs come in and go out as 16-byte chunks through LDS (a per-thread struct
+// copy is three strided 8-byte accesses each way); falls back to the per-thread form for unaligned buffers
+__global__ __launch_bounds__(256) void pack_scalar_quadratic_kernel(const QT *__restrict__ in, int64_t n, const int64_t *__restrict__ varmap,
+                                                                    QT *__restrict__ out, int aligned) {
+    typedef unsigned long long u64;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    __shared__ u64 words[256 * 3];
+    const int64_t base = (int64_t)blockIdx.x * 256;
+    const int cnt = (int)min((int64_t)256, n - base);
+    const int tid = threadIdx.x;
+    if (aligned && cnt == 256) {
+        const u64x2 *src = reinterpret_cast<const u64x2 *>(in + base);
+        u64x2 *sw = reinterpret_cast<u64x2 *>(words);
+        sw[tid] = src[tid];
+        if (tid < 128) sw[256 + tid] = src[256 + tid];
+        __syncthreads();
+        const double c = __longlong_as_double((long long)words[3 * tid]);
+        const int64_t r = (int64_t)words[3 * tid + 1], cl = (int64_t)words[3 * tid + 2];
+        const double cm = (r == cl) ? 2 * c : c;                 // moi_interop.jl:58 (each thread rewrites its own three words)
+        words[3 * tid] = (u64)__double_as_longlong(cm);
+        words[3 * tid + 1] = (u64)map_var(varmap, r);
+        words[3 * tid + 2] = (u64)map_var(varmap, cl);
+        __syncthreads();
+        u64x2 *dst = reinterpret_cast<u64x2 *>(out + base);
+        dst[tid] = sw[tid];
+        if (tid < 128) dst[256 + tid] = sw[256 + tid];
+        return;
+    }
+    if (tid < cnt) {
+        QT t = in[base + tid];
+        QT o;
+        o.coeff = (t.row == t.col) ? 2 * t.coeff : t.coeff;     // moi_interop.jl:58
+        o.row = map_var(varmap, t.row);
+        o.col = map_var(varmap, t.col);
+        out[base + tid] = o;
+    }
 }
-// one wave per row (handles ragged rows through row_ptr)
-__global__ void pack_vector_affine_kernel(const LT *__restrict__ in, const int64_t *__restrict__ row_ptr, int64_t rows, int64_t row_len,
-                                          const int64_t *__restrict__ varmap, int64_t row_offset, VAT *__restrict__ out) {
-    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
+// one wave per row (handles ragged rows through row_ptr): 64 terms at a time through LDS, written as 16-byte chunks
+__global__ __launch_bounds__(256) void pack_vector_affine_kernel(const LT *__restrict__ in, const int64_t *__restrict__ row_ptr, int64_t rows,
+                                                                 int64_t row_len, const int64_t *__restrict__ varmap, int64_t row_offset,
+                                                                 VAT *__restrict__ out) {
+    typedef unsigned long long u64;
+    __shared__ u64 s_c[4][64], s_v[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;                                     // (no workgroup barrier below: waves are independent)
     const int64_t beg = row_ptr ? row_ptr[row] : row * row_len;
     const int64_t end = row_ptr ? row_ptr[row + 1] : beg + row_len;
-    for (int64_t k = beg + lane; k < end; k += 64) {
-        LT t = in[k];
-        VAT o;
-        o.output_index = row_offset + row + 1;
-        o.coeff = t.coeff;
-        o.var = map_var(varmap, t.var);
-        out[k] = o;
+    const u64 rowword = (u64)(row_offset + row + 1);
+    for (int64_t ts = beg; ts < end; ts += 64) {
+        const int cnt = (int)min((int64_t)64, end - ts);
+        if (lane < cnt) {
+            const LT t = in[ts + lane];
+            s_c[wave][lane] = (u64)__double_as_longlong(t.coeff);
+            s_v[wave][lane] = (u64)map_var(varmap, t.var);
+        }
+        __builtin_amdgcn_wave_barrier();
+        wave_write_words<3>(reinterpret_cast<u64 *>(out) + ts * 3, cnt, lane, [&](int q) -> u64 {
+            const int t = q / 3, f = q - 3 * t;
+            return f == 0 ? rowword : (f == 1 ? s_c[wave][t] : s_v[wave][t]);
+        });
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -285,7 +322,8 @@ extern "C" int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int
     if (nq == 0) return PMT_OK;
     PMT_REQUIRE(quad && out_quad, PMT_INVALID_ARGUMENT, "pack_scalar_quadratic: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
-        PMT_LAUNCH(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad);
+        const int aligned = (((reinterpret_cast<uintptr_t>(quad) | reinterpret_cast<uintptr_t>(out_quad)) & 15) == 0) ? 1 : 0;
+        PMT_LAUNCH(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad, aligned);
         return check_launch("pack_scalar_quadratic_kernel");
     });
 }

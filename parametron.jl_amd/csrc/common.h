@@ -66,4 +66,27 @@ __device__ __forceinline__ int64_t map_var(const int64_t *__restrict__ varmap, i
     return varmap ? varmap[var - 1] : var;
 }
 
+// One wave writes `nterms` consecutive terms of W 8-byte words each, starting at `seg`, as 16-byte chunks (global_store_dwordx4)
+// instead of W strided 8-byte stores per lane; word(q) returns word q of the segment (term q / W, field q % W).  `seg` is 8-byte
+// aligned only, so a leading / trailing single word is handled.  All lanes of the wave call this together.
+template <int W, typename F>
+__device__ __forceinline__ void wave_write_words(unsigned long long *__restrict__ seg, int nterms, int lane, F word) {
+    typedef unsigned long long u64w;
+    typedef u64w u64w2 __attribute__((ext_vector_type(2)));
+    const int nwords = nterms * W;
+    const int lead = (int)((reinterpret_cast<uintptr_t>(seg) >> 3) & 1);
+    if (lead && lane == 0) seg[0] = word(0);
+    for (int c = lane; lead + 2 * c < nwords; c += 64) {
+        const int q0 = lead + 2 * c;
+        if (q0 + 1 < nwords) {
+            u64w2 v;
+            v.x = word(q0);
+            v.y = word(q0 + 1);
+            *reinterpret_cast<u64w2 *>(seg + q0) = v;
+        } else {
+            seg[q0] = word(q0);
+        }
+    }
+}
+
 }  // namespace pmt

@@ -145,11 +145,13 @@ int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int
     return check_launch("seq_dot_kernel");
 }
 
-// ---- bilinearmul!: one block row per x index
+// ---- bilinearmul!: one block row per x index.  The coefficients of the NEXT row are fetched into registers while the current row's
+// terms are written, and the LDS row buffer is double buffered: one barrier per row and no exposed load latency.
 __global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict__ Q, int64_t ldq, int64_t nxr, int64_t ny,
                                                        const int64_t *__restrict__ xvar, const int64_t *__restrict__ yvar,
                                                        int moi, const int64_t *__restrict__ varmap, u64 *__restrict__ out_quad) {
-    __shared__ double qc[QE_BT];
+    constexpr int NPT = QE_BT / 256;
+    __shared__ double qc[2][QE_BT];
     __shared__ u64 yvm[QE_BT];
     __shared__ int64_t yv[QE_BT];
     const int64_t b0 = (int64_t)blockIdx.x * QE_BT;
@@ -159,24 +161,48 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const double *__restrict_
         yv[k] = v;
         yvm[k] = (u64)(moi ? map_var(varmap, v) : v);
     }
-    for (int64_t r = blockIdx.y; r < nxr; r += gridDim.y) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < bt; k += blockDim.x) {
-            const int64_t lin = r * ny + b0 + k;                 // Q[k]: column-major LINEAR index of the nxr x ny matrix (:853)
-            const int64_t qc_col = lin / nxr, qc_row = lin - qc_col * nxr;
-            qc[k] = Q[qc_col * ldq + qc_row];
+    // Q[k]: column-major LINEAR index lin = r*ny + b0 + k of the nxr x ny matrix (:853).  One 64-bit division per block row
+    // (uniform) instead of a div/mod per element.
+    auto fetch_row = [&](int64_t r, double (&v)[NPT]) {
+        const int64_t lin0 = r * ny + b0;
+        const int64_t col0 = lin0 / nxr, row0 = lin0 - col0 * nxr;
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const int k = threadIdx.x + 256 * u;
+            v[u] = 0.0;
+            if (k < bt) {
+                int64_t qc_row = row0 + k, qc_col = col0;
+                if (nxr >= QE_BT) {
+                    if (qc_row >= nxr) { qc_row -= nxr; ++qc_col; }  // k < QE_BT <= nxr: at most one wrap
+                } else {
+                    qc_col += qc_row / nxr;
+                    qc_row = qc_row % nxr;
+                }
+                v[u] = Q[qc_col * ldq + qc_row];
+            }
         }
-        __syncthreads();
+    };
+    double v[NPT];
+    int64_t r = blockIdx.y;
+    if (r < nxr) fetch_row(r, v);
+    int cur = 0;
+    for (; r < nxr; r += gridDim.y) {
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) qc[cur][threadIdx.x + 256 * u] = v[u];
+        __syncthreads();                                         // row r is in qc[cur]; the other buffer's readers (row r - stride) are done
+        if (r + gridDim.y < nxr) fetch_row(r + gridDim.y, v);     // in flight while this row is written
         const int64_t xv = xvar[r];
         const u64 xvm = (u64)(moi ? map_var(varmap, xv) : xv);
+        const double *row = qc[cur];
         write_qt_segment(out_quad, r * ny + b0, bt, [&](int term, int field) -> u64 {
             if (field == 0) {
-                double c = qc[term];
+                double c = row[term];
                 if (moi && xv == yv[term]) c = 2 * c;
                 return d2u(c);
             }
             return field == 1 ? xvm : yvm[term];
         });
+        cur ^= 1;
     }
 }
 
