@@ -310,6 +310,9 @@ int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed, uint64_t 
  * "<kernel>\t<launches>\t<total_ms>\t<min_ms>\t<max_ms>\n"; returns the untruncated length.
  * ------------------------------------------------------------------------------------- */
 int pmt_profile_enable(int on);
+/* restrict the bracketing to kernels whose name contains `substring` (NULL or "": all) — two event records per launch are not
+ * free (a few microseconds of queue time each), so a benchmark times only the kernel it reports on */
+int pmt_profile_filter(const char *substring);
 int64_t pmt_profile_report(char *host_buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pmt_fill_uniform_f64": (_ci, [_vp, _i64, _u64, _f64, _vp]),
     "pmt_fill_uniform_offset_f64": (_ci, [_vp, _i64, _u64, _u64, _f64, _vp]),
     "pmt_profile_enable": (_ci, [_ci]),
+    "pmt_profile_filter": (_ci, [C.c_char_p]),
     "pmt_profile_report": (_i64, [C.c_char_p, _sz]),
     "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),
     "pmt_plan_destroy": (_ci, [_vp]),

@@ -66,6 +66,7 @@ namespace pmt {
 
 struct ProfRecord { const char *name; hipEvent_t e0, e1; };
 static bool g_prof_on = false;
+static std::string g_prof_filter;               // non-empty: only kernels whose name contains it are bracketed
 static std::vector<ProfRecord> g_prof_records;
 static std::vector<hipEvent_t> g_prof_pool;
 
@@ -78,6 +79,7 @@ static hipEvent_t prof_event() {
 
 ProfScope::ProfScope(const char *name, hipStream_t s) : name_(name), s_(s) {
     if (!g_prof_on) return;
+    if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str())) return;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
     if (st != hipStreamCaptureStatusNone) return;          // never time inside a graph capture
@@ -94,6 +96,12 @@ ProfScope::~ProfScope() {
 }  // namespace pmt
 
 using namespace pmt;
+
+extern "C" int pmt_profile_filter(const char *substring) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_prof_filter = substring ? substring : "";
+    return PMT_OK;
+}
 
 extern "C" int pmt_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
