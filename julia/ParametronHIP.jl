@@ -12,6 +12,8 @@
 #     ParametronHIP.update!(plan); fetch!(moi_f.quadratic_terms, hip.quad)   # then MOI.set as in src/moi_interop.jl:134
 module ParametronHIP
 
+using SparseArrays
+
 const lib = get(ENV, "PARAMETRON_HIP_LIB", "libparametron_hip.so")
 
 # isbits layouts shared with the C structs (SURVEY.md Appendix C): LinearTerm{Float64} / MOI.ScalarAffineTerm{Float64} = 16 B,
@@ -89,9 +91,65 @@ quad_gram!(out_quad, out_lin, out_const, A, lda, rows, cols, xvar, b, sign, moi,
                 A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_lin, out_const, workspace, stream))
 
 "bilinearmul!(dest, Q, x', y) — src/functions.jl:840-858"
-bilinear!(out_quad, Q, rows, cols, xvar, yvar, moi, varmap, stream) =
-    check(ccall((:pmt_bilinear_f64, lib), Cint, (DevPtr, Int64, Int64, DevPtr, DevPtr, Cint, DevPtr, DevPtr, Ptr{Cvoid}),
-                Q, rows, cols, xvar, yvar, moi, varmap, out_quad, stream))
+bilinear!(out_quad, Q, ldq, rows, cols, xvar, yvar, moi, varmap, stream) =
+    check(ccall((:pmt_bilinear_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, DevPtr, Cint, DevPtr, DevPtr, Ptr{Cvoid}),
+                Q, ldq, rows, cols, xvar, yvar, moi, varmap, out_quad, stream))
+
+"Matrix{Float64} -> padded device copy (leading dimension ldd >= rows; DESIGN.md §2): a pitched host-to-device copy"
+upload_matrix!(plan::Plan, dst::DevPtr, ldd, A::Matrix{Float64}) =
+    check(ccall((:pmt_plan_upload_2d, lib), Cint, (Ptr{Cvoid}, DevPtr, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
+                plan.handle, dst, 8 * ldd, A, 8 * size(A, 1), 8 * size(A, 1), size(A, 2)))
+
+# ---- solver hand-off (DESIGN.md §8): OSQP-style CSC data built on the device, behind MOI.set
+
+"the Gram node with P's CSC values written from the contraction's epilogue (out_quad may be C_NULL)"
+quad_gram_csc!(out_P_values, out_quad, out_lin, out_const, A, lda, rows, cols, xvar, b, sign, varmap, alpha, workspace, stream) =
+    check(ccall((:pmt_quad_gram_csc_f64, lib), Cint,
+                (DevPtr, Int64, Int64, Int64, DevPtr, DevPtr, Cint, DevPtr, Cdouble, DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Ptr{Cvoid}),
+                A, lda, rows, cols, xvar, b, sign, varmap, alpha, out_P_values, out_quad, out_lin, out_const, workspace, stream))
+
+"structure of a solver matrix from 1-based (row, col) indices (host, once): perm, seg_ptr, colptr, rowval (0-based), nnz"
+function csc_order(rows::Vector{Int64}, cols::Vector{Int64}, nrows, ncols; upper::Bool=false)
+    n = length(rows)
+    perm, seg = zeros(Int64, max(n, 1)), zeros(Int64, n + 1)
+    colptr, rowval, nnz = zeros(Int64, ncols + 1), zeros(Int64, max(n, 1)), Ref{Int64}(0)
+    check(ccall((:pmt_csc_order, lib), Cint,
+                (Int64, Ptr{Int64}, Ptr{Int64}, Int64, Int64, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ref{Int64}),
+                n, rows, cols, nrows, ncols, upper, perm, seg, colptr, rowval, nnz))
+    perm[1:n], seg[1:nnz[] + 1], colptr, rowval[1:nnz[]]
+end
+
+"values of a solver matrix: dst[dst_index[s]] = alpha * sum of the MOI coefficients of run s (per re-evaluation)"
+csc_values!(dst::DevPtr, src_coeff::DevPtr, stride, nnz_in, perm::DevPtr, seg::DevPtr, nnz_out, alpha, dst_index::DevPtr, stream) =
+    check(ccall((:pmt_csc_values_f64, lib), Cint, (DevPtr, Int64, Int64, DevPtr, DevPtr, Int64, Cdouble, DevPtr, DevPtr, Ptr{Cvoid}),
+                src_coeff, stride, nnz_in, perm, seg, nnz_out, alpha, dst_index, dst, stream))
+
+"l, u of `f(x) in set` rows from the constants: kind 0 = Zeros/EqualTo, 1 = Nonnegatives/GreaterThan, 2 = Nonpositives/LessThan"
+qp_bounds!(l::DevPtr, u::DevPtr, consts::DevPtr, rows, kind, value, infty, stream) =
+    check(ccall((:pmt_qp_bounds_f64, lib), Cint, (DevPtr, Int64, Cint, Cdouble, Cdouble, DevPtr, DevPtr, Ptr{Cvoid}),
+                consts, rows, kind, value, infty, l, u, stream))
+
+# ---- sparse constraint matrix (SparseMatrixCSC with a fixed pattern; BASELINE config 5)
+
+"row-major order of the structural non-zeros + per-row boundaries of `nslab` column slabs (host, once per pattern)"
+function sparse_plan(C::SparseMatrixCSC{Float64,Int64}; nslab::Integer=8)
+    m, n = size(C)
+    nz = length(C.nzval)
+    perm, trow, tcol, rowptr = zeros(Int64, max(nz, 1)), zeros(Int64, max(nz, 1)), zeros(Int64, max(nz, 1)), zeros(Int64, m + 1)
+    check(ccall((:pmt_sparse_rowmajor_order, lib), Cint,
+                (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+                m, n, C.colptr, C.rowval, perm, trow, tcol, rowptr))
+    slab = zeros(Int64, max(m, 1) * (nslab + 1))
+    check(ccall((:pmt_sparse_slab_ptr, lib), Cint, (Int64, Int64, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), m, n, nslab, rowptr, tcol, slab))
+    (perm = perm, term_col = tcol, row_ptr = rowptr, slab_ptr = slab)
+end
+
+"C*x (+|-) d for a sparse C written straight into MOI.VectorAffineTerms (XCD-aware scatter)"
+sparse_pack_vector!(out_terms::DevPtr, nzval::DevPtr, perm::DevPtr, term_var::DevPtr, slab_ptr::DevPtr, rows, nslab, varmap::DevPtr,
+                    row_offset, stream) =
+    check(ccall((:pmt_sparse_pack_vector_slabs_f64, lib), Cint,
+                (DevPtr, DevPtr, DevPtr, DevPtr, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
+                nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream))
 
 "device-side `rand!` Parameter callback (README.md:36-43): U[0,1)*scale, counter based"
 device_uniform!(dst::DevPtr, n, seed, scale, stream) =

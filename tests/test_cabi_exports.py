@@ -77,3 +77,28 @@ def test_header_is_plain_c_and_layouts_hold_for_a_c_compiler(tmp_path):
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_julia_binding_stub_matches_the_header():
+    """julia/ParametronHIP.jl cannot be executed here (no julia); keep it honest statically: every ccall names a declared symbol and
+    passes exactly as many arguments as the C declaration has parameters."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "parametron_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(pmt_\w+)\s*\(([^;{]*?)\)\s*;", header):
+        params = m.group(2).strip()
+        decls[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
+    src = open(os.path.join(root, "julia", "ParametronHIP.jl")).read()
+    calls = list(re.finditer(r"ccall\(\(:(pmt_\w+), lib\),\s*[\w{}.]+,\s*\(", src))
+    assert len(calls) >= 20
+    for m in calls:
+        name = m.group(1)
+        assert name in decls, "%s is not declared in the header" % name
+        depth, i = 1, m.end()
+        while depth:                                                       # the argument-type tuple, balanced parentheses
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        types = src[m.end():i - 1].strip().rstrip(",")
+        ntypes = 0 if not types else len([t for t in re.split(r",(?![^{]*})", types) if t.strip()])
+        assert ntypes == decls[name], "%s: %d argument types in the Julia stub, %d parameters in the header" % (name, ntypes, decls[name])
