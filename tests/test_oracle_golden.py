@@ -383,3 +383,42 @@ def test_fill_uniform_stream_is_fixed():
     assert np.array_equal(u, O.fill_uniform(8, 1)[:4])             # counter based: prefix-stable
     golden = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "fill_uniform_seed1.npy"))
     assert np.array_equal(O.fill_uniform(len(golden), 1), golden)
+
+
+# ------------------------------------------------------------------ independent golden vectors (tests/golden/make_c1_golden.py)
+def _c1_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_readme_example1.npz"))
+
+
+def test_oracle_reproduces_the_independent_config1_golden_vectors():
+    """BASELINE config 1 computed by a third implementation (plain Python written from SURVEY.md Appendix A): the C oracle must
+    reproduce it — indices exactly, literal coefficients bit for bit, canonical coefficients within 1e-12."""
+    g = _c1_golden()
+    n, r, m = int(g["n"]), int(g["r"]), int(g["m"])
+    vm = np.zeros(n, dtype=np.int64); vm[:] = g["varmap"]
+    A = g["A"].reshape(n, r).T
+    Cm = g["C"].reshape(n, m).T
+    xi = np.arange(1, n + 1, dtype=np.int64)
+    assert np.array_equal(g["A"], O.fill_uniform(r * n, 1)) and np.array_equal(g["d"], O.fill_uniform(m, 4, 2.0))
+    res = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(A, xi), g["b"])
+    terms, _, consts = res.flat()
+    assert np.array_equal(terms["coeff"].reshape(r, n), g["residual_coeff"]) and np.array_equal(terms["var"].reshape(r, n), g["residual_var"])
+    assert np.array_equal(consts, g["residual_const"])
+    obj = O.Quad().vecdot_affs_affs(res, res)
+    at, qt, const = obj.moi(vm)
+    assert np.array_equal(qt.view(np.int64), g["literal_quad"].view(np.int64))
+    assert np.array_equal(at.view(np.int64), g["literal_aff"].view(np.int64)) and const == g["const"][0]
+    obj.canonicalize()
+    at, qt, const = obj.moi(vm)
+    assert np.array_equal(qt["row"], g["canonical_quad"]["row"]) and np.array_equal(qt["col"], g["canonical_quad"]["col"])
+    np.testing.assert_allclose(qt["coeff"], g["canonical_quad"]["coeff"], rtol=1e-12, atol=0)
+    assert np.array_equal(at["var"], g["canonical_aff"]["var"])
+    np.testing.assert_allclose(at["coeff"], g["canonical_aff"]["coeff"], rtol=1e-12, atol=0)
+    ct, cc = O.AffVec(m).vecsubtract(O.AffVec(m).matvecmul_vars(Cm, xi), g["d"]).moi(vm)
+    assert np.array_equal(ct.view(np.int64), g["constraint_terms"].view(np.int64)) and np.array_equal(cc, g["constraint_consts"])
+    bt, bc = O.AffVec(n).vecsubtract(xi, g["lows"]).moi(vm)
+    assert np.array_equal(bt.view(np.int64), g["bounds_terms"].view(np.int64)) and np.array_equal(bc, g["bounds_consts"])
+    Q = g["Q"].reshape(n, n).T
+    _, bq, _ = O.Quad().bilinearmul(Q, xi, xi).moi(vm)
+    assert np.array_equal(bq.view(np.int64), g["bilinear_quad"].view(np.int64))
