@@ -32,7 +32,6 @@ constexpr int SN = 128;               // columns handled (smaller instances are 
 constexpr int SKC = PMT_BS_KC;        // rows per LDS chunk (64: 66 KB of LDS; 128 = a whole instance measured 18 % slower)
 constexpr int SGP = SKC + 1;          // odd pitch: conflict-free operand reads
 constexpr int SPITCH = 129;           // epilogue staging pitch
-constexpr int SNT = 512;
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -57,19 +56,24 @@ __device__ __constant__ const unsigned char S_VALID2[8] = {1, 1, 1, 1, 0, 0, 1, 
 
 }  // namespace
 
-__global__ __launch_bounds__(SNT, 2) void batch_small_kernel(SmallArgs p) {
+// NW waves per workgroup; wave w plays the roles w, w + NW, ... of the 8-role table (roles w and w + 4 sit on the same SIMD in the
+// 8-wave layout, so the 4-wave layout keeps the per-SIMD balance).  NW = 4: 256 threads, two workgroups per CU at the full 256-VGPR
+// budget — one workgroup's loads, q and epilogue overlap the other's contraction.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void batch_small_kernel(SmallArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int NR = 8 / NW;                               // roles per wave
+    constexpr int NCLS = NT / 128;                           // row classes of the q accumulation
     __shared__ double panel[SN * SGP];                      // the chunk; reused by the epilogue for half a tile (64 x SPITCH)
     __shared__ double cvec[SKC];
-    __shared__ double cvec_q[SNT];
+    __shared__ double cvec_q[NT];
     static_assert(SN * SGP >= 64 * SPITCH, "LDS buffer must hold the epilogue staging tile");
     constexpr int KP = SKC / 2;                              // 16-byte pieces per column
-    constexpr int CPP = SNT / KP;                            // columns per pass
+    constexpr int CPP = NT / KP;                             // columns per pass
     constexpr int NP = SN / CPP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, lk = lane >> 4;
     const int kp = tid % KP, cc0 = tid / KP;
-    const int tn1 = S_TN1[wave], tn2 = S_TN2[wave];
-    const int v1 = S_VALID1[wave], v2 = S_VALID2[wave];
     const bool fast = p.vec_in && p.cols == SN && (p.rows % SKC) == 0 && p.rows > 0;
     const int nchunk = (int)max((int64_t)1, (p.rows + SKC - 1) / SKC);
     const int64_t n = p.cols;
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(SNT, 2) void batch_small_kernel(SmallArgs p) {
         }
     };
 
-    double acc[5][4];
-    double qpart = 0.0;                                      // thread t: column t & 127, rows (t >> 7) + 4u of every chunk
+    double acc[NR][5][4];
+    double qpart = 0.0;                                      // thread t: column t & 127, rows (t >> 7) + NCLS*u of every chunk
     int64_t inst = blockIdx.x;
     int ch = 0;
     if (inst < p.B) load_chunk(inst, 0);
@@ -122,48 +126,56 @@ __global__ __launch_bounds__(SNT, 2) void batch_small_kernel(SmallArgs p) {
         }
         if (tid < SKC) cvec[tid] = cval;
         __syncthreads();
-        const int64_t i0 = (int64_t)ch * SKC;
         int64_t ninst = inst;
         int nch = ch + 1;
         if (nch == nchunk) { nch = 0; ninst = inst + gridDim.x; }
         if (ninst < p.B) load_chunk(ninst, (int64_t)nch * SKC);
         if (ch == 0) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
+            for (int ro = 0; ro < NR; ++ro)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[ro][i][r] = 0.0;
             qpart = 0.0;
         }
-        // ---- q from the chunk (vector ALU; runs beside the other waves' MFMAs): thread t owns column t & 127 and the rows k = (t >> 7) mod 4
-        // — a wave reads 64 consecutive columns at one k (pitch 65: conflict-free), c_k is an LDS broadcast
+        // ---- q from the chunk (vector ALU; runs beside the other waves' MFMAs): thread t owns column t & 127 and the rows
+        // k = (t >> 7) mod NCLS — a wave reads 64 consecutive columns at one k (pitch 65: conflict-free), c_k is an LDS broadcast
         if (!(PMT_BS_SKIP & 2)) {
             const double *colp = panel + (tid & 127) * SGP + (tid >> 7);
 #pragma unroll 4
-            for (int u = 0; u < SKC / 4; ++u) qpart += cvec[(tid >> 7) + 4 * u] * colp[4 * u];
+            for (int u = 0; u < SKC / NCLS; ++u) qpart += cvec[(tid >> 7) + NCLS * u] * colp[NCLS * u];
         }
         // ---- contraction: 16 k-steps of 4 rows
         if (!(PMT_BS_SKIP & 1)) {
-            const double *pa[5], *pb1, *pb2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pa[i] = panel + (S_TM1[wave][i] * 16 + lm) * SGP + lk;
-            pa[4] = panel + (S_TM2[wave] * 16 + lm) * SGP + lk;
-            pb1 = panel + (tn1 * 16) * SGP + lk;
-            pb2 = panel + (tn2 * 16) * SGP + lk;
             int rc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) rc[r] = (((((lm >> 2) + r) & 3) << 2) | (lm & 3)) * SGP;     // column group rotated by r blocks
+            const double *pa[NR][5], *pb1[NR], *pb2[NR];
+#pragma unroll
+            for (int ro = 0; ro < NR; ++ro) {
+                const int role = wave + ro * NW;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pa[ro][i] = panel + (S_TM1[role][i] * 16 + lm) * SGP + lk;
+                pa[ro][4] = panel + (S_TM2[role] * 16 + lm) * SGP + lk;
+                pb1[ro] = panel + (S_TN1[role] * 16) * SGP + lk;
+                pb2[ro] = panel + (S_TN2[role] * 16) * SGP + lk;
+            }
 #pragma unroll 2
             for (int ks = 0; ks < SKC / 4; ++ks) {
-                double a[5], b1[4], b2[4];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) a[i] = pa[i][ks * 4];
+                for (int ro = 0; ro < NR; ++ro) {
+                    double a[5], b1[4], b2[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { b1[r] = pb1[rc[r] + ks * 4]; b2[r] = pb2[rc[r] + ks * 4]; }
+                    for (int i = 0; i < 5; ++i) a[i] = pa[ro][i][ks * 4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r) { b1[r] = pb1[ro][rc[r] + ks * 4]; b2[r] = pb2[ro][rc[r] + ks * 4]; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1[r], acc[i][r], 0, 0, 0);
-                    acc[4][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[4], b2[r], acc[4][r], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[ro][i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1[r], acc[ro][i][r], 0, 0, 0);
+                        acc[ro][4][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[4], b2[r], acc[ro][4][r], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -173,36 +185,43 @@ __global__ __launch_bounds__(SNT, 2) void batch_small_kernel(SmallArgs p) {
             if (p.Cm) {                                      // constraint block: a 16 KB transposition, read through L2
                 const double *Ci = p.Cm + inst * p.m * n;
                 double *oc = p.out_C + inst * p.out_stride;
-                for (int64_t e = tid; e < p.m * n; e += SNT) {
+                for (int64_t e = tid; e < p.m * n; e += NT) {
                     const int64_t row = e / n, col = e - row * n;
                     oc[e] = Ci[col * p.m + row];
                 }
-                if (tid < p.m) p.out_d[inst * p.out_stride + tid] = signed_const(p.d[inst * p.m + tid], p.sign_d);
-                for (int64_t i = tid + SNT; i < p.m; i += SNT) p.out_d[inst * p.out_stride + i] = signed_const(p.d[inst * p.m + i], p.sign_d);
+                for (int64_t i = tid; i < p.m; i += NT) p.out_d[inst * p.out_stride + i] = signed_const(p.d[inst * p.m + i], p.sign_d);
             }
-            __syncthreads();                                 // q: add the four row classes of a column (through LDS), 2x
+            __syncthreads();                                 // q: add the row classes of a column (through LDS), 2x
             cvec_q[tid] = qpart;
             __syncthreads();
-            if (tid < 128 && tid < p.cols)
-                p.out_lin[inst * p.out_stride + tid] = 2 * (((cvec_q[tid] + cvec_q[tid + 128]) + cvec_q[tid + 256]) + cvec_q[tid + 384]);
+            if (tid < 128 && tid < p.cols) {
+                double sum = cvec_q[tid];
+#pragma unroll
+                for (int c = 1; c < NCLS; ++c) sum = sum + cvec_q[tid + 128 * c];
+                p.out_lin[inst * p.out_stride + tid] = 2 * sum;
+            }
             const int i_ = lane >> 4, bq = (lane >> 2) & 3, j_ = lane & 3;       // accumulator element -> (row, col) inside a sub-tile
             for (int h = 0; h < ((PMT_BS_SKIP & 4) ? 0 : 2); ++h) {
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int tm = i < 4 ? S_TM1[wave][i] : S_TM2[wave];
-                    const int tn = i < 4 ? tn1 : tn2;
-                    const bool valid = i < 4 ? ((v1 >> i) & 1) : (v2 & 1);
-                    if (valid && (tm >> 2) == h) {
+                for (int ro = 0; ro < NR; ++ro) {
+                    const int role = wave + ro * NW;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = tm * 16 + 4 * bq + i_, col = tn * 16 + 4 * ((bq + r) & 3) + j_;
-                            panel[(row - 64 * h) * SPITCH + col] = 2 * acc[i][r];
+                    for (int i = 0; i < 5; ++i) {
+                        const int tm = i < 4 ? S_TM1[role][i] : S_TM2[role];
+                        const int tn = i < 4 ? S_TN1[role] : S_TN2[role];
+                        const bool valid = i < 4 ? ((S_VALID1[role] >> i) & 1) : (S_VALID2[role] & 1);
+                        if (valid && (tm >> 2) == h) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = tm * 16 + 4 * bq + i_, col = tn * 16 + 4 * ((bq + r) & 3) + j_;
+                                panel[(row - 64 * h) * SPITCH + col] = 2 * acc[ro][i][r];
+                            }
                         }
                     }
                 }
                 __syncthreads();
-                for (int row = wave; row < 64; row += SNT / 64) {
+                for (int row = wave; row < 64; row += NW) {
                     const int64_t j = 64 * h + row;
                     if (j >= n) break;
                     const int64_t term0 = j * n - (j * (j - 1)) / 2;
@@ -228,8 +247,12 @@ int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols,
     p.A = A; p.lda = lda; p.rows = rows; p.cols = cols; p.strideA = strideA; p.b = b; p.strideb = strideb; p.sign = sign;
     p.out_q = out_q; p.out_lin = out_lin; p.out_const = out_const; p.out_stride = out_stride; p.B = B;
     p.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (strideA & 1) == 0) ? 1 : 0;
-    const unsigned grid = (unsigned)std::min<int64_t>(B, 4096);
-    PMT_LAUNCH(batch_small_kernel, dim3(grid), dim3(SNT), 0, s, p);
+    static const int nw = [] { const char *e = getenv("PMT_BATCH_SMALL_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();   // 4: two 256-thread workgroups per CU — measured 1.16 ms vs 0.72
+    if (nw == 8) {
+        PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<8>, dim3((unsigned)std::min<int64_t>(B, 4096)), dim3(512), 0, s, p);
+    } else {
+        PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<4>, dim3((unsigned)std::min<int64_t>(B, 4096)), dim3(256), 0, s, p);
+    }
     return check_launch("batch_small_kernel");
 }
 
