@@ -708,11 +708,7 @@ def _rule_canonicalize(model, ctx, x):
         raise ArgumentError("canonicalize on the device needs an AffineFunction or QuadraticFunction expression")
     if isinstance(dx, DQuad):
         dx.materialize()
-    x.prepare()
-    for inp in schedule([x]):
-        if isinstance(inp, DeviceNode):
-            inp.prepare()
-    evaluate(ctx, [x])                                                     # once, to learn the (static) indices
+    evaluate(ctx, [x])                                                     # once (prepare + emit), to learn the (static) indices
 
     def order_affine(terms_ptr, nterms):
         t = fetch_terms(ctx, terms_ptr, nterms, LT); ctx.synchronize()
