@@ -225,6 +225,14 @@ int pmt_canonical_order_quadratic(int64_t n, const int64_t *host_rows, const int
 int pmt_segment_sum_f64(const void *in_terms, int64_t in_stride_bytes, const int64_t *perm, const int64_t *seg_ptr, int64_t nseg,
                         void *out_terms, int64_t out_stride_bytes, void *stream);
 
+/* prune_zero!(f; atol) (src/functions.jl:294-297, 409-413): out_terms = the terms with abs(coeff) > atol, in order; *out_count (DEVICE
+ * memory) = how many.  term_bytes: 16 (pmt_linear_term) or 24 (pmt_quadratic_term).  Not on the solve path: the count is data
+ * dependent, the caller synchronises before using it.  NOTE the reference's quirk: prune_zero!(::QuadraticFunction; atol) prunes the
+ * affine part with the DEFAULT atol (0), :410 — callers that mirror it pass atol only for the quadratic terms. */
+size_t pmt_prune_zero_workspace_bytes(int64_t n, int term_bytes);
+int pmt_prune_zero_f64(const void *terms, int64_t n, int term_bytes, double atol, void *out_terms, int64_t *out_count,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Solver hand-off: what happens AFTER MOI.set(optimizer, ...) (src/moi_interop.jl:134,171) — in the
  * reference third-party code (MathOptInterface 0.8 + the OSQP wrapper) on the host.  Here the MOI buffers stay in HBM and

@@ -6,11 +6,10 @@ solve!, src/Parametron.jl:3-36) over the C ABI of libparametron_hip.so (include/
 """
 from . import _lib  # noqa: F401
 from ._lib import ArgumentError, DimensionMismatch, ErrorException  # noqa: F401
-from .functions import (AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, canonicalize,  # noqa: F401
-                        prune_zero)
+from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, canonicalize  # noqa: F401
 from .parameter import DerivedParameter, DeviceUniformParameter, Parameter  # noqa: F401
-from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, getindex, getproperty, lazy, transpose, vcat,  # noqa: F401
-                             vect, wrap)
+from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, getindex, getproperty, lazy, prune_zero, transpose,  # noqa: F401
+                             vcat, vect, wrap)
 from .hostops import Transpose  # noqa: F401
 from . import moi  # noqa: F401
 from .model import (AbstractOptimizer, Maximize, Minimize, MockOptimizer, Model, constraint, dualstatus, initialize,  # noqa: F401

@@ -880,6 +880,45 @@ def expression(thunk):
     return thunk() if callable(thunk) and not _is_lazy(thunk) else thunk
 
 
+def prune_zero(expr, atol=0.0):
+    """prune_zero(expr(); atol) for a device expression (src/functions.jl:294-297, 409-413): the expression is re-evaluated, its term
+    lists are compacted ON THE DEVICE (pmt_prune_zero_f64) and only the surviving terms are fetched.  The result is a native host
+    function — the number of terms is data dependent, so this is not a node of the solve path (nor is it in the reference)."""
+    if not isinstance(expr, DeviceNode):
+        from .functions import prune_zero as host_prune
+        return host_prune(expr() if _is_lazy(expr) else expr, atol)
+    ctx = expr.model.device()
+    out = expr.out
+    if not isinstance(out, (DAff, DQuad)):
+        raise ArgumentError("prune_zero needs an AffineFunction or QuadraticFunction expression")
+    if isinstance(out, DQuad):
+        out.materialize()
+    evaluate(ctx, [expr])
+
+    bufs = expr.__dict__.setdefault("_prune_bufs", {})          # plan memory is never freed: allocate once per node
+
+    def compact(ptr, n, dtype, tol):
+        nbytes = dtype.itemsize
+        if ptr not in bufs:
+            ws_bytes = int(ctx.lib.pmt_prune_zero_workspace_bytes(n, nbytes))
+            bufs[ptr] = (ctx.alloc(nbytes * max(n, 1)), ctx.alloc(8), ctx.alloc(ws_bytes), ws_bytes)
+        dst, cnt, ws, ws_bytes = bufs[ptr]
+        ctx.call("pmt_prune_zero_f64", P(ptr), n, nbytes, float(tol), P(dst), P(cnt), P(ws), ws_bytes)
+        k = np.zeros(1, dtype=np.int64)
+        ctx.fetch(k, cnt, 8); ctx.synchronize()
+        t = fetch_terms(ctx, dst, int(k[0]), dtype); ctx.synchronize()
+        return t
+    c = fetch_f64(ctx, out.const, 1)
+    if isinstance(out, DAff):
+        t = compact(out.terms, out.nterms, LT, atol)
+        ctx.synchronize()
+        return AffineFunction.from_arrays(t, c[0])
+    q = compact(out.quad, out.nq, QT, atol)
+    l = compact(out.lin, out.nl, LT, 0.0)                 # the reference prunes the affine part with the DEFAULT atol (:410)
+    ctx.synchronize()
+    return QuadraticFunction.from_arrays(q, l, c[0])
+
+
 def getindex(x, *idx):
     """@expression p[i, j] / p[:, j]"""
     return lazy(lambda v: v[idx if len(idx) > 1 else idx[0]], x)

@@ -166,3 +166,41 @@ def test_findallocs_reports_kernels_and_no_plan_growth():         # test/debug.j
     out2 = io.StringIO()
     P.findallocs(out2, p)
     assert "no device work" in out2.getvalue()
+
+
+def test_prune_zero_on_the_device_matches_the_host_rule():       # src/functions.jl:294-297, 409-413; test/functions.jl:9-28
+    import ctypes as C
+    import gpu_util as g
+    # C ABI: stable compaction of LinearTerms and QuadraticTerms, data-dependent count
+    rng = np.random.default_rng(0)
+    n = 5000
+    lt = np.zeros(n, dtype=g.LT); lt["coeff"] = np.where(rng.random(n) < 0.4, 0.0, rng.standard_normal(n) * 1e-3); lt["var"] = rng.integers(1, 50, n)
+    lt["coeff"][::7] = -0.0
+    for atol in (0.0, 5e-4):
+        d_in, d_out, cnt = g.to_dev(lt), g.empty_terms(n, g.LT), torch.zeros(1, dtype=torch.int64, device=g.DEV)
+        wsb = g.lib().pmt_prune_zero_workspace_bytes(n, 16)
+        ws = g.empty_f64(wsb // 8 + 1)
+        g.call("pmt_prune_zero_f64", g.ptr(d_in), n, 16, atol, g.ptr(d_out), g.ptr(cnt), g.ptr(ws), C.c_size_t(wsb), g.stream())
+        keep = lt[np.abs(lt["coeff"]) > atol]
+        assert int(cnt.item()) == len(keep)
+        g.assert_terms_equal(g.terms_to_host(d_out, len(keep), g.LT), keep)
+    qt = np.zeros(300, dtype=g.QT); qt["coeff"] = np.where(rng.random(300) < 0.5, 0.0, 1.5); qt["row"] = rng.integers(1, 9, 300); qt["col"] = rng.integers(1, 9, 300)
+    d_in, d_out, cnt = g.to_dev(qt), g.empty_terms(300, g.QT), torch.zeros(1, dtype=torch.int64, device=g.DEV)
+    wsb = g.lib().pmt_prune_zero_workspace_bytes(300, 24)
+    ws = g.empty_f64(wsb // 8 + 1)
+    g.call("pmt_prune_zero_f64", g.ptr(d_in), 300, 24, 0.0, g.ptr(d_out), g.ptr(cnt), g.ptr(ws), C.c_size_t(wsb), g.stream())
+    keep = qt[np.abs(qt["coeff"]) > 0]
+    assert int(cnt.item()) == len(keep)
+    g.assert_terms_equal(g.terms_to_host(d_out, len(keep), g.QT), keep)
+    # expression level: x'Qx + q'x with zeros in Q and q; the affine part is pruned with the DEFAULT atol (the reference's quirk)
+    model = P.mock_model()
+    x = [Variable(model) for _ in range(3)]
+    Qv = np.array([[1.0, 0.0, 1e-9], [0.0, 0.0, 2.0], [0.0, 0.0, 0.0]])
+    Q = P.Parameter(model, val=np.asfortranarray(Qv))
+    qv = P.Parameter(model, val=np.array([0.0, 1e-9, 3.0]))
+    expr = P.bilinear(x, Q, x) + P.dot(qv, x)
+    full = expr()
+    got = P.prune_zero(expr, atol=1e-6)                                    # device expression: compacted on the device
+    want = P.prune_zero(full, atol=1e-6)                                   # host function: the host rule
+    assert repr(got) == repr(want)
+    assert len(got.quadratic) == 2 and len(got.affine.linear) == 2         # 1e-9 survives in the affine part (default atol = 0)
