@@ -7,13 +7,14 @@
 //     chunk is 66 KB, so TWO workgroups share a CU and one loads while the other multiplies;
 //   * only the 36 of the 64 16x16 sub-tiles that touch the upper triangle are computed.  Sub-tiles are dealt to the 8 waves as
 //     "four of one column strip + one of another" so that the four rotated B-operand reads of a strip are shared (5 + 8 LDS reads per
-//     20 MFMAs) and every SIMD carries 10 sub-tiles (9 useful);
+//     20 MFMAs) and every SIMD carries 9 sub-tiles (the slots a role does not need are compiled out per role class);
 //   * q is accumulated from the same LDS chunk by the vector ALU and the coefficients leave through an LDS transposition as
 //     contiguous row segments; c'c (a serial left-to-right chain per instance, src/functions.jl:574) stays in its own kernel, one
 //     thread per instance — inside this kernel the chain stalls a whole workgroup.
 // Coefficient order within a dot product differs from the general path only in q (tolerance 1e-12); Q uses the same MFMA lane
 // mapping and k order as gram_sk.hip.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -161,23 +162,37 @@ __global__ __launch_bounds__(NW * 64, 2) void batch_small_kernel(SmallArgs p) {
                 pb1[ro] = panel + (S_TN1[role] * 16) * SGP + lk;
                 pb2[ro] = panel + (S_TN2[role] * 16) * SGP + lk;
             }
+            // the unused sub-tile slots of a role (group-1 slot 3 of roles 6, 7; the group-2 slot of roles 4, 5) are compiled OUT per
+            // role class instead of multiplied and discarded: 9 useful sub-tiles per SIMD, not 10.  The class is wave-uniform and
+            // chosen outside the k loop, whose body stays branch-free.
+            auto contract = [&](auto has4_t, auto has2_t) {
+                constexpr bool H4 = decltype(has4_t)::value, H2 = decltype(has2_t)::value;
 #pragma unroll 2
-            for (int ks = 0; ks < SKC / 4; ++ks) {
+                for (int ks = 0; ks < SKC / 4; ++ks) {
 #pragma unroll
-                for (int ro = 0; ro < NR; ++ro) {
-                    double a[5], b1[4], b2[4];
+                    for (int ro = 0; ro < NR; ++ro) {
+                        double a[5], b1[4], b2[4];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) a[i] = pa[ro][i][ks * 4];
+                        for (int i = 0; i < 3; ++i) a[i] = pa[ro][i][ks * 4];
+                        if (H4) a[3] = pa[ro][3][ks * 4];
+                        if (H2) a[4] = pa[ro][4][ks * 4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { b1[r] = pb1[ro][rc[r] + ks * 4]; b2[r] = pb2[ro][rc[r] + ks * 4]; }
+                        for (int r = 0; r < 4; ++r) { b1[r] = pb1[ro][rc[r] + ks * 4]; if (H2) b2[r] = pb2[ro][rc[r] + ks * 4]; }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc[ro][i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1[r], acc[ro][i][r], 0, 0, 0);
-                        acc[ro][4][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[4], b2[r], acc[ro][4][r], 0, 0, 0);
+                            for (int i = 0; i < (H4 ? 4 : 3); ++i)
+                                acc[ro][i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1[r], acc[ro][i][r], 0, 0, 0);
+                            if (H2) acc[ro][4][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[4], b2[r], acc[ro][4][r], 0, 0, 0);
+                        }
                     }
                 }
-            }
+            };
+            using T = std::true_type;
+            using F = std::false_type;
+            if (NR == 1 && wave >= 6) contract(F{}, T{});
+            else if (NR == 1 && wave >= 4) contract(T{}, F{});
+            else contract(T{}, T{});
         }
         // ---- outputs after the last chunk of an instance
         if (ch == nchunk - 1) {
