@@ -31,7 +31,7 @@ constexpr int SN = 128;               // columns handled (smaller instances are 
 #define PMT_BS_KC 64
 #endif
 constexpr int SKC = PMT_BS_KC;        // rows per LDS chunk (64: 66 KB of LDS; 128 = a whole instance measured 18 % slower)
-constexpr int SGP = SKC + 1;          // odd pitch: conflict-free operand reads
+constexpr int SGP = SKC + 17;         // pitch = 17 (mod 32) doubles: the 16 columns x 2 k of half a wave land on 32 distinct bank pairs (SKC + 1 = 1 mod 32 does not)
 constexpr int SPITCH = 129;           // epilogue staging pitch
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
