@@ -271,3 +271,31 @@ def test_device_handoff_with_permuted_optimizer_indices_takes_the_generic_path()
         np.testing.assert_allclose(got["q"], q, rtol=1e-12)
         Aw = np.zeros((m, n)); Aw[:, vm] = Cm()
         assert np.array_equal(dense_of(got["A"], (m, n)), Aw)
+
+
+def test_handoff_with_constant_objective_and_maximize_quadratic():
+    """Constant (Parameter-free) objective: P and q are built once on the host from the MOI function; Maximize flips the sign of P, q
+    and r.  Constraints are parameterised, so A, l, u still follow the Parameters."""
+    n = 4
+    model = P.Model(DenseQPOptimizer(variable_offset=1))
+    x = [Variable(model) for _ in range(n)]
+    rng = np.random.default_rng(9)
+    lo = P.Parameter(lambda v: v.__setitem__(Ellipsis, -rng.random(n)), np.zeros(n), model)
+    obj = 0.0 - 1.0 * (x[0] ** 2 + 2.0 * x[0] * x[1] + 3.0 * x[1] ** 2 + x[3] ** 2) + 4.0 * x[2] + 1.5      # concave: a Maximize problem
+    P.objective(model, P.Maximize, obj)
+    P.constraint(model, x, ">=", lo)
+    P.constraint(model, 1.0 * x[2] + x[3] <= 2.0)
+    P.solve(model)
+    qp = DeviceQP(model)
+    for _ in range(2):
+        got = qp.fetch()
+        off = 1
+        Pu = dense_of(got["P"], (qp.nvars, qp.nvars))[off:, off:]
+        want = np.zeros((n, n)); want[0, 0] = 2.0; want[0, 1] = 2.0; want[1, 1] = 6.0; want[3, 3] = 2.0      # -(-(...)): minimise the negated objective
+        assert np.array_equal(Pu, want)
+        assert got["q"][off:].tolist() == [0.0, 0.0, -4.0, 0.0] and got["r"] == -1.5
+        Am = dense_of(got["A"], (qp.nrows, qp.nvars))[:, off:]
+        assert qp.nrows == n + 1 and np.array_equal(Am[0], [0.0, 0.0, 1.0, 1.0]) and np.array_equal(Am[1:], np.eye(n))
+        assert got["u"][0] == 2.0 and got["l"][0] == -1e20 and np.array_equal(got["l"][1:], lo()) and np.all(got["u"][1:] == 1e20)
+        P.solve(model)
+        qp.refresh()
