@@ -58,8 +58,7 @@ __device__ __constant__ const unsigned char S_VALID2[8] = {1, 1, 1, 1, 0, 0, 1, 
 }  // namespace
 
 // NW waves per workgroup; wave w plays the roles w, w + NW, ... of the 8-role table (roles w and w + 4 sit on the same SIMD in the
-// 8-wave layout, so the 4-wave layout keeps the per-SIMD balance).  NW = 4: 256 threads, two workgroups per CU at the full 256-VGPR
-// budget — one workgroup's loads, q and epilogue overlap the other's contraction.
+// 8-wave layout, so a 4-wave layout would keep the per-SIMD balance).  Shipped: NW = 8, one 512-thread workgroup per CU.
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void batch_small_kernel(SmallArgs p) {
     constexpr int NT = NW * 64;
@@ -262,12 +261,8 @@ int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols,
     p.A = A; p.lda = lda; p.rows = rows; p.cols = cols; p.strideA = strideA; p.b = b; p.strideb = strideb; p.sign = sign;
     p.out_q = out_q; p.out_lin = out_lin; p.out_const = out_const; p.out_stride = out_stride; p.B = B;
     p.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (strideA & 1) == 0) ? 1 : 0;
-    static const int nw = [] { const char *e = getenv("PMT_BATCH_SMALL_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();   // 4: two 256-thread workgroups per CU — measured 1.16 ms vs 0.72
-    if (nw == 8) {
-        PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<8>, dim3((unsigned)std::min<int64_t>(B, 4096)), dim3(512), 0, s, p);
-    } else {
-        PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<4>, dim3((unsigned)std::min<int64_t>(B, 4096)), dim3(256), 0, s, p);
-    }
+    // (a 4-wave instantiation — two workgroups per CU — measured 1.16 ms against 0.72 ms for this one; profiles/r01d_side_stream.txt)
+    PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<8>, dim3((unsigned)std::min<int64_t>(B, 4096)), dim3(512), 0, s, p);
     return check_launch("batch_small_kernel");
 }
 
