@@ -257,9 +257,10 @@ int pmt_qp_bounds_f64(const double *consts, int64_t rows, int set_kind, double s
 
 /* ---------------------------------------------------------------------------------------
  * Sparse constraint matrix (BASELINE config 5): C given in CSC (Julia SparseMatrixCSC: colptr/rowval
- * 1-based Int64, nzval).  pmt_sparse_plan_* computes ONCE the row-major order of the structural non-zeros;
- * per re-evaluation pmt_sparse_pack_vector_f64 gathers nzval through it into MOI.VectorAffineTerms
- * (row-major, columns ascending within a row = the reference's matvecmul! order restricted to structural nz).
+ * 1-based Int64, nzval).  The reference has no sparse path — matvecmul!(y, A::AbstractMatrix, x) src/functions.jl:775-798 walks every
+ * (row, col) — so the output here is the reference's output minus the structural zeros.  pmt_sparse_rowmajor_order computes ONCE the
+ * row-major order of the structural non-zeros; per re-evaluation pmt_sparse_pack_vector_f64 gathers nzval through it into
+ * MOI.VectorAffineTerms (update! src/moi_interop.jl:64-81; row-major, columns ascending within a row = matvecmul!'s order).
  * ------------------------------------------------------------------------------------- */
 /* host-side helper: perm[t] = index into nzval of the t-th term in row-major order, rows_out[t], cols_out[t] (1-based) */
 int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *host_colptr, const int64_t *host_rowval,
@@ -280,7 +281,7 @@ int pmt_sparse_pack_vector_slabs_f64(const double *nzval, const int64_t *perm, c
                                      pmt_vector_affine_term *out_terms, void *stream);
 int pmt_sparse_assemble_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
                                   int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream);
-/* constants: out[i] = 0.0 (+|-) d[i] */
+/* constants of the same node: out[i] = 0.0 (+|-) d[i]  (vecadd!/vecsubtract! on zero!'d functions, src/functions.jl:244,452,474) */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -356,7 +357,8 @@ int pmt_plan_begin_record(pmt_plan *plan);
 int pmt_plan_end_record(pmt_plan *plan);
 void *pmt_plan_recording_stream(pmt_plan *plan);
 int64_t pmt_plan_tape_length(const pmt_plan *plan);
-/* replay the tape on the plan's stream: one update!(model).  use_graph != 0 replays a captured hipGraph */
+/* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
+ * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */
 int pmt_plan_update(pmt_plan *plan);
 int pmt_plan_instantiate_graph(pmt_plan *plan);
 
