@@ -344,6 +344,8 @@ int pmt_host_free(void *host_ptr);
 /* asynchronous copies on the plan's stream */
 int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
 int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
+/* zero a device buffer (setup time): the padding rows of a Parameter matrix / vector must be zero when a kernel is given the padded row count */
+int pmt_plan_zero(pmt_plan *plan, void *device_dst, size_t bytes);
 /* pitched variants (hipMemcpy2DAsync): `height` rows of `width_bytes`, e.g. the columns of a matrix whose device copy is padded */
 int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes,
                        size_t height);

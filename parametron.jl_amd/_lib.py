@@ -101,6 +101,7 @@ SIGNATURES = {
     "pmt_host_free": (_ci, [_vp]),
     "pmt_plan_upload": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
     "pmt_plan_begin_record": (_ci, [_vp]),
     "pmt_plan_end_record": (_ci, [_vp]),

@@ -232,6 +232,14 @@ extern "C" int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *hos
     return PMT_OK;
 }
 
+extern "C" int pmt_plan_zero(pmt_plan *plan, void *device_dst, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_zero: null plan");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(device_dst, PMT_INVALID_ARGUMENT, "plan_zero: null pointer");
+    PMT_HIP_CHECK(hipMemsetAsync(device_dst, 0, bytes, plan->stream));
+    return PMT_OK;
+}
+
 extern "C" int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch: null plan");
     if (bytes == 0) return PMT_OK;

@@ -127,6 +127,19 @@ def _to_native(kind, val):
     return [AffineFunction.of(float(v) if _isnum(v) else v) for v in val]
 
 
+def _gram_rows(gram):
+    """Row count handed to the Gram kernel: the zero-padded count (device.row_padded) when both the matrix and the vector carry the
+    zero padding rows — whole 16-row stages keep the contraction on its branch-free path; zero rows change nothing."""
+    from .device import DMat, DVec, row_padded
+    rows = gram.mat.rows
+    padded = row_padded(rows)
+    if padded == rows or not isinstance(gram.mat, DMat) or gram.mat.lda < padded:
+        return rows
+    if gram.vec is not None and not (isinstance(gram.vec, DVec) and getattr(gram.vec, "padded", 0) >= padded):
+        return rows
+    return padded
+
+
 class _Record:
     """Common part of Objective and Constraint (src/moi_interop.jl:113-129, 141-166)."""
 
@@ -174,14 +187,14 @@ class _Record:
                 n = gram.mat.cols
                 self.f = ScalarQuadraticFunction(n, 0, alloc=ctx.pinned_array)
                 dp, dl, dc = ctx.alloc(8 * max(n * (n + 1) // 2, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
-                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(gram.mat.rows, n))))
+                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(_gram_rows(gram), n))))
                 self.dev = {"P_values": dp, "P_vars": handoff_varmap[gram.xvars.vars - 1], "lin": dl, "const": dc}
                 self.mode = "canonical-csc"
                 vec = gram.vec.buf if gram.vec is not None else None
                 alpha = -1.0 if self.model.sense == "Maximize" else 1.0
 
                 def emit(c):
-                    c.call("pmt_quad_gram_csc_f64", P(gram.mat.buf), gram.mat.lda, gram.mat.rows, n, P(gram.xvars.buf), P(vec),
+                    c.call("pmt_quad_gram_csc_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec),
                            gram.sign if vec else 0, P(varmap_buf), alpha, P(dp), None, P(dl), P(dc), P(ws))
                 return emit
             if use_gram:
@@ -189,13 +202,13 @@ class _Record:
                 nq = n * (n + 1) // 2
                 self.f = ScalarQuadraticFunction(n, nq, alloc=ctx.pinned_array)
                 dq, dl, dc = ctx.alloc(24 * max(nq, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
-                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(gram.mat.rows, n))))
+                ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(_gram_rows(gram), n))))
                 self.dev = {"quad": dq, "lin": dl, "const": dc}
                 self.mode = "canonical"
                 vec = gram.vec.buf if gram.vec is not None else None
 
                 def emit(c):
-                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.lda, gram.mat.rows, n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
+                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
                            1, P(varmap_buf), P(dq), P(dl), P(dc), P(ws))
                 return emit
             self.mode = "literal"

@@ -16,6 +16,7 @@ from oracle import oracle as O  # noqa: E402
 
 def test_padded_lda_policy():
     assert padded_lda(4096) == 4160 and padded_lda(512) == 576 and padded_lda(8) == 8 and padded_lda(4000) == 4000 and padded_lda(1024) % 2 == 0
+    assert padded_lda(4090) == 4160 and padded_lda(1000) == 1008 and padded_lda(63) == 63 and padded_lda(65) == 80      # zero rows up to a multiple of 16
 
 
 def test_matrix_fill_places_the_contiguous_stream_with_a_leading_dimension():
@@ -90,3 +91,31 @@ def test_row_major_column_major_and_page_locked_parameter_values_upload_identica
         model.close()
     for t, c in results[1:]:
         assert np.array_equal(t.view(np.int64), results[0][0].view(np.int64)) and np.array_equal(c, results[0][1])
+
+
+@pytest.mark.parametrize("r,n", [(1000, 40), (70, 130), (4090, 256)])
+def test_row_counts_that_are_not_a_multiple_of_16_use_zero_padded_copies(r, n):
+    """The Gram objective is given the zero-padded row count (device.row_padded); zero rows change neither 2A'A, 2A'c nor c'c
+    (c'c stays the exact left-to-right sum: adding 0.0 is the identity), so the result equals numpy on the unpadded data."""
+    from parametron_jl_amd.device import row_padded
+    from parametron_jl_amd.moi import _gram_rows
+    rng = np.random.default_rng(r)
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    x = [Variable(model) for _ in range(n)]
+    Av, bv = rng.random((r, n)), rng.random(r)
+    A = P.Parameter(model, val=np.asfortranarray(Av))
+    b = P.Parameter(model, val=bv)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    for _ in range(2):
+        P.solve(model)
+        assert A._dev.lda >= row_padded(r) and _gram_rows(model.objective.expr.gram_candidate) == row_padded(r) != r
+        f = model.objective.f
+        iu = np.triu_indices(n)
+        np.testing.assert_allclose(f.quadratic_terms["coeff"], (2 * Av.T @ Av)[iu], rtol=1e-12)
+        np.testing.assert_allclose(f.affine_terms["coeff"], -2 * Av.T @ bv, rtol=1e-12)
+        seq = 0.0
+        for v in 0.0 - bv:
+            seq = seq + v * v
+        assert f.constant == seq
+        Av[...] = rng.random((r, n)); A.val[...] = Av; bv[...] = rng.random(r)      # overwrite: the padding must stay zero
