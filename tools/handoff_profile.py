@@ -1,5 +1,6 @@
+"""Per-kernel times and the steady solve! time of config 2 with the device hand-off (Model(..., handoff="device")): python tools/handoff_profile.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import parametron_jl_amd as P
 n, r, m = 4096, 4096, 512
 model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", handoff="device")
