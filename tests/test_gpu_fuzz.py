@@ -1,0 +1,82 @@
+"""-m gpu: randomised shapes through the Gram node (stream-K split, whole-tile and bounds-checked paths, padded / odd leading
+dimensions, 8-byte-misaligned bases) and the dense affine nodes, against numpy — a fixed seed, so failures reproduce."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _shapes(seed, count, rmax, nmax):
+    rng = np.random.default_rng(seed)
+    special = [(1, 1), (16, 128), (256, 128), (257, 129), (512, 256), (300, 127), (15, 300), (272, 384)]
+    rnd = [(int(rng.integers(1, rmax)), int(rng.integers(1, nmax))) for _ in range(count - len(special))]
+    return special + rnd
+
+
+@pytest.mark.parametrize("rows,n", _shapes(11, 28, 700, 420))
+def test_gram_node_random_shapes(rows, n):
+    import gpu_util as g
+    rng = np.random.default_rng(rows * 1000 + n)
+    lda = rows + int(rng.integers(0, 5))                                   # odd / even / padded leading dimensions
+    shift = int(rng.integers(0, 2))                                        # 8-byte misaligned base: the 16-byte load path must not be taken
+    A = rng.random((rows, n)) - 0.4
+    b = rng.random(rows) - 0.5
+    buf = np.zeros(shift + lda * n)
+    buf[shift:].reshape(n, lda)[:, :rows] = A.T
+    dbuf = g.to_dev(buf)
+    dA = dbuf[shift:]
+    db, xvar = g.to_dev(b), g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    vm_h = np.arange(1, n + 1, dtype=np.int64) + 3
+    vm = g.to_dev(vm_h)
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(g.lib().pmt_quad_gram_workspace_bytes(rows, n) // 8)
+    sign = int(rng.choice([-1, 1]))
+    g.call("pmt_quad_gram_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), sign, 1, g.ptr(vm), g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), g.stream())
+    q = g.terms_to_host(oq, nq, g.QT)
+    iu = np.triu_indices(n)
+    G = 2 * A.T @ A
+    scale = 2 * np.abs(A).T @ np.abs(A)                                    # signed data: tolerance relative to sum |a||b|
+    assert np.array_equal(q["row"], vm_h[iu[0]]) and np.array_equal(q["col"], vm_h[iu[1]])
+    assert np.all(np.abs(q["coeff"] - G[iu]) <= 1e-12 * scale[iu] + 1e-300)
+    l = g.terms_to_host(ol, n, g.LT)
+    c = 0.0 + sign * b
+    assert np.array_equal(l["var"], vm_h)
+    assert np.all(np.abs(l["coeff"] - 2 * A.T @ c) <= 1e-12 * (2 * np.abs(A).T @ np.abs(c)) + 1e-300)
+    seq = 0.0
+    for v in (0.0 + b if sign > 0 else 0.0 - b):
+        seq = seq + v * v
+    assert g.f64_to_host(oc, 1)[0] == seq
+    # the CSC epilogue writes the same coefficients
+    px = g.empty_f64(nq)
+    g.call("pmt_quad_gram_csc_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), sign, g.ptr(vm), 1.0, g.ptr(px), None, g.ptr(ol), g.ptr(oc),
+           g.ptr(ws), g.stream())
+    want = np.empty(nq)
+    want[iu[1] * (iu[1] + 1) // 2 + iu[0]] = q["coeff"]
+    assert g.same_bits(g.f64_to_host(px, nq), want)
+
+
+@pytest.mark.parametrize("rows,n", _shapes(12, 20, 300, 300))
+def test_affine_nodes_random_shapes(rows, n):
+    import gpu_util as g
+    rng = np.random.default_rng(rows * 977 + n)
+    lda = rows + int(rng.integers(0, 4))
+    A = rng.random((rows, n)) - 0.5
+    b = rng.random(rows)
+    buf = np.zeros(lda * n); buf.reshape(n, lda)[:, :rows] = A.T
+    dA, db = g.to_dev(buf), g.to_dev(b)
+    xv = rng.permutation(n).astype(np.int64) + 1
+    vm_h = rng.permutation(n).astype(np.int64) + 1
+    xvar, vm = g.to_dev(xv), g.to_dev(vm_h)
+    lt, c1 = g.empty_terms(rows * n, g.LT), g.empty_f64(rows)
+    vat, c2 = g.empty_terms(rows * n, g.VAT), g.empty_f64(rows)
+    g.call("pmt_affine_assemble_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), 1, g.ptr(lt), g.ptr(c1), g.stream())
+    g.call("pmt_affine_pack_vector_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), -1, g.ptr(vm), 5, g.ptr(vat), g.ptr(c2), g.stream())
+    t = g.terms_to_host(lt, rows * n, g.LT)
+    assert g.same_bits(t["coeff"].reshape(rows, n), A) and np.array_equal(t["var"].reshape(rows, n), np.tile(xv, (rows, 1)))
+    assert g.same_bits(g.f64_to_host(c1, rows), 0.0 + b)
+    v = g.terms_to_host(vat, rows * n, g.VAT)
+    assert g.same_bits(v["coeff"].reshape(rows, n), A) and np.array_equal(v["var"].reshape(rows, n), np.tile(vm_h[xv - 1], (rows, 1)))
+    assert np.array_equal(v["out"].reshape(rows, n), np.tile(np.arange(6, rows + 6)[:, None], (1, n)))
+    assert g.same_bits(g.f64_to_host(c2, rows), 0.0 - b)
