@@ -80,3 +80,43 @@ def test_affine_nodes_random_shapes(rows, n):
     assert g.same_bits(v["coeff"].reshape(rows, n), A) and np.array_equal(v["var"].reshape(rows, n), np.tile(vm_h[xv - 1], (rows, 1)))
     assert np.array_equal(v["out"].reshape(rows, n), np.tile(np.arange(6, rows + 6)[:, None], (1, n)))
     assert g.same_bits(g.f64_to_host(c2, rows), 0.0 - b)
+
+
+def test_config2_full_size_checksums():
+    """BASELINE config 2 at full size (n = r = 4096, m = 512) through size-independent properties: the coefficient checksum of the
+    canonical objective is ||A 1||^2 + ||A||_F^2 (sum over j <= k of 2 (A'A)_jk), that of q is -2 (A 1).b, index checksums are closed
+    forms, and the constraint block carries C's entries row-major.  Reference sums are computed by torch in fp64 on the device."""
+    import ctypes as C
+    import gpu_util as g
+    n = r = 4096
+    m = 512
+    s = g.stream()
+    A, b, Cm, d = g.empty_f64(r * n), g.empty_f64(r), g.empty_f64(m * n), g.empty_f64(m)
+    for buf, cnt, seed, sc in ((A, r * n, 1, 1.0), (b, r, 2, 1.0), (Cm, m * n, 3, 1.0), (d, m, 4, 2.0)):
+        g.call("pmt_fill_uniform_f64", g.ptr(buf), cnt, C.c_uint64(seed), sc, s)
+    xvar = torch.arange(1, n + 1, dtype=torch.int64, device=g.DEV)
+    vm = xvar + 7
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(g.lib().pmt_quad_gram_workspace_bytes(r, n) // 8)
+    g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, 1, g.ptr(vm), g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), s)
+    vt, vc = g.empty_terms(m * n, g.VAT), g.empty_f64(m)
+    g.call("pmt_affine_pack_vector_f64", g.ptr(Cm), m, m, n, g.ptr(xvar), g.ptr(d), -1, g.ptr(vm), 0, g.ptr(vt), g.ptr(vc), s)
+    torch.cuda.synchronize()
+    Am = A.view(n, r).t()                                                  # (r, n) view of the column-major buffer
+    q3 = oq.view(nq, 3)
+    coeff = q3[:, 0].view(torch.float64)
+    row1 = Am.sum(dim=1)
+    want = float((row1 * row1).sum() + (Am * Am).sum())
+    assert float(coeff.sum()) == pytest.approx(want, rel=1e-11)
+    assert int(q3[:, 1].sum()) == sum((7 + j + 1) * (n - j) for j in range(n))            # row index vm[j] appears n - j times
+    assert int(q3[:, 2].sum()) == sum((7 + k + 1) * (k + 1) for k in range(n))            # col index vm[k] appears k + 1 times
+    l2 = ol.view(n, 2)
+    assert float(l2[:, 0].view(torch.float64).sum()) == pytest.approx(float(-2 * (row1 * b).sum()), rel=1e-11)
+    assert torch.equal(l2[:, 1], vm)
+    assert float(oc.item()) == pytest.approx(float((b * b).sum()), rel=1e-13)
+    v3 = vt.view(m * n, 3)
+    assert torch.equal(v3[:, 1].view(torch.float64).view(m, n), Cm.view(n, m).t())        # bit for bit, row-major
+    assert torch.equal(v3[:, 0].view(m, n), torch.arange(1, m + 1, device=g.DEV).view(m, 1).expand(m, n))
+    assert torch.equal(v3[:, 2].view(m, n), vm.view(1, n).expand(m, n))
+    assert torch.equal(vc, 0.0 - d)
