@@ -96,3 +96,26 @@ def test_batch_small_and_general_paths_agree_with_numpy(n, r, m):
         assert slab[off["const"]] == seq                                   # left-to-right sum, bit for bit
         Ch = wl.Cm[inst * m * n:(inst + 1) * m * n].cpu().numpy().reshape(n, m).T
         assert np.array_equal(slab[off["C"]:off["C"] + m * n].reshape(m, n), Ch)
+
+
+def test_config4_full_size_checksums():
+    """BASELINE config 4 at full size (8192 instances of n = r = 128, m = 16): per-instance coefficient checksums in closed form
+    (sum of Q = ||A 1||^2 + ||A||_F^2, sum of q = -2 (A 1).b, const = b.b), the constraint block bit for bit — vectorised in torch."""
+    from parametron_jl_amd import batch
+    total, n, r, m = 8192, 128, 128, 16
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.compute()
+    torch.cuda.synchronize()
+    off, L = batch.slab_layout(n, m)
+    nq = n * (n + 1) // 2
+    A = wl.A.view(total, n, r).transpose(1, 2)                             # (B, r, n): column-major per instance
+    b = wl.b.view(total, r)
+    row1 = A.sum(dim=2)
+    want_q = (row1 * row1).sum(dim=1) + (A * A).sum(dim=(1, 2))
+    got = wl.local
+    torch.testing.assert_close(got[:, :nq].sum(dim=1), want_q, rtol=1e-11, atol=0)
+    torch.testing.assert_close(got[:, off["q"]:off["q"] + n].sum(dim=1), -2 * (row1 * b).sum(dim=1), rtol=1e-11, atol=0)
+    torch.testing.assert_close(got[:, off["const"]], (b * b).sum(dim=1), rtol=1e-13, atol=0)
+    Cm = wl.Cm.view(total, n, m).transpose(1, 2)                           # (B, m, n)
+    assert torch.equal(got[:, off["C"]:off["C"] + m * n].view(total, m, n), Cm)
+    assert torch.equal(got[:, off["dconst"]:], 0.0 - wl.d.view(total, m))
