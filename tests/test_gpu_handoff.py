@@ -299,3 +299,41 @@ def test_handoff_with_constant_objective_and_maximize_quadratic():
         assert got["u"][0] == 2.0 and got["l"][0] == -1e20 and np.array_equal(got["l"][1:], lo()) and np.all(got["u"][1:] == 1e20)
         P.solve(model)
         qp.refresh()
+
+
+def test_config2_full_size_device_handoff_properties():
+    """Config 2 at full size with the device hand-off: P's CSC values are the Gram coefficients at k(k+1)/2 + j (checksum and sampled
+    entries against torch), the CSC structure is the dense upper triangle shifted by the optimizer's index offset, A's CSC values are
+    C column by column bit for bit, l = u = d."""
+    n, r, m = 4096, 4096, 512
+    off = 3
+    model = P.Model(P.MockOptimizer(variable_offset=off), quadratic_mode="canonical", handoff="device")
+    x = [Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model, advance=False)
+    b = P.DeviceUniformParameter((r,), 2, model, advance=False)
+    Cm = P.DeviceUniformParameter((m, n), 3, model, advance=False)
+    d = P.DeviceUniformParameter((m,), 4, model, scale=2.0, advance=False)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, Cm * x == d)
+    P.solve(model)
+    qp = model.device_qp
+    assert model.objective.mode == "canonical-csc" and qp.nvars == n + off and qp.P.nnz == n * (n + 1) // 2 and qp.A.nnz == m * n
+    got = qp.fetch()
+    px, pi, pp = got["P"]
+    assert pp[:off + 1].tolist() == [0] * (off + 1) and np.array_equal(np.diff(pp[off:]), np.arange(1, n + 1))
+    assert pi[:6].tolist() == [off, off, off + 1, off, off + 1, off + 2] and pi[-1] == n + off - 1
+    Ah, bh, Ch, dh = A(), b(), Cm(), d()
+    row1 = Ah.sum(axis=1)
+    assert px.sum() == pytest.approx(float(row1 @ row1 + (Ah * Ah).sum()), rel=1e-11)
+    rng = np.random.default_rng(0)
+    ks = rng.integers(0, n, 300); js = (rng.random(300) * (ks + 1)).astype(np.int64)
+    want = 2 * np.einsum("ij,ij->j", Ah[:, js], Ah[:, ks])
+    np.testing.assert_allclose(px[ks * (ks + 1) // 2 + js], want, rtol=1e-12)
+    np.testing.assert_allclose(got["q"][off:], -2 * Ah.T @ bh, rtol=1e-12)
+    assert np.all(got["q"][:off] == 0.0)
+    ax, ai, ap = got["A"]
+    assert np.array_equal(ap[off:], np.arange(0, m * n + 1, m)) and np.array_equal(ai[:m], np.arange(m))
+    assert np.array_equal(ax.reshape(n, m).T, Ch)                          # column by column = C's own column-major order
+    assert np.array_equal(got["l"], dh) and np.array_equal(got["u"], dh)
+    model.close()
