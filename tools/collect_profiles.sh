@@ -26,6 +26,18 @@ for k in f:
     if "pmt::" in k and k in w:
         res[k] = {"read_bytes": 2 * 1024 * sum(f[k]) / len(f[k]), "write_bytes": 1024 * sum(w[k]) / len(w[k]), "launches": len(f[k])}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
+# per-launch durations of the timed region only (the stats CSV averages over spin-up and warm-up launches too)
+tr = sorted(csv.DictReader(open(glob.glob(out + "/stats/*/*kernel_trace.csv")[0])), key=lambda r: int(r["Start_Timestamp"]))
+bu = json.load(open(out + "/bench_under_rocprof.json"))
+lines = ["rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`, per-launch durations split at the timed region (last %d launches):" % bu["steps"]]
+for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if name in r["Kernel_Name"]]
+    last = d[-bu["steps"]:]
+    lines.append("%-28s %3d launches; timed region: avg %.1f us, min %.1f, max %.1f; before it: avg %.1f us" %
+                 (name, len(d), sum(last) / len(last), min(last), max(last), sum(d[:-len(last)]) / max(1, len(d) - len(last))))
+lines.append("bench.py's HIP-event average for the dominant kernel in the same run: %.1f us" % (bu["roofline"]["avg_ms"] * 1e3))
+open(out + "/rocprofv3_timed_region.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
 b = json.load(open(out + "/bench.json"))
 print("bench:", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], b["roofline_affine"]["achieved"], b["roofline_affine"]["frac"])
 print(open(glob.glob(out + "/stats/*/*kernel_stats.csv")[0]).read()[:1200])
