@@ -230,10 +230,15 @@ static int validate_affine(const double *A, int64_t lda, int64_t rows, int64_t c
     return PMT_OK;
 }
 
+// term buffers are write-once streams: non-temporal stores (tuning builds can switch them off with PMT_NONTEMPORAL=0)
 static bool env_nt() {
+#ifdef PMT_TUNING
     static int v = -1;
     if (v < 0) { const char *e = getenv("PMT_NONTEMPORAL"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
+#else
+    return true;
+#endif
 }
 
 template <int MODE>

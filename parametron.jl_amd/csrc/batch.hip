@@ -13,11 +13,8 @@ namespace pmt {
 
 int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride, hipStream_t s);
-bool batch_small_enabled();
 int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
-                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride,
-                       const double *Cm, int64_t m, const double *d, int sign_d, double *out_C, double *out_d, hipStream_t s);
-int launch_batch_const(const double *b, int64_t strideb, int64_t rows, int sign, int64_t B, double *out_const, int64_t out_stride, hipStream_t s);
+                       int64_t B, double *out, int64_t out_stride, const double *Cm, int64_t m, const double *d, int sign_d, hipStream_t s);
 
 // out[inst][row*cols + col] = C_inst[row, col] (column-major in, row-major out); 32x32 LDS tiles
 __global__ __launch_bounds__(256) void batch_transpose_kernel(const double *__restrict__ src, int64_t rows, int64_t cols, int64_t stride_src,
@@ -96,12 +93,9 @@ extern "C" int pmt_batch_lsq_coeffs_f64(const double *A, const double *b, const 
     PMT_REQUIRE(out && (n * r == 0 || A) && (r == 0 || b) && (m * n == 0 || Cm) && (m == 0 || d), PMT_INVALID_ARGUMENT, "batch_lsq: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         const int64_t nq = n * (n + 1) / 2;
-        if (n > 0 && n <= 128 && batch_small_enabled()) {
-            // small instances: objective and constraint block of an instance from one workgroup (batch_small.hip)
-            int rc = launch_batch_small(A, r, r, n, r * n, b, r, sign_b, B, out, out + nq, out + nq + n, out_stride, Cm, m, d, sign_d,
-                                        out + nq + n + 1, out + nq + n + 1 + m * n, s);
-            if (rc) return rc;
-            return launch_batch_const(b, r, r, sign_b, B, out + nq + n, out_stride, s);
+        if (n > 0 && n <= 128) {
+            // small instances: the whole slab of an instance from one persistent workgroup (batch_small.hip)
+            return launch_batch_small(A, r, r, n, r * n, b, r, sign_b, B, out, out_stride, Cm, m, d, sign_d, s);
         }
         if (n > 0) {
             int rc = launch_batch_gram(A, r, r, n, r * n, b, r, sign_b, B, out, out + nq, out + nq + n, out_stride, s);

@@ -468,26 +468,9 @@ __global__ void batch_const_kernel(const double *__restrict__ b, int64_t strideb
     out[inst * out_stride] = acc;
 }
 
-int launch_batch_const(const double *b, int64_t strideb, int64_t rows, int sign, int64_t B, double *out_const, int64_t out_stride, hipStream_t s) {
-    PMT_LAUNCH(batch_const_kernel, dim3((unsigned)cdiv(B, 64)), dim3(64), 0, s, b, strideb, rows, sign, B, out_const, out_stride);
-    return check_launch("batch_const_kernel");
-}
-
-bool batch_small_enabled();
-int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
-                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride,
-                       const double *Cm, int64_t m, const double *d, int sign_d, double *out_C, double *out_d, hipStream_t s);
-int launch_batch_const(const double *b, int64_t strideb, int64_t rows, int sign, int64_t B, double *out_const, int64_t out_stride, hipStream_t s);
-
 int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, int64_t strideA, const double *b, int64_t strideb, int sign,
                       int64_t B, double *out_q, double *out_lin, double *out_const, int64_t out_stride, hipStream_t s) {
-    // instances of at most 128 columns: one workgroup per instance, everything from one pass over A (batch_small.hip)
-    if (cols <= 128 && batch_small_enabled()) {
-        int rc = launch_batch_small(A, lda, rows, cols, strideA, b, strideb, sign, B, out_q, out_lin, out_const, out_stride,
-                                    nullptr, 0, nullptr, 0, nullptr, nullptr, s);
-        if (rc) return rc;
-        return launch_batch_const(b, strideb, rows, sign, B, out_const, out_stride, s);
-    }
+    // (instances of at most 128 columns take batch_small.hip; the caller decides)
     BatchGramArgs bg;
     bg.A = A; bg.lda = lda; bg.rows = rows; bg.cols = cols; bg.strideA = strideA; bg.out = out_q; bg.out_stride = out_stride;
     bg.ntiles = (int)cdiv(cols, ST);
@@ -624,10 +607,14 @@ size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
     return (size_t)MAXG * 2 * SLOT * sizeof(double);
 }
 
+// Tuning builds only (-DPMT_TUNING, tools/): kernel variant / ablation / grid size from the environment.  The shipped library reads
+// no environment variable: its results cannot be changed from outside.
+#ifdef PMT_TUNING
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+#endif
 
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s) {
@@ -639,9 +626,13 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;
     // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16;
     //          2 = wg512 with BK 32
+#ifdef PMT_TUNING
     static const int variant = env_int("PMT_GRAM_SK_VARIANT", 1);   // measured equal within noise (profiles/r01b_gram_variants.txt)
     static const int abl = env_int("PMT_GRAM_SK_ABLATE", 0);
     static const int gdef = env_int("PMT_GRAM_SK_BLOCKS", 0);
+#else
+    constexpr int variant = 1, gdef = 0;
+#endif
     const int gwant = gdef > 0 ? gdef : (variant == 0 ? 512 : 256);
     g.G = (int)std::min<int64_t>(T * g.nchunk, std::min(gwant, MAXG));
     g.tfull = (int)(T / g.G);                         // at n = r = 4096: 528 tiles = 2 per workgroup + 16 split 16 ways
@@ -651,6 +642,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.ws = reinterpret_cast<double *>(workspace);
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
+#ifdef PMT_TUNING
 #define SK_LAUNCH(TN, BK, WPS)                                                                                              \
     do {                                                                                                                    \
         if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
@@ -661,7 +653,12 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     if (variant == 0) SK_LAUNCH(4, 16, 2);
     else if (variant == 1) SK_LAUNCH(2, 16, PMT_SK_WPS);
     else SK_LAUNCH(2, 32, 2);
+#else
+    PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
+#endif
+#ifdef PMT_TUNING
 #undef SK_LAUNCH
+#endif
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
     if (g.nchunk > 1 && R > 0) {

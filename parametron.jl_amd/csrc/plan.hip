@@ -42,6 +42,42 @@ namespace pmt {
 static std::mutex g_mu;
 static std::unordered_map<void *, pmt_plan *> g_recording;   // recording handle -> plan
 
+// the plan whose recording handle `stream` is, or null for an ordinary HIP stream
+static pmt_plan *recording_plan(void *stream) {
+    if (!stream) return nullptr;
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_recording.find(stream);
+    return it != g_recording.end() ? it->second : nullptr;
+}
+
+// Contract check of pmt_quad_gram_f64 / _csc: the canonical order of the output IS the position order, so `xvar` must be strictly
+// increasing (include/parametron_hip.h).  The indices are static, so when the call is RECORDED into a plan they are read back and
+// checked once, at record time (setup, not the solve path); an immediate call is checked only in -DPMT_DEBUG_CHECKS builds (it costs a
+// stream synchronisation per call).
+int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream) {
+    if (n < 2 || !xvar_dev) return PMT_OK;
+    pmt_plan *plan = recording_plan(stream);
+    hipStream_t s;
+    if (plan) {
+        s = plan->stream;
+    } else {
+#ifdef PMT_DEBUG_CHECKS
+        s = reinterpret_cast<hipStream_t>(stream);
+#else
+        return PMT_OK;
+#endif
+    }
+    std::vector<int64_t> h((size_t)n);
+    PMT_HIP_CHECK(hipStreamSynchronize(s));                   // the indices may still be on their way (asynchronous upload on this stream)
+    PMT_HIP_CHECK(hipMemcpy(h.data(), xvar_dev, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i + 1 < n; ++i)
+        if (h[(size_t)i] >= h[(size_t)i + 1])
+            return fail(PMT_INVALID_ARGUMENT, "quad_gram: xvar must be strictly increasing (xvar[" + std::to_string(i) + "] = " +
+                        std::to_string(h[(size_t)i]) + " >= xvar[" + std::to_string(i + 1) + "] = " + std::to_string(h[(size_t)i + 1]) +
+                        "); use the literal objective or canonicalize on the device for other variable orders");
+    return PMT_OK;
+}
+
 int dispatch(void *stream, Launch launch) {
     if (stream) {
         pmt_plan *plan = nullptr;
@@ -226,6 +262,7 @@ extern "C" int pmt_host_free(void *host_ptr) {
 
 extern "C" int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_upload: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(device_dst && host_src, PMT_INVALID_ARGUMENT, "plan_upload: null pointer");
     PMT_HIP_CHECK(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, plan->stream));
@@ -234,6 +271,7 @@ extern "C" int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *hos
 
 extern "C" int pmt_plan_zero(pmt_plan *plan, void *device_dst, size_t bytes) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_zero: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(device_dst, PMT_INVALID_ARGUMENT, "plan_zero: null pointer");
     PMT_HIP_CHECK(hipMemsetAsync(device_dst, 0, bytes, plan->stream));
@@ -242,6 +280,7 @@ extern "C" int pmt_plan_zero(pmt_plan *plan, void *device_dst, size_t bytes) {
 
 extern "C" int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(host_dst && device_src, PMT_INVALID_ARGUMENT, "plan_fetch: null pointer");
     PMT_HIP_CHECK(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, plan->stream));
@@ -252,6 +291,7 @@ extern "C" int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device
 extern "C" int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes,
                                   size_t height) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_upload_2d: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     if (width_bytes == 0 || height == 0) return PMT_OK;
     PMT_REQUIRE(device_dst && host_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_upload_2d: bad argument");
     PMT_HIP_CHECK(hipMemcpy2DAsync(device_dst, dst_pitch, host_src, src_pitch, width_bytes, height, hipMemcpyHostToDevice, plan->stream));
@@ -261,6 +301,7 @@ extern "C" int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_p
 extern "C" int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
                                  size_t height) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch_2d: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     if (width_bytes == 0 || height == 0) return PMT_OK;
     PMT_REQUIRE(host_dst && device_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_fetch_2d: bad argument");
     PMT_HIP_CHECK(hipMemcpy2DAsync(host_dst, dst_pitch, device_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, plan->stream));
@@ -269,6 +310,7 @@ extern "C" int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitc
 
 extern "C" int pmt_plan_synchronize(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_synchronize: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
     return PMT_OK;
 }
@@ -299,6 +341,7 @@ static int replay(pmt_plan *plan, hipStream_t s) {
 extern "C" int pmt_plan_update(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_update: null plan");
     PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));      // the tape's launches go to this plan's device whatever the caller's current device is
     if (plan->graph_exec) {
         PMT_HIP_CHECK(hipGraphLaunch(plan->graph_exec, plan->stream));
         return PMT_OK;

@@ -157,6 +157,30 @@ def vcat(*vs):
     return out
 
 
+def _is_numeric(v):
+    """a plain number array (matrix or vector of numbers), not a scalar"""
+    if isinstance(v, np.ndarray):
+        return v.dtype != object and v.ndim >= 1
+    return isinstance(v, (list, tuple)) and len(v) > 0 and elem_kind(v) == "num"
+
+
+def _num_array(v):
+    return np.asarray(v, dtype=np.float64)
+
+
+def _matmul(a, b):
+    """Julia's `*` on number arrays: the matrix product, with Julia's errors (MethodError for vector*vector)."""
+    if a.ndim == 1 and b.ndim == 1:
+        raise ArgumentError("no method matching *(::Vector{Float64}, ::Vector{Float64}); use dot(x, y) or x' * y")
+    if a.ndim == 1:                                     # Vector * Matrix: only the outer product with a one-row matrix exists
+        if b.shape[0] != 1:
+            raise DimensionMismatch("vector * matrix: the matrix must have one row, has %d" % b.shape[0])
+        return np.outer(a, b[0])
+    if a.shape[1] != b.shape[0]:
+        raise DimensionMismatch("A has dimensions %r but B has dimensions %r" % (a.shape, b.shape))
+    return a @ b
+
+
 def apply(f, *args):
     """Evaluate a Parameter-free expression immediately (src/lazyexpression.jl:189-192)."""
     if f == "*":
@@ -165,16 +189,25 @@ def apply(f, *args):
         a, b = args
         if isinstance(a, Transpose):
             if isinstance(b, np.ndarray) and b.ndim == 2:
+                if _is_numeric(a.parent):                     # numbers: x' * Q is the row vector (Q' x)'
+                    return Transpose(_matmul(np.ascontiguousarray(b.T), _num_array(a.parent)))
                 return _RowTimesMatrix(a.parent, b)
             return vecdot(a.parent, b)
         if isinstance(a, _RowTimesMatrix):
             return bilinearmul(a.Q, a.x, b)
+        na, nb = _is_numeric(a), _is_numeric(b)
+        if na and nb:
+            # plain numbers on both sides: Julia's `*` is the MATRIX product (never numpy's elementwise broadcast) —
+            # Matrix*Matrix, Matrix*Vector; Vector*Vector has no method (the generic rule src/lazyexpression.jl:198 would throw)
+            return _matmul(_num_array(a), _num_array(b))
         if isinstance(a, np.ndarray) and a.ndim == 2 and is_vector(b):
             return matvecmul(a, b)
         if _isnum(a) and is_vector(b):
             return scale(a, b)
         if _isnum(b) and is_vector(a):
             return scale(b, a)
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+            raise ArgumentError("no method matching *(%s, %s)" % (type(a).__name__, type(b).__name__))
         return a * b
     if f in ("+", "-"):
         a, b = args

@@ -189,6 +189,10 @@ def const_device_value(ctx, x):
         d = DMat(ctx, *m.shape); _upload_value(ctx, d, m); return d
     if k == "var":
         return DVars(ctx, [x])
+    if k == "lt":                                       # LinearTerm constant (2 * x): an AffineFunction of one term, copyto! :420
+        return const_device_value(ctx, AffineFunction.of(x))
+    if k == "qt":                                       # QuadraticTerm constant (x^2, 3 * x * y): copyto! :432-434
+        return const_device_value(ctx, QuadraticFunction.of(x))
     if k == "varvec":
         return DVars(ctx, list(x))
     if k == "aff":
@@ -588,6 +592,16 @@ def _rule_mul_scalar(model, ctx, a, b):                                         
     ins = _inputs(a, b)
     if isinstance(da, DNum) or isinstance(db, DNum):
         s, f = (da, db) if isinstance(da, DNum) else (db, da)
+        if isinstance(f, DVars) and f.n == 1:
+            # Number * Variable -> LinearTerm (src/functions.jl:114-116): no `optimize` rule of its own in the reference (the generic
+            # rule :198 calls `*` out of place, isbits result); on the device an AffineFunction of one term, constant 0
+            out = DAff(ctx, 1)
+
+            def emit(c):
+                c.call("pmt_scale_vars_f64", P(f.buf), 1, P(s.buf), 0.0, P(out.terms))
+            return DeviceNode(model, "*", ins, out, emit)
+        if isinstance(f, DNum):
+            raise ArgumentError("number * number is plain data: compute it inside a Parameter callback")
         if isinstance(f, DAff):
             out = DAff(ctx, f.nterms)
 
@@ -759,6 +773,37 @@ def _arg_kind(a):
     return kind_of(a)
 
 
+def _host_value(a):
+    """Host value of an argument of a Parameter-only (plain data) expression.  A DeviceNode argument (only adjoint nodes of matrix
+    Parameters produce plain data) is EVALUATED, not just fetched: its buffer is written by its own emit, which nobody else runs when
+    the node feeds nothing but derived data (fetching alone returned zeros on the first call and the previous solve's value later)."""
+    if isinstance(a, (Parameter, DeviceNode)):
+        return a()
+    if isinstance(a, Transpose) and _is_lazy(a.parent):
+        return Transpose(_host_value(a.parent))
+    return a
+
+
+def _source_parameters(args):
+    """The Parameters a derived value depends on, through DeviceNode arguments too (DerivedParameter follows their versions)."""
+    out, seen = [], set()
+
+    def visit(a):
+        if id(a) in seen:
+            return
+        seen.add(id(a))
+        if isinstance(a, Parameter):
+            out.append(a)
+        elif isinstance(a, DeviceNode):
+            for i in a.inputs:
+                visit(i)
+        elif isinstance(a, Transpose):
+            visit(a.parent)
+    for a in args:
+        visit(a)
+    return out
+
+
 def lazy(f, *args):
     """optimize_toplevel(LazyExpression(f, args...)) — src/lazyexpression.jl:184-193."""
     if not any(_is_lazy(a) or isinstance(a, _LazyRowTimesMatrix) or (isinstance(a, Transpose) and _is_lazy(a.parent)) for a in args):
@@ -772,13 +817,11 @@ def lazy(f, *args):
         fn, fargs = f, args
 
         def call():
-            return fn(*[a() if isinstance(a, Parameter) else (fetch_value(a.model.device(), a.out) if isinstance(a, DeviceNode) else a)
-                        for a in fargs])
-        return DerivedParameter(call, args, model)
+            return fn(*[_host_value(a) for a in fargs])
+        return DerivedParameter(call, _source_parameters(args), model)
     if f == "getproperty":                                                       # rule :300-302 (GetField): p.x as plain derived data
         obj, name = args
-        return DerivedParameter(lambda: getattr(obj() if isinstance(obj, Parameter) else fetch_value(obj.model.device(), obj.out), name),
-                                [obj], model)
+        return DerivedParameter(lambda: getattr(_host_value(obj), name), _source_parameters([obj]), model)
     kinds = [_arg_kind(a) for a in args]
     if f in ("+", "-") and len(args) > 2 and f == "+":                           # rule :234-236
         return lazy("+", lazy("+", args[0], args[1]), *args[2:])
@@ -789,10 +832,8 @@ def lazy(f, *args):
         host_args = args
 
         def recompute():
-            vals = [a() if isinstance(a, Parameter) else (fetch_value(a.model.device(), a.out) if isinstance(a, DeviceNode) else a)
-                    for a in host_args]
-            return hostops.apply(f, *vals)
-        return DerivedParameter(recompute, args, model)
+            return hostops.apply(f, *[_host_value(a) for a in host_args])
+        return DerivedParameter(recompute, _source_parameters(args), model)
     ctx = model.device()
     if f == "*":
         if len(args) == 3 and kinds[0] == "tvarvec":

@@ -102,3 +102,29 @@ def test_julia_binding_stub_matches_the_header():
         types = src[m.end():i - 1].strip().rstrip(",")
         ntypes = 0 if not types else len([t for t in re.split(r",(?![^{]*})", types) if t.strip()])
         assert ntypes == decls[name], "%s: %d argument types in the Julia stub, %d parameters in the header" % (name, ntypes, decls[name])
+
+
+def test_shipped_library_reads_no_environment_switches():
+    """Tuning / ablation switches (PMT_GRAM_SK_ABLATE & co. could silently corrupt results in round 1) exist only in -DPMT_TUNING
+    builds: the shipped library contains no PMT_* environment name and does not import getenv for them."""
+    path = os.path.join(ROOT, "parametron.jl_amd", "lib", "libparametron_hip.so")
+    if not os.path.exists(path):
+        pytest.skip("library not built")
+    blob = open(path, "rb").read()
+    names = set(re.findall(rb"PMT_[A-Z_]{3,}", blob))
+    assert not names, "environment switch names in the shipped library: %r" % sorted(names)
+    for src in os.listdir(os.path.join(ROOT, "parametron.jl_amd", "csrc")):
+        if src.endswith((".hip", ".h")):
+            text = open(os.path.join(ROOT, "parametron.jl_amd", "csrc", src)).read()
+            # every getenv must sit inside an #ifdef PMT_TUNING block
+            depth_tuning, stack = 0, []
+            for line in text.splitlines():
+                t = line.strip()
+                if t.startswith(("#ifdef", "#ifndef", "#if ")):
+                    stack.append("PMT_TUNING" in t and t.startswith("#ifdef"))
+                elif t.startswith("#else") and stack:
+                    stack[-1] = False
+                elif t.startswith("#endif") and stack:
+                    stack.pop()
+                if "getenv(" in line and not t.startswith("//"):
+                    assert any(stack), "%s reads the environment outside #ifdef PMT_TUNING: %s" % (src, t)

@@ -72,10 +72,11 @@ def test_batch_sharding_is_data_independent():
     assert torch.equal(torch.cat(parts), whole.local)
 
 
-@pytest.mark.parametrize("n,r,m", [(128, 128, 16), (128, 70, 3), (100, 33, 5), (16, 1, 1), (128, 200, 2), (200, 64, 4)])
+@pytest.mark.parametrize("n,r,m", [(128, 128, 16), (128, 70, 3), (100, 33, 5), (16, 1, 1), (128, 200, 2), (200, 64, 4), (128, 64, 40), (64, 50, 40), (127, 31, 17)])
 def test_batch_small_and_general_paths_agree_with_numpy(n, r, m):
-    """Ragged shapes: fewer than 128 columns (zero padded in LDS), row counts that are not a multiple of the 64-row chunk, odd
-    leading dimensions (unaligned loads), and n > 128 (general tiled path)."""
+    """Ragged shapes: fewer than 128 columns (zero padded in LDS), row counts that are not a multiple of the 32-row chunk (1 to 7
+    chunks per instance), odd leading dimensions (unaligned loads), constraint blocks too large for the register prefetch (m*n > 2048)
+    or for the LDS staging buffer (written straight to HBM), and n > 128 (general tiled path)."""
     import gpu_util as g
     from parametron_jl_amd import batch
     total = 5
@@ -119,3 +120,29 @@ def test_config4_full_size_checksums():
     Cm = wl.Cm.view(total, n, m).transpose(1, 2)                           # (B, m, n)
     assert torch.equal(got[:, off["C"]:off["C"] + m * n].view(total, m, n), Cm)
     assert torch.equal(got[:, off["dconst"]:], 0.0 - wl.d.view(total, m))
+
+
+def test_batch_many_instances_per_workgroup():
+    """More than 64 instances per persistent workgroup (one per CU): the c'c chains are computed 64 instances at a time by the lanes of
+    one wave; every instance's slab must still be its own (const bit for bit, Q/q within 1e-12, C exactly)."""
+    from parametron_jl_amd import batch
+    total, n, r, m = 256 * 64 + 300, 8, 5, 1
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.compute()
+    torch.cuda.synchronize()
+    off, L = batch.slab_layout(n, m)
+    nq = n * (n + 1) // 2
+    A = wl.A.view(total, n, r).transpose(1, 2).cpu().numpy()              # (B, r, n)
+    b = wl.b.view(total, r).cpu().numpy()
+    got = wl.local.cpu().numpy()
+    iu = np.triu_indices(n)
+    G = 2.0 * np.einsum("bri,brj->bij", A, A)
+    np.testing.assert_allclose(got[:, :nq], G[:, iu[0], iu[1]], rtol=1e-12)
+    np.testing.assert_allclose(got[:, off["q"]:off["q"] + n], -2.0 * np.einsum("bri,br->bi", A, b), rtol=1e-12)
+    seq = np.zeros(total)
+    for i in range(r):                                                     # left to right, vectorised over instances
+        c = 0.0 - b[:, i]
+        seq = seq + c * c
+    assert np.array_equal(got[:, off["const"]], seq)
+    assert np.array_equal(got[:, off["C"]:off["C"] + m * n].reshape(total, m, n), wl.Cm.view(total, n, m).transpose(1, 2).cpu().numpy())
+    assert np.array_equal(got[:, off["dconst"]:], 0.0 - wl.d.view(total, m).cpu().numpy())

@@ -1,0 +1,94 @@
+"""-m gpu: robustness of the C-ABI library (round-1 review items): plans are independent — two plans driven from two host threads
+produce the results of the serial run; the strictly-increasing `xvar` contract of pmt_quad_gram_f64 is checked when the call is
+recorded into a plan."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _gram_plan(g, seed, n, r, reps_holder):
+    """a plan with its OWN stream that rebuilds the canonical objective of a seeded r x n problem"""
+    L = g.lib()
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, None, C.byref(plan))
+    rec = C.c_void_p(L.pmt_plan_recording_stream(plan))
+    stream = C.c_void_p(L.pmt_plan_stream(plan))
+    A, b = g.empty_f64(r * n), g.empty_f64(r)
+    g.call("pmt_fill_uniform_f64", g.ptr(A), r * n, seed, 1.0, stream)
+    g.call("pmt_fill_uniform_f64", g.ptr(b), r, seed + 1, 1.0, stream)
+    xvar = torch.arange(1, n + 1, dtype=torch.int64, device=g.DEV)
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(L.pmt_quad_gram_workspace_bytes(r, n) // 8)
+    torch.cuda.synchronize()
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, 1, None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), rec)
+    g.call("pmt_plan_end_record", plan)
+    keep = (A, b, xvar, ws)
+    return plan, (oq, ol, oc), nq, keep
+
+
+def test_two_plans_from_two_threads_are_independent():
+    import gpu_util as g
+    n, r, reps = 384, 1024, 40
+    plans = [_gram_plan(g, seed, n, r, None) for seed in (11, 23)]
+    # serial reference results
+    want = []
+    for plan, (oq, ol, oc), nq, _ in plans:
+        g.call("pmt_plan_update", plan)
+        g.call("pmt_plan_synchronize", plan)
+        want.append((g.terms_to_host(oq, nq, g.QT).copy(), g.terms_to_host(ol, n, g.LT).copy(), g.f64_to_host(oc, 1).copy()))
+        oq.fill_(-7); ol.fill_(-7); oc.fill_(float("nan"))
+    torch.cuda.synchronize()                         # the poison fills ran on torch's stream, the plans have their own
+    errors = []
+
+    def drive(k):
+        try:
+            plan = plans[k][0]
+            for _ in range(reps):
+                g.call("pmt_plan_update", plan)
+            g.call("pmt_plan_synchronize", plan)
+        except Exception as e:                       # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=drive, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for (plan, (oq, ol, oc), nq, _), (wq, wl, wc) in zip(plans, want):
+        g.assert_terms_equal(g.terms_to_host(oq, nq, g.QT), wq)
+        g.assert_terms_equal(g.terms_to_host(ol, n, g.LT), wl)
+        assert g.same_bits(g.f64_to_host(oc, 1), wc)
+        g.call("pmt_plan_destroy", plan)
+
+
+def test_recorded_gram_node_rejects_unsorted_xvar():
+    import gpu_util as g
+    from parametron_jl_amd import _lib
+    L = g.lib()
+    n, r = 8, 8
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, None, C.byref(plan))
+    rec = C.c_void_p(L.pmt_plan_recording_stream(plan))
+    A, b = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = torch.tensor([1, 2, 4, 3, 5, 6, 7, 8], dtype=torch.int64, device=g.DEV)
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(max(1, L.pmt_quad_gram_workspace_bytes(r, n) // 8))
+    torch.cuda.synchronize()
+    g.call("pmt_plan_begin_record", plan)
+    with pytest.raises(_lib.ArgumentError, match="strictly increasing"):
+        g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, 1, None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), rec)
+    assert L.pmt_plan_tape_length(plan) == 0                     # nothing was recorded
+    good = torch.arange(1, n + 1, dtype=torch.int64, device=g.DEV)
+    g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(good), g.ptr(b), -1, 1, None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), rec)
+    g.call("pmt_plan_end_record", plan)
+    assert L.pmt_plan_tape_length(plan) == 1
+    g.call("pmt_plan_destroy", plan)

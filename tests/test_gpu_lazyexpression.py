@@ -204,3 +204,60 @@ def test_prune_zero_on_the_device_matches_the_host_rule():       # src/functions
     want = P.prune_zero(full, atol=1e-6)                                   # host function: the host rule
     assert repr(got) == repr(want)
     assert len(got.quadratic) == 2 and len(got.affine.linear) == 2         # 1e-9 survives in the affine part (default atol = 0)
+
+
+def test_matrix_products_of_parameters():                       # generic rule :198 on number-only arguments
+    """A * B and A * b of Parameters are Julia matrix products (derived data), recomputed when a source changes."""
+    m = P.mock_model()
+    Av = np.array([[1.0, 2.0], [3.0, 4.0]])
+    A = P.Parameter(m, val=Av)
+    B = P.Parameter(lambda: np.array([[5.0, 6.0], [7.0, 8.0]]), m)
+    b = P.Parameter(lambda: np.array([5.0, 6.0]), m)
+    x = [Variable(m) for _ in range(2)]
+    AB, Ab = A * B, A * b
+    assert np.array_equal(AB(), Av @ B()) and np.array_equal(Ab(), Av @ b())
+    e = AB * x                                                  # feeds matvecmul! on the device
+    assert e() == hostops.matvecmul(Av @ B(), x)
+    Av[0, 0] = -1.0
+    m.setdirty()
+    assert np.array_equal(AB(), Av @ B())
+    assert e() == hostops.matvecmul(Av @ B(), x)
+
+
+def test_adjoint_node_feeding_plain_data_is_evaluated():        # round-1 advisor finding: fetch without evaluate
+    """dot(A', B) / A' * B read the adjoint node's buffer: it must be (re)evaluated, not just fetched — first call and after
+    an update of A."""
+    m = P.mock_model()
+    Av = np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]])
+    A = P.Parameter(m, val=Av)
+    Bv = np.arange(6.0).reshape(3, 2) + 1
+    B = P.Parameter(lambda: Bv, m)
+    At = A.T
+    d = P.dot(At, B)
+    assert d() == float(np.sum(Av.T * Bv))
+    prod = At * P.Parameter(lambda: np.array([1.0, -1.0]), m)   # A' * v
+    assert np.array_equal(prod(), Av.T @ np.array([1.0, -1.0]))
+    Av[:] = Av[::-1].copy()
+    m.setdirty()
+    assert d() == float(np.sum(Av.T * Bv))
+    assert np.array_equal(prod(), Av.T @ np.array([1.0, -1.0]))
+
+
+def test_scalar_parameter_times_scalar_decision_terms():         # generic rule :198: Number * Variable / LinearTerm / QuadraticTerm
+    m = P.mock_model()
+    x, y = Variable(m), Variable(m)
+    state = {"p": 3.0}
+    p = P.Parameter(lambda: state["p"], m)
+    e1 = p * x
+    assert e1() == P.AffineFunction.of(3.0 * x)
+    e2 = 2 * x + p
+    assert e2() == 2 * x + 3.0
+    e3 = p * x ** 2
+    assert e3() == P.QuadraticFunction.of(3.0 * x * x)
+    e4 = p * (x * y) + 2 * y
+    assert e4()({x: 2.0, y: 5.0}) == 3.0 * 10.0 + 10.0
+    state["p"] = -1.5
+    m.setdirty()
+    assert e1() == P.AffineFunction.of(-1.5 * x)
+    assert e3() == P.QuadraticFunction.of(-1.5 * x * x)
+    assert no_alloc(m, e1) and no_alloc(m, e3)

@@ -260,3 +260,26 @@ def test_generic_functions_of_parameters_user_functions_hcat_getindex_reshape():
     assert np.all(pmat_angular() == 2.0)
     A = [1, 2, 3, 4]
     assert np.array_equal(P.lazy(np.reshape, A, (2, 2)), np.reshape(A, (2, 2)))   # no Parameter involved: evaluated on the spot
+
+
+# ------------------------------------------------------------------ generic rule src/lazyexpression.jl:198 on plain numbers
+def test_number_array_products_are_matrix_products():
+    """Julia's `*` on number arrays is the matrix product; numpy's elementwise broadcast must never leak through
+    (round-1 advisor finding: apply('*', A, B) returned A .* B)."""
+    A = np.array([[1.0, 2.0], [3.0, 4.0]])
+    B = np.array([[5.0, 6.0], [7.0, 8.0]])
+    b = np.array([5.0, 6.0])
+    assert np.array_equal(hostops.apply("*", A, B), np.array([[19.0, 22.0], [43.0, 50.0]]))
+    assert np.array_equal(hostops.apply("*", A, b), np.array([17.0, 39.0]))
+    assert np.array_equal(hostops.apply("*", 2.0, b), np.array([10.0, 12.0]))
+    assert np.array_equal(hostops.apply("*", b, np.array([[1.0, 2.0, 3.0]])), np.outer(b, [1.0, 2.0, 3.0]))   # Vector * one-row Matrix
+    with pytest.raises(P.ArgumentError):                       # Vector * Vector: MethodError in Julia
+        hostops.apply("*", b, b)
+    with pytest.raises(P.DimensionMismatch):
+        hostops.apply("*", A, np.ones(3))
+    with pytest.raises(P.DimensionMismatch):
+        hostops.apply("*", A, np.ones((3, 2)))
+    # x' * Q for numbers is the row vector (Q'x)'; times a vector it is the bilinear form
+    row = hostops.apply("*", hostops.Transpose(b), A)
+    assert isinstance(row, hostops.Transpose) and np.array_equal(row.parent, A.T @ b)
+    assert hostops.apply("*", row, b) == float(b @ A @ b)
