@@ -5,49 +5,70 @@
 // (src/moi_interop.jl:45-81), coefficients only (the index arrays are identical for every instance, batch.hip).
 //
 // Both bounds of the step are ~0.3 ms for 8192 instances (1.9 GB of HBM traffic; 37.7 M v_mfma_f64_4x4x4_4b at 16 cycles on 1024 SIMDs),
-// so the kernel is a software pipeline in which the matrix pipe, the loads and the stores all run at the same time:
-//   * A is streamed in 32-row chunks through TWO LDS panels (K-contiguous columns, odd pitch: conflict-free for the ds_read2_b64 form
-//     the compiler emits).  In phase g the waves multiply chunk g out of panel g & 1, write chunk g + 1 (loaded during phase g - 1) from
-//     registers into the other panel and issue the global loads of chunk g + 2: one barrier per phase, a whole phase of flight time for
-//     every load, and chunks run on across instance boundaries.
-//   * only the 36 of the 64 16x16 sub-tiles that touch the upper triangle are computed, dealt to the 8 waves as "four of one column
-//     strip + one of another" (9 per SIMD; the rotated B-operand reads of a strip are shared; unused slots compiled out per role class).
-//   * the finished slab of an instance is assembled in LDS in its final memory order (Q packed row-major upper triangle | q | c'c |
-//     C row-major | d-constants: 83.6 KB) and copied to HBM as 16-byte stores spread over the k-steps of the NEXT instance's phases, so
-//     the write-out never stops the matrix pipe (round 1 wrote 8 bytes per lane, row by row, with the pipe idle).
-//   * q is accumulated from the LDS chunk by the vector ALU (same summation order as round 1); c'c — a serial left-to-right chain per
-//     instance (src/functions.jl:574) — is computed for 64 instances at a time by the lanes of one wave while the first chunk is in flight
-//     (round 1: a second kernel, 19 us).
+// so the matrix pipe, the loads and the stores must all run at the same time.  The 8 waves of the workgroup are SPECIALISED (w and w + 4
+// share a SIMD):
+//   * waves 0-3 ("matrix waves", one per SIMD) do nothing but LDS operand reads and MFMAs.  Only the 36 of the 64 16x16 sub-tiles that
+//     touch the upper triangle are computed; wave w owns the column strips 7 - w (sub-tiles tm = 0..7-w) and w (tm = 0..w): 9 sub-tiles
+//     per wave, and because both strips start at tm = 0 the A operands are shared — 8 - w + 8 LDS reads per 36 MFMAs (round 1: 13 per 20).
+//   * waves 4, 5 ("loader waves") stream A in 32-row chunks through TWO LDS panels: in phase g the matrix waves multiply chunk g out of
+//     panel g & 1 while the loaders issue the global loads of chunk g + 2 and write chunk g + 1 (loaded during phase g - 1) into the
+//     other panel — one barrier per phase, a whole phase of flight time per load, chunks run on across instance boundaries.  They also
+//     accumulate q from the LDS chunk with their vector ALU (round 1's summation order).
+//   * waves 6, 7 ("storer waves") write results: the finished slab of an instance is assembled in LDS in its final memory order (Q packed
+//     row-major upper triangle | q | c'c | C row-major | d-constants: 83.6 KB) and copied to HBM as 16-byte stores during the NEXT instance's
+//     phases, so the write-out never stops the matrix pipe (round 1 wrote 8 bytes per lane, row by row, with the pipe idle).  They also
+//     transpose the constraint block and compute c'c — a serial left-to-right chain per instance (src/functions.jl:574) — for 64 instances
+//     at a time, one per lane, while the first chunk is in flight (round 1: a second kernel, 19 us).
+// Why three kinds of waves (measured, profiles/r02_batch_small.txt): the vector-memory path of a CU accepts ~10 B/cycle when the whole chip
+// streams, so issuing a chunk's loads takes ~3400 cycles and a 2 KB store ~400 — the issuing wave just sits there.  With every wave doing
+// loads, stores, address arithmetic and MFMAs in turn the matrix pipe was busy 37 % (round 1) / 50 % (pipelined, unspecialised) of the
+// kernel; loads and stores in the SAME wave also wait for each other (one in-order counter).  Separated, each stream has the whole phase.
+// The kernel runs at the chip's power limit: 0.39 ms without the HBM reads at 2.39 GHz, 0.46 ms with them at 1.97 GHz, the same ~1.0 M
+// cycles either way (profiles/r02_batch_small.txt).
 // Q uses the MFMA lane mapping and k order of gram_sk.hip: bit-identical to pmt_quad_gram_f64 on the same instance.
 #include <type_traits>
 
 #include "common.h"
 
 #ifndef PMT_BS_SKIP
-#define PMT_BS_SKIP 0      // profiling builds only: 1 = no contraction, 2 = no q, 4 = no slab staging / copy-out, 8 = no chunk loads
+#define PMT_BS_SKIP 0      // profiling builds only: 1 = no contraction, 2 = no q, 8 = no chunk loads, 32 = no operand reads
 #endif
 #ifndef PMT_BS_PITCH
-#define PMT_BS_PITCH 33    // LDS pitch of a panel column in doubles
+#define PMT_BS_PITCH 34    // LDS pitch of a panel column in doubles: 2 (mod 32) is conflict-free for ds_read_b64 (an odd pitch for ds_read2_b64)
 #endif
-#ifndef PMT_BS_LOADKS
-#define PMT_BS_LOADKS 1    // k-steps multiplied before the phase's LDS stores / global loads are issued
+#ifndef PMT_BS_PRIO
+#define PMT_BS_PRIO 0      // s_setprio of the matrix waves (helpers stay at 0): 0, 2, 3 measured equal
 #endif
-#ifndef PMT_BS_COPYEVERY
-#define PMT_BS_COPYEVERY 2 // one 16-byte copy-out piece per thread every this many k-steps
+#ifndef PMT_BS_FENCE
+#define PMT_BS_FENCE 1     // operand reads are hoisted at most one k-step ahead of their MFMAs (unfenced the scheduler hoists several k-steps and spills)
+#endif
+
+#ifndef PMT_BS_TRACE
+#define PMT_BS_TRACE 0     // tuning builds: s_memtime stamps of workgroup 0's matrix wave 0, read back with pmt_debug_bs_trace (the loader waves must not
+                           // be instrumented: a stamp is a global store, and their hand-counted s_waitcnt assumes they issue loads only)
 #endif
 
 namespace pmt {
+
+#if PMT_BS_TRACE
+__device__ long long g_bs_trace[2][8192];
+#define BS_STAMP(who, idx) do { if (blockIdx.x == 0 && (idx) < 8192) g_bs_trace[who][idx] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BS_STAMP(who, idx) do { } while (0)
+#endif
 
 namespace {
 
 constexpr int SN = 128;                 // columns handled (smaller instances are zero padded)
 constexpr int CK = 32;                  // rows per chunk
 constexpr int SGP = PMT_BS_PITCH;
-constexpr int NT = 512;
+constexpr int NT = 512;                 // threads per workgroup: waves 0-3 matrix, waves 4-7 helpers
+constexpr int NH = 256;                 // first helper thread
+constexpr int NL = 128, NS = 128;       // loader / storer threads
 constexpr int PANEL = SN * SGP;         // doubles per panel
 constexpr int STAGE_CAP = 10464;        // slab staging capacity in doubles (config 4: 10449 + 1 alignment shift)
-constexpr int NP = 4;                   // 16-byte pieces per thread per chunk
-constexpr int CREG = 4;                 // constraint-block entries prefetched per thread (m*n <= 2048)
+constexpr int NPL = 16;                 // 16-byte pieces per loader thread per chunk
+constexpr int CREG = 16;                // constraint-block entries prefetched per storer thread (m*n <= 2048)
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -60,99 +81,318 @@ struct SmallArgs {
     int stage_all;                      // the whole slab fits the LDS staging buffer (else C and d are written directly)
 };
 
-// wave w computes sub-tiles (tm = S_TM1[w][i], tn = S_TN1[w]) for i < 4 and (S_TM2[w], S_TN2[w]); the slots a role does not need (the
-// fourth group-1 tile of waves 6, 7; the group-2 tile of waves 4, 5) are compiled out of its role class
-__device__ __constant__ const signed char S_TN1[8] = {7, 7, 6, 5, 4, 3, 6, 2};
-__device__ __constant__ const signed char S_TM1[8][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 2, 3}, {0, 1, 2, 3}, {0, 1, 2, 3}, {0, 1, 2, 3}, {4, 5, 6, 6}, {0, 1, 2, 2}};
-__device__ __constant__ const signed char S_TN2[8] = {5, 5, 1, 1, 4, 3, 4, 0};
-__device__ __constant__ const signed char S_TM2[8] = {4, 5, 0, 1, 0, 0, 4, 0};
+struct Shared {
+    double *panel, *stage, *cvec;       // panel[2][PANEL], stage[STAGE_CAP + 2], cvec[2][CK]
+};
 
-}  // namespace
+__device__ __forceinline__ void phase_barrier() { __syncthreads(); }
 
-// FAST: cols == 128, rows a multiple of 32, 16-byte aligned columns — aligned 16-byte loads without bounds checks.
-template <bool FAST>
-__global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
-    __shared__ __attribute__((aligned(16))) double panel[2 * PANEL];
-    __shared__ __attribute__((aligned(16))) double stage[STAGE_CAP + 2];
-    __shared__ double cvec[2][CK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- matrix wave W (0..3): column strips 7 - W (tm = 0 .. 7 - W) and W (tm = 0 .. W)
+// ALLCOLS: n == 128 (no column predicate on the staging stores)
+template <int W, bool ALLCOLS>
+__device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh, int lane, int n, int nchunk) {
+    constexpr int KA = 8 - W, KB = W + 1, TNA = 7 - W, TNB = W;
     const int lm = lane & 15, lk = lane >> 4;
-    const int kp = tid & 15, cc0 = tid >> 4;                 // chunk loads: 16-byte piece kp of columns cc0 + 32 q
-    const int64_t n = p.cols, nq = n * (n + 1) / 2;
-    const int nchunk = (int)max((int64_t)1, (p.rows + CK - 1) / CK);
+    double accA[KA][4], accB[KB][4];
+#pragma unroll
+    for (int i = 0; i < KA; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accA[i][r] = 0.0;
+#pragma unroll
+    for (int i = 0; i < KB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accB[i][r] = 0.0;
+    int rc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rc[r] = (((((lm >> 2) + r) & 3) << 2) | (lm & 3)) * SGP;     // column group rotated by r blocks
+    // staging positions of this lane's accumulator elements: element (tile tm = i, r) is C[row_i][colX_r] with row_i = 16 i + 4 bq + i_,
+    // colX_r = 16 TNX + 4 ((bq + r) & 3) + j_  ->  packed upper-triangular position row n - row (row - 1) / 2 + (col - row); the same for
+    // every instance, so they are computed once (rb[i] + cX[r]); only the two diagonal sub-tiles (and columns >= n) need a predicate
+    const int i_ = lane >> 4, bq = (lane >> 2) & 3, j_ = lane & 3;
+    int rb[KA], cA[4], cB[4];
+#pragma unroll
+    for (int i = 0; i < KA; ++i) { const int row = i * 16 + 4 * bq + i_; rb[i] = row * n - (row * (row - 1)) / 2 - row; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cA[r] = TNA * 16 + 4 * ((bq + r) & 3) + j_; cB[r] = TNB * 16 + 4 * ((bq + r) & 3) + j_; }
+    const int rowdA = (KA - 1) * 16 + 4 * bq + i_, rowdB = (KB - 1) * 16 + 4 * bq + i_;      // rows of the diagonal sub-tiles (tm == tn)
+    if (PMT_BS_PRIO) __builtin_amdgcn_s_setprio(PMT_BS_PRIO);                                                           // the matrix pipe's wave outranks the helper on its SIMD
+    const int a0 = lm * SGP + lk;                                                            // sub-tile tm: + tm * 16 * SGP
+    const int bA0 = (TNA * 16) * SGP + lk, bB0 = (TNB * 16) * SGP + lk;
     const int64_t G = gridDim.x;
-    const int64_t mn = p.Cm ? p.m * n : 0;
-    const bool creg_path = p.Cm && p.stage_all && mn <= (int64_t)CREG * NT && p.m <= NT;
-    const int64_t L = (p.Cm && p.stage_all) ? nq + n + 1 + mn + p.m : nq + n + 1;      // staged (contiguous) doubles per instance
+    int cur = 0;
+    int tphase = 0; (void)tphase;
+    phase_barrier();                                          // panel 0 holds the first chunk
+    for (int64_t inst = blockIdx.x; inst < p.B; inst += G) {
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const double *pan = sh.panel + cur * PANEL;
+            if (PMT_BS_TRACE && W == 0 && lane == 0) BS_STAMP(0, 4 * tphase + 0);
+            if (!(PMT_BS_SKIP & 1)) {
+                // explicit software pipeline: the operands of k-step ks + 1 are read (into the other register set) BEFORE the MFMAs of
+                // k-step ks are issued, so the LDS latency hides behind 36 MFMAs instead of idling this SIMD's matrix pipe (there is no second
+                // matrix wave on the SIMD to cover it).  The fences keep the reads from being hoisted further (register pressure).
+                double a[2][KA], bA[2][4], bB[2][4];
+                auto read_operands = [&](int s_, int ks) {
+                    if (PMT_BS_SKIP & 32) {
+#pragma unroll
+                        for (int i = 0; i < KA; ++i) a[s_][i] = (double)(lane + i + ks);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { bA[s_][r] = (double)(lane + r); bB[s_][r] = (double)(lane - r); }
+                        return;
+                    }
+#pragma unroll
+                    for (int i = 0; i < KA; ++i) a[s_][i] = pan[a0 + i * 16 * SGP + ks * 4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { bA[s_][r] = pan[bA0 + rc[r] + ks * 4]; bB[s_][r] = pan[bB0 + rc[r] + ks * 4]; }
+                };
+                read_operands(0, 0);
+#pragma unroll
+                for (int ks = 0; ks < CK / 4; ++ks) {
+                    const int s_ = ks & 1;
+                    if (ks + 1 < CK / 4) read_operands(s_ ^ 1, ks + 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int i = 0; i < KA; ++i) accA[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bA[s_][r], accA[i][r], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < KB; ++i) accB[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bB[s_][r], accB[i][r], 0, 0, 0);
+                    }
+                    if (PMT_BS_FENCE) asm volatile("" ::: "memory");
+                }
+            }
+            if (PMT_BS_TRACE && W == 0 && lane == 0) BS_STAMP(0, 4 * tphase + 1);
+            if (ch == nchunk - 1) {
+                phase_barrier();                              // the storer waves have copied the previous slab out of the staging buffer
+                // ---- the Q coefficients of this instance, x2, at their packed row-major upper-triangular positions in the staging buffer
+                double *outp = p.out + inst * p.out_stride;
+                double *st = sh.stage + (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
+#pragma unroll
+                for (int i = 0; i < KA; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (i < KA - 1 || rowdA <= cA[r]) && (ALLCOLS || cA[r] < n);
+                        if (ok) st[rb[i] + cA[r]] = 2 * accA[i][r];
+                        accA[i][r] = 0.0;
+                    }
+                    if (i < KB) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool ok = (i < KB - 1 || rowdB <= cB[r]) && (ALLCOLS || cB[r] < n);
+                            if (ok) st[rb[i] + cB[r]] = 2 * accB[i][r];
+                            accB[i][r] = 0.0;
+                        }
+                    }
+                }
+            }
+            if (PMT_BS_TRACE && W == 0 && lane == 0) BS_STAMP(0, 4 * tphase + 2);
+            phase_barrier();
+            if (PMT_BS_TRACE && W == 0 && lane == 0) { BS_STAMP(0, 4 * tphase + 3); }
+            ++tphase;
+            cur ^= 1;
+        }
+    }
+}
 
-    // ---- chunk (inst, ch): global -> registers; registers -> LDS panel `buf`
-    f64x2 R[NP];
-    double cval = 0.0;
-    auto load_chunk = [&](int64_t inst, int ch) {
+// ---- loader waves 4, 5 (lt = 0..127): chunk loads -> LDS panels, and q from the LDS chunk
+template <bool FAST>
+__device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &sh, int lt, int n, int nchunk) {
+    const int lane = lt & 63, lw = lt >> 6;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int kp = lt & 15, cc0 = lt >> 4;                    // chunk loads: 16-byte piece kp of columns cc0 + 8 q
+    const int nq = n * (n + 1) / 2;
+    const int64_t G = gridDim.x;
+    const bool has_c = p.b && p.sign;
+    const double *csrc = has_c ? p.b : p.A;
+    const int64_t cstride = has_c ? p.strideb : p.strideA;
+    const int csign = has_c ? p.sign : 0;
+
+    // chunk (inst, ch): global -> registers (set S); registers -> LDS panel `buf`.
+    // Two register sets, parity of the phase: in phase g the loads of chunk g + 2 are issued FIRST (into the set chunk g has just left),
+    // then chunk g + 1 — loaded during phase g - 1, a whole phase ago — goes from the other set into LDS.  Issuing a chunk's 17 loads takes
+    // ~3400 cycles (the CU's vector-memory path accepts ~10 B/cycle when the chip streams), so they must not sit behind a wait.
+    // FAST: the loads are issued through inline asm and waited for by hand (wait_chunk): the compiler's waitcnt pass answers loop-carried
+    // loads with s_waitcnt vmcnt(0), which here would wait for the loads issued a moment ago.  These waves issue no other vector-memory
+    // operation, loads return in order, so "at most NLOADS outstanding" means exactly: the older set has landed.
+    constexpr int NLOADS = NPL + 1;
+    f64x2 R[2][NPL] = {};
+    double cval[2] = {0.0, 0.0};
+    auto load_chunk = [&](auto set_t, int64_t inst, int ch) {
+        constexpr int S = decltype(set_t)::value;
         const double *A = p.A + inst * p.strideA;
         const int64_t row = (int64_t)ch * CK + 2 * kp;
         if (PMT_BS_SKIP & 8) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) { R[q].x = 1.0; R[q].y = 2.0; }
+            for (int q = 0; q < NPL; ++q) { R[S][q].x = 1.0; R[S][q].y = 2.0; }
+            cval[S] = 0.5;
         } else if (FAST) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) R[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)(cc0 + 32 * q) * p.lda + row);
+            for (int q = 0; q < NPL; ++q) {
+                const double *src = A + (int64_t)(cc0 + 8 * q) * p.lda + row;
+                f64x2 &dst = R[S][q];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+            }
+            // every thread reads c of row lt & 31 (no branch); without a b (sign 0) the read goes to A and signed_const(., 0) = 0
+            const double *src = csrc + inst * cstride + (int64_t)ch * CK + (lt & (CK - 1));
+            double &dst = cval[S];
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
         } else {
             const int64_t rmax = max(p.rows - 1, (int64_t)0), cmax = max(p.cols - 1, (int64_t)0);
             const int64_t r0 = min(row, rmax), r1 = min(row + 1, rmax);
             const bool ok0 = row < p.rows, ok1 = row + 1 < p.rows;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int col = cc0 + 32 * q;
+            for (int q = 0; q < NPL; ++q) {
+                const int col = cc0 + 8 * q;
                 const double *src = A + min((int64_t)col, cmax) * p.lda;
                 const bool okc = col < p.cols && p.rows > 0;
                 const double x = okc ? src[r0] : 0.0, y = okc ? src[r1] : 0.0;
-                R[q].x = (okc && ok0) ? x : 0.0;
-                R[q].y = (okc && ok1) ? y : 0.0;
+                R[S][q].x = (okc && ok0) ? x : 0.0;
+                R[S][q].y = (okc && ok1) ? y : 0.0;
+            }
+            cval[S] = 0.0;
+            if (lt < CK) {
+                const int64_t rr = (int64_t)ch * CK + lt;
+                if (has_c && rr < p.rows) cval[S] = p.b[inst * p.strideb + rr];
             }
         }
-        cval = 0.0;
-        if (tid < CK) {
-            const int64_t rr = (int64_t)ch * CK + tid;
-            if (p.b && p.sign && rr < p.rows) cval = signed_const(p.b[inst * p.strideb + rr], p.sign);
+    };
+    // wait until register set S has landed; `younger` = number of loads issued after it that may stay in flight (0 or NLOADS)
+    auto wait_chunk = [&](auto set_t, auto younger_t) {
+        constexpr int S = decltype(set_t)::value;
+        constexpr int YOUNGER = decltype(younger_t)::value;
+        if (FAST && !(PMT_BS_SKIP & 8)) {
+            f64x2 (&r)[NPL] = R[S];                           // (asm operands inside a generic lambda must name locals)
+            double &cv = cval[S];
+            asm volatile("s_waitcnt vmcnt(%17)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                         "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(cv) : "n"(YOUNGER) : "memory");
         }
     };
-    auto store_chunk = [&](int buf) {
-        double *pan = panel + buf * PANEL;
+    auto store_chunk = [&](auto set_t, int buf) {
+        constexpr int S = decltype(set_t)::value;
+        double *pan = sh.panel + buf * PANEL;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            double *d = pan + (cc0 + 32 * q) * SGP + 2 * kp;
-            d[0] = R[q].x; d[1] = R[q].y;
+        for (int q = 0; q < NPL; ++q) {
+            double *d = pan + (cc0 + 8 * q) * SGP + 2 * kp;
+            if (SGP % 2 == 0) *reinterpret_cast<f64x2 *>(d) = R[S][q];
+            else { d[0] = R[S][q].x; d[1] = R[S][q].y; }
         }
-        if (tid < CK) cvec[buf][tid] = cval;
+        if (FAST) sh.cvec[buf * CK + (lt & (CK - 1))] = signed_const(cval[S], csign);         // four threads write the same value: benign
+        else if (lt < CK) sh.cvec[buf * CK + lt] = signed_const(cval[S], csign);
     };
 
-    // ---- copy-out of the slab staged for the PREVIOUS instance: piece u = 16 bytes per thread; stage and HBM are co-aligned
-    double *cp_out = nullptr; int cp_head = 0, cp_u = 0, cp_n = 0;
-    auto copy_piece = [&]() {
-        if (cp_u < cp_n) {
-            const int64_t pos = cp_head + 2 * ((int64_t)tid + (int64_t)NT * cp_u);
-            const double *st = stage + cp_head;
-            if (pos + 1 < L) *reinterpret_cast<f64x2 *>(cp_out + pos) = *reinterpret_cast<const f64x2 *>(st + pos);
-            else if (pos < L) cp_out[pos] = st[pos];
-            ++cp_u;
+    double qpart[4] = {0.0, 0.0, 0.0, 0.0};                   // lane: columns 64 lw + 16 j + lm, rows lk + 4u of every chunk
+    const int qoff = (64 * lw + lm) * SGP + lk;
+    auto next_of = [&](int64_t i, int c, int64_t &ni, int &nc) { nc = c + 1; ni = i; if (nc == nchunk) { nc = 0; ni = i + G; } };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using None = std::integral_constant<int, 0>;
+    using OneSet = std::integral_constant<int, NLOADS>;
+    // prime the pipeline: chunk 0 -> panel 0 (through set 0), chunk 1 -> set 1.  Phase g then loads chunk g + 2 into set g & 1 and stores
+    // chunk g + 1 from set (g + 1) & 1.
+    int64_t inst = blockIdx.x;
+    int ch = 0;
+    if (inst < p.B) {
+        load_chunk(P0{}, inst, 0);
+        wait_chunk(P0{}, None{});
+        store_chunk(P0{}, 0);
+        int64_t n1i; int n1c;
+        next_of(inst, 0, n1i, n1c);
+        if (n1i >= p.B) { n1i = inst; n1c = 0; }
+        load_chunk(P1{}, n1i, n1c);
+    }
+    phase_barrier();
+    // phase g (parity PAR): the matrix waves multiply chunk g out of panel PAR
+    auto phase = [&](auto par_t) {
+        constexpr int PAR = decltype(par_t)::value;
+        using Other = std::integral_constant<int, PAR ^ 1>;
+        const double *pan = sh.panel + PAR * PANEL;
+        int64_t n1i, n2i; int n1c, n2c;
+        next_of(inst, ch, n1i, n1c);
+        next_of(n1i, n1c, n2i, n2c);
+        if (n2i >= p.B) { n2i = inst; n2c = ch; }             // past the end: re-load a valid chunk, never used
+        const bool last = (ch == nchunk - 1);
+        load_chunk(par_t, n2i, n2c);                          // chunk g + 2 -> set PAR (chunk g left it during phase g - 1)
+        wait_chunk(Other{}, OneSet{});                        // chunk g + 1 (set PAR ^ 1, issued a phase ago) has landed ...
+        store_chunk(Other{}, PAR ^ 1);                        // ... and goes into the other panel
+        if (!(PMT_BS_SKIP & 2)) {                             // q: rows lk + 4 ks of this lane's four columns (vector ALU)
+#pragma unroll
+            for (int ks = 0; ks < CK / 4; ++ks) {
+                const double c = sh.cvec[PAR * CK + lk + 4 * ks];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double pr = c * pan[qoff + j * 16 * SGP + 4 * ks]; qpart[j] = qpart[j] + pr; }
+            }
         }
+        if (last) {
+            phase_barrier();                                  // the previous slab has left the staging buffer
+            double *outp = p.out + inst * p.out_stride;
+            double *st = sh.stage + (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
+            // q: the four row classes of a column, added in class order, x2
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double p1 = __shfl(qpart[j], lane + 16, 64), p2 = __shfl(qpart[j], lane + 32, 64), p3 = __shfl(qpart[j], lane + 48, 64);
+                const int col = 64 * lw + 16 * j + lm;
+                if (lk == 0 && col < n) st[nq + col] = 2 * (((qpart[j] + p1) + p2) + p3);
+                qpart[j] = 0.0;
+            }
+        }
+        phase_barrier();
+        inst = n1i; ch = n1c;
+    };
+    while (inst < p.B) {
+        phase(P0{});
+        if (inst >= p.B) break;
+        phase(P1{});
+    }
+    // the clamped re-loads of the last two phases are still in flight INTO the register sets: nothing may reuse those registers before
+    // they have landed
+    wait_chunk(P0{}, None{});
+    wait_chunk(P1{}, None{});
+}
+
+// ---- storer waves 6, 7 (st_ = 0..127): slab copy-out, constraint block, c'c
+__device__ __forceinline__ void storer_waves(const SmallArgs &p, const Shared &sh, int st_, int n, int nchunk) {
+    const int lane = st_ & 63, sw = st_ >> 6;
+    const int nq = n * (n + 1) / 2;
+    const int64_t G = gridDim.x;
+    const int m = p.Cm ? (int)min(p.m, (int64_t)1 << 20) : 0;
+    const int64_t mn = (int64_t)m * n;
+    const bool creg_path = p.Cm && p.stage_all && mn <= (int64_t)CREG * NS && m <= NS;
+    const int L = (p.Cm && p.stage_all) ? nq + n + 1 + (int)mn + m : nq + n + 1;         // staged (contiguous) doubles per instance
+    const bool has_c = p.b && p.sign;
+
+    // copy-out of the slab staged for the PREVIOUS instance: 16 bytes per thread per piece, stage and HBM co-aligned; pair indices past
+    // the end are clamped to the last pair (rewritten with the same bytes), so a batch needs no branch.  Four pieces at a time keep four
+    // LDS reads in flight (a lone read queues behind the matrix waves' operand reads).  The store ISSUE is what takes the time here — the
+    // write path of a CU has a bounded number of stores in flight — which is why these waves do nothing else that the phase waits for.
+    double *cp_out = nullptr; int cp_head = 0, cp_u = 0, cp_n = 0, cp_last = 0;
+    auto copy_batch = [&]() {
+        f64x2 v[4]; int pos[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pos[k] = cp_head + 2 * min(st_ + NS * (cp_u + k), cp_last);
+            v[k] = *reinterpret_cast<const f64x2 *>(sh.stage + cp_head + pos[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f64x2 *>(cp_out + pos[k]) = v[k];
+        cp_u += 4;
     };
     auto copy_begin = [&](int64_t inst) {
         cp_out = p.out + inst * p.out_stride;
         cp_head = (int)((reinterpret_cast<uintptr_t>(cp_out) >> 3) & 1);
+        const int npairs = (L - cp_head) / 2;                 // >= 1 (L >= 3)
+        cp_last = npairs - 1;
         cp_u = 0;
-        cp_n = (PMT_BS_SKIP & 4) ? 0 : (int)((L - cp_head + 2 * NT - 1) / (2 * NT));
-        if (cp_head && tid == 0 && !(PMT_BS_SKIP & 4)) cp_out[0] = stage[cp_head];
+        cp_n = (npairs + NS - 1) / NS;
+        if (cp_head && st_ == 0) cp_out[0] = sh.stage[cp_head];                                         // unaligned first element
+        if (cp_head + 2 * npairs < L && st_ == 1) cp_out[L - 1] = sh.stage[cp_head + L - 1];            // odd last element
     };
 
-    // ---- c'c of 64 of this workgroup's instances at a time, one instance per lane of wave 7: ((0 + c_0^2) + c_1^2) + ...
+    // c'c of 64 of this workgroup's instances at a time, one instance per lane of the last wave: ((0 + c_0^2) + c_1^2) + ...
     // left to right (src/functions.jl:574), loads batched eight deep
     double cst = 0.0;
     auto const_chains = [&](int64_t li0) {
         const int64_t my = (int64_t)blockIdx.x + (li0 + lane) * G;
         double s = 0.0;
-        if (my < p.B && p.b && p.sign) {
+        if (my < p.B && has_c) {
             const double *bb = p.b + my * p.strideb;
             int64_t i = 0;
             for (; i + 8 <= p.rows; i += 8) {
@@ -167,161 +407,80 @@ __global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
         cst = s;
     };
 
-    auto run = [&](auto has4_t, auto has2_t) {
-        constexpr bool H4 = decltype(has4_t)::value, H2 = decltype(has2_t)::value;
-        const int role = wave;
-        double acc[5][4];
+    double creg[CREG]; double dreg = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
-        double qpart = 0.0;                                  // lane: column 16*wave + lm, rows lk + 4u of every chunk
-        int rc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rc[r] = (((((lm >> 2) + r) & 3) << 2) | (lm & 3)) * SGP;     // column group rotated by r blocks
-        int aoff[5];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) aoff[i] = (S_TM1[role][i] * 16 + lm) * SGP + lk;
-        aoff[4] = (S_TM2[role] * 16 + lm) * SGP + lk;
-        const int b1off = (S_TN1[role] * 16) * SGP + lk, b2off = (S_TN2[role] * 16) * SGP + lk;
-        const int qoff = (16 * wave + lm) * SGP + lk;
-
-        int64_t inst = blockIdx.x, li = 0;
-        int ch = 0, cur = 0;
-        bool pending = false;
-        double creg[CREG]; double dreg = 0.0;
-#pragma unroll
-        for (int u = 0; u < CREG; ++u) creg[u] = 0.0;
-
-        auto next_of = [&](int64_t i, int c, int64_t &ni, int &nc) { nc = c + 1; ni = i; if (nc == nchunk) { nc = 0; ni = i + G; } };
-
-        // prime the pipeline: chunk 0 -> panel 0, chunk 1 in registers
-        if (inst < p.B) {
-            load_chunk(inst, 0);
-            if (wave == 7) const_chains(0);
-            store_chunk(0);
-            int64_t ni; int nc;
-            next_of(inst, 0, ni, nc);
-            if (ni < p.B) load_chunk(ni, nc);
-        }
-        __syncthreads();
-
-        while (inst < p.B) {
-            const double *pan = panel + cur * PANEL;
-            int64_t n1i, n2i; int n1c, n2c;
-            next_of(inst, ch, n1i, n1c);
-            next_of(n1i, n1c, n2i, n2c);
-            if (n2i >= p.B) { n2i = inst; n2c = ch; }         // past the end: re-load a valid chunk, never used (no branch around the loads)
+    for (int u = 0; u < CREG; ++u) creg[u] = 0.0;
+    int64_t li = 0;
+    bool pending = false;
+    if ((int64_t)blockIdx.x < p.B && sw == 1) const_chains(0);
+    phase_barrier();
+    for (int64_t inst = blockIdx.x; inst < p.B; inst += G) {
+        for (int ch = 0; ch < nchunk; ++ch) {
             const bool last = (ch == nchunk - 1);
-
-            auto ksteps = [&](int k0, int k1, bool copy) {
-#pragma unroll
-                for (int ks = k0; ks < k1; ++ks) {
-                    if (!(PMT_BS_SKIP & 1)) {
-                        double a[5], b1[4], b2[4];
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) a[i] = pan[aoff[i] + ks * 4];
-                        if (H4) a[3] = pan[aoff[3] + ks * 4];
-                        if (H2) a[4] = pan[aoff[4] + ks * 4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { b1[r] = pan[b1off + rc[r] + ks * 4]; if (H2) b2[r] = pan[b2off + rc[r] + ks * 4]; }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                            for (int i = 0; i < (H4 ? 4 : 3); ++i)
-                                acc[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b1[r], acc[i][r], 0, 0, 0);
-                            if (H2) acc[4][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[4], b2[r], acc[4][r], 0, 0, 0);
-                        }
-                    }
-                    if (copy && (ks % PMT_BS_COPYEVERY) == 0) copy_piece();
-                }
-            };
-
-            // the copy-out of the previous instance is spread over the phases before this instance's last one
-            const bool copy_here = pending && !last;
-            ksteps(0, PMT_BS_LOADKS, copy_here);
-            if (!(PMT_BS_SKIP & 2)) {                         // q from the chunk (vector ALU, beside the partner wave's MFMAs)
-#pragma unroll
-                for (int u = 0; u < CK / 4; ++u) { const double pr = cvec[cur][lk + 4 * u] * pan[qoff + 4 * u]; qpart = qpart + pr; }
-            }
-            store_chunk(cur ^ 1);                             // chunk g + 1 (registers) -> the other panel
-            load_chunk(n2i, n2c);                             // chunk g + 2 -> registers
-            if (last && creg_path) {                          // constraint block of this instance: in flight during the phase
+            if (ch == 0 && creg_path) {                       // constraint block of this instance: loaded in its first phase, staged in its last
                 const double *Ci = p.Cm + inst * mn;
 #pragma unroll
-                for (int u = 0; u < CREG; ++u) { const int64_t e = tid + (int64_t)NT * u; creg[u] = e < mn ? Ci[e] : 0.0; }
-                dreg = tid < p.m ? p.d[inst * p.m + tid] : 0.0;
+                for (int u = 0; u < CREG; ++u) {              // entry e of the ROW-major output: consecutive lanes -> consecutive staging addresses
+                    const int e = min(st_ + NS * u, (int)mn - 1);     // (the column-major reads are strided, but hit L1/L2; entries past the end are
+                    const int row = e / n, col = e - row * n;         //  clamped to the last one: written twice, same value)
+                    creg[u] = Ci[col * m + row];
+                }
+                dreg = p.d[inst * m + min(st_, m - 1)];
             }
-            ksteps(PMT_BS_LOADKS, CK / 4, copy_here);
-            if (pending && (ch == nchunk - 2 || nchunk == 1)) {     // whatever is left must be out before anyone restages
-                while (cp_u < cp_n) copy_piece();
-                pending = false;
-                if (nchunk == 1) __syncthreads();
+            if (pending) {                                    // the previous slab leaves during this instance's phases, a share per phase
+                const int todo = (cp_n - cp_u + (nchunk - ch) - 1) / (nchunk - ch);
+                for (int u = 0; u < todo; u += 4) copy_batch();          // (pieces past the end are clamped re-writes of the last pair)
+                if (last) { while (cp_u < cp_n) copy_batch(); pending = false; }
             }
-
             if (last) {
-                // ---- the slab of this instance, in its final order, into the staging buffer
+                phase_barrier();                              // every wave: the previous slab has left the staging buffer, restaging may begin
                 double *outp = p.out + inst * p.out_stride;
-                const int head = (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
-                double *st = stage + head;
-                if (!(PMT_BS_SKIP & 4)) {
-                    const int i_ = lane >> 4, bq = (lane >> 2) & 3, j_ = lane & 3;   // accumulator element -> (row, col) inside a sub-tile
+                double *st = sh.stage + (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
+                if (sw == 1 && lane == (int)(li & 63)) st[nq + n] = cst;
+                if (p.Cm) {
+                    double *sc = p.stage_all ? st + nq + n + 1 : outp + nq + n + 1;           // staged, or straight to HBM when too large
+                    if (creg_path) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        if ((i == 3 && !H4) || (i == 4 && !H2)) continue;
-                        const int tm = i < 4 ? S_TM1[role][i] : S_TM2[role];
-                        const int tn = i < 4 ? S_TN1[role] : S_TN2[role];
-                        const int row = tm * 16 + 4 * bq + i_;
-                        const int rbase = row * (int)n - (row * (row - 1)) / 2 - row;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int col = tn * 16 + 4 * ((bq + r) & 3) + j_;
-                            if (row <= col && col < n) st[rbase + col] = 2 * acc[i][r];
-                        }
-                    }
-                    // q: the four row classes of a column, added in class order, x2
-                    const double p1 = __shfl(qpart, lane + 16, 64), p2 = __shfl(qpart, lane + 32, 64), p3 = __shfl(qpart, lane + 48, 64);
-                    if (lk == 0 && 16 * wave + lm < n) st[nq + 16 * wave + lm] = 2 * (((qpart + p1) + p2) + p3);
-                    if (wave == 7 && lane == (int)(li & 63)) st[nq + n] = cst;
-                    if (p.Cm) {
-                        double *sc = p.stage_all ? st + nq + n + 1 : outp + nq + n + 1;       // staged, or straight to HBM when too large
-                        if (creg_path) {
-#pragma unroll
-                            for (int u = 0; u < CREG; ++u) {
-                                const int64_t e = tid + (int64_t)NT * u;
-                                if (e < mn) { const int64_t col = e / p.m, row = e - col * p.m; sc[row * n + col] = creg[u]; }
-                            }
-                            if (tid < p.m) sc[mn + tid] = signed_const(dreg, p.sign_d);
-                        } else {
-                            const double *Ci = p.Cm + inst * mn;
-                            for (int64_t e = tid; e < mn; e += NT) { const int64_t col = e / p.m, row = e - col * p.m; sc[row * n + col] = Ci[e]; }
-                            for (int64_t i = tid; i < p.m; i += NT) sc[mn + i] = signed_const(p.d[inst * p.m + i], p.sign_d);
-                        }
+                        for (int u = 0; u < CREG; ++u) sc[min(st_ + NS * u, (int)mn - 1)] = creg[u];
+                        sc[mn + min(st_, m - 1)] = signed_const(dreg, p.sign_d);
+                    } else {
+                        const double *Ci = p.Cm + inst * mn;
+                        for (int64_t e = st_; e < mn; e += NS) { const int64_t col = e / m, row = e - col * m; sc[row * n + col] = Ci[e]; }
+                        for (int i = st_; i < m; i += NS) sc[mn + i] = signed_const(p.d[inst * m + i], p.sign_d);
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
-                qpart = 0.0;
                 ++li;
             }
-            __syncthreads();
+            phase_barrier();
             if (last) {
                 copy_begin(inst);
                 pending = true;
-                if ((li & 63) == 0 && wave == 7) const_chains(li);          // more than 64 instances per workgroup: next batch of chains
+                if ((li & 63) == 0 && sw == 1) const_chains(li);          // more than 64 instances per workgroup: next batch of chains
             }
-            cur ^= 1;
-            inst = n1i; ch = n1c;
         }
-        if (pending) { while (cp_u < cp_n) copy_piece(); }
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    if (wave >= 6) run(F{}, T{});
-    else if (wave >= 4) run(T{}, F{});
-    else run(T{}, T{});
+    }
+    if (pending) { while (cp_u < cp_n) copy_batch(); }
+}
+
+}  // namespace
+
+// FAST: cols == 128, rows a multiple of 32, 16-byte aligned columns — aligned 16-byte loads without bounds checks.
+template <bool FAST>
+__global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
+    __shared__ __attribute__((aligned(16))) double panel[2 * PANEL];
+    __shared__ __attribute__((aligned(16))) double stage[STAGE_CAP + 2];
+    __shared__ double cvec[2 * CK];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int n = (int)p.cols;                                // <= 128
+    const int nchunk = (int)max((int64_t)1, (p.rows + CK - 1) / CK);
+    Shared sh{panel, stage, cvec};
+    // every wave executes the same number of barriers: one to start, one per phase, one more in the last phase of every instance
+    if (wave == 0) matrix_wave<0, FAST>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 1) matrix_wave<1, FAST>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 2) matrix_wave<2, FAST>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 3) matrix_wave<3, FAST>(p, sh, tid & 63, n, nchunk);
+    else if (wave < 6) loader_waves<FAST>(p, sh, tid - NH, n, nchunk);
+    else storer_waves(p, sh, tid - NH - NL, n, nchunk);
 }
 
 static int cu_count() {
@@ -352,5 +511,11 @@ int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols,
     else PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<false>, grid, dim3(NT), 0, s, p);
     return check_launch("batch_small_kernel");
 }
+
+#if PMT_BS_TRACE
+extern "C" int pmt_debug_bs_trace(long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_trace), sizeof(long long) * 2 * 8192) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // namespace pmt
