@@ -353,6 +353,26 @@ int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const vo
                       size_t height);
 int pmt_plan_synchronize(pmt_plan *plan);
 
+/* Staged (overlapped) uploads of host-updated Parameter values — `Parameter(model, val=buf)` / `Parameter(f, val, model)`,
+ * src/parameter.jl:57,88,101-102: the user (or f) rewrites a host buffer between solves and update!() reads it when the Parameter is
+ * evaluated.  pmt_plan_upload puts that PCIe copy on the plan's stream, serially in front of the kernels.  A staged upload goes through
+ * the plan's COPY stream into a second device buffer (`device_staging`, same size / pitch as the Parameter's buffer) and therefore runs
+ * while the kernels of the previous re-evaluation are still busy; the next update consumes it on the plan's stream:
+ *     pmt_plan_stage_upload[_2d]   copy stream: waits until the previous commit has read the staging buffer, H2D, records "staged"
+ *     pmt_plan_wait_staged         plan stream: waits for every staged upload issued so far
+ *     pmt_plan_commit_staged       pmt_plan_wait_staged + device-to-device copy staging -> Parameter buffer (a Parameter that needs a
+ *                                  transposition / permutation anyway runs that kernel from the staging buffer instead)
+ *     pmt_plan_staging_consumed    plan stream: records "consumed" behind the commits (call once after the last commit of an update)
+ *     pmt_plan_staged_synchronize  host: blocks until the staged uploads have left the HOST buffers (which may then be overwritten)
+ * The host buffers must be page-locked (pmt_host_alloc) for the copy to be asynchronous. */
+int pmt_plan_stage_upload(pmt_plan *plan, void *device_staging, const void *host_src, size_t bytes);
+int pmt_plan_stage_upload_2d(pmt_plan *plan, void *device_staging, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes,
+                             size_t height);
+int pmt_plan_wait_staged(pmt_plan *plan);
+int pmt_plan_commit_staged(pmt_plan *plan, void *device_dst, const void *device_staging, size_t bytes);
+int pmt_plan_staging_consumed(pmt_plan *plan);
+int pmt_plan_staged_synchronize(pmt_plan *plan);
+
 /* recording: between begin_record and end_record every pmt_*_f64 call issued with stream ==
  * pmt_plan_recording_stream(plan) is appended to the plan's tape instead of being launched */
 int pmt_plan_begin_record(pmt_plan *plan);

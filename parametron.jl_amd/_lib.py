@@ -103,6 +103,12 @@ SIGNATURES = {
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
+    "pmt_plan_stage_upload": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_stage_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    "pmt_plan_wait_staged": (_ci, [_vp]),
+    "pmt_plan_commit_staged": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_staging_consumed": (_ci, [_vp]),
+    "pmt_plan_staged_synchronize": (_ci, [_vp]),
     "pmt_plan_begin_record": (_ci, [_vp]),
     "pmt_plan_end_record": (_ci, [_vp]),
     "pmt_plan_recording_stream": (_vp, [_vp]),

@@ -34,33 +34,38 @@ __device__ __forceinline__ void store8(u64 *p, u64 v) {
 }
 
 // MODE 0: LinearTerm output   MODE 1: VectorAffineTerm output
-template <int MODE, bool NT>
+// TR: rows per tile (64, or 32 for blocks that would otherwise give fewer than ~4 workgroups per CU: the 512 x 4096 constraint block
+// of config 2 is 512 tiles of 64 x 64 — two per CU, 8 waves, tail-dominated: 19 us inside the step against 13 us when it had the
+// chip to itself; with 32-row tiles 1024 workgroups of half the LDS)
+template <int MODE, bool NT, int TR>
 __global__ __launch_bounds__(256) void affine_tile_kernel(
     const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
     const int64_t *__restrict__ xvar, const double *__restrict__ b, int sign,
     const int64_t *__restrict__ varmap, int64_t row_offset,
     u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out) {
-    __shared__ double tile[TILE * PITCH];
+    __shared__ double tile[TR * PITCH];
     __shared__ u64 vmx[TILE];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int64_t c0 = (int64_t)blockIdx.x * TILE;
-    const int64_t r0 = (int64_t)blockIdx.y * TILE;
-    const int nr = (int)min((int64_t)TILE, rows - r0);
+    const int64_t r0 = (int64_t)blockIdx.y * TR;
+    const int nr = (int)min((int64_t)TR, rows - r0);
     const int nc = (int)min((int64_t)TILE, cols - c0);
-    const bool full = (nr == TILE) && (nc == TILE);
+    const bool full = (nr == TR) && (nc == TILE);
 
     // ---- load phase: column-major A tile -> LDS tile[row][col]
     if (full && vec_in) {
-        const int cg = t >> 5;             // 0..7 : column within the group of 8
-        const int lr = (t & 31) * 2;       // row pair
+        constexpr int TPC = TR / 2;        // threads per column (16-byte pieces of a column segment)
+        constexpr int CPI = 256 / TPC;     // columns per iteration
+        const int cg = t / TPC;            // column within the group
+        const int lr = (t % TPC) * 2;      // row pair
         const double *base = A + (c0 + cg) * lda + r0 + lr;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            f64x2 v = *reinterpret_cast<const f64x2 *>(base + (int64_t)it * 8 * lda);
-            const int c = it * 8 + cg;
+        for (int it = 0; it < TILE / CPI; ++it) {
+            f64x2 v = *reinterpret_cast<const f64x2 *>(base + (int64_t)it * CPI * lda);
+            const int c = it * CPI + cg;
             tile[lr * PITCH + c] = v.x;
             tile[(lr + 1) * PITCH + c] = v.y;
         }
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
     } else {
         if (full && vec_out) {
             // rows in pairs: 3 full-wave 16-byte stores per pair (row segment = 192 qwords = 96 chunks)
-            for (int rp = wave * 2; rp < TILE; rp += 8) {
+            for (int rp = wave * 2; rp < TR; rp += 8) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     int r, chunk;
@@ -247,13 +252,16 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
     if (rows == 0 || cols == 0) return PMT_OK;   // cols == 0 (constants only) is handled by the callers
     const int vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
     const int vec_out = ((reinterpret_cast<uintptr_t>(out_terms) & 15) == 0 && (cols & 1) == 0) ? 1 : 0;
-    dim3 grid((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TILE));
-    if (env_nt())
-        PMT_LAUNCH_NAMED(MODE == 0 ? "affine_tile_kernel<LT>" : "affine_tile_kernel<VAT>", (affine_tile_kernel<MODE, true>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
-                           reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
-    else
-        PMT_LAUNCH_NAMED(MODE == 0 ? "affine_tile_kernel<LT>" : "affine_tile_kernel<VAT>", (affine_tile_kernel<MODE, false>), grid, dim3(256), 0, s, A, lda, rows, cols, xvar, b, sign, varmap, row_offset,
-                           reinterpret_cast<u64 *>(out_terms), out_consts, vec_in, vec_out);
+    const char *name = MODE == 0 ? "affine_tile_kernel<LT>" : "affine_tile_kernel<VAT>";
+    u64 *out = reinterpret_cast<u64 *>(out_terms);
+    // small blocks: 32-row tiles, twice the workgroups (see the kernel's comment); ~1024 = 4 per CU is where 64-row tiles start to fill the chip
+    const bool small = cdiv(cols, TILE) * cdiv(rows, TILE) < 1024 && rows > 32;
+#define AFFINE_LAUNCH(NTV, TRV)                                                                                                          \
+    PMT_LAUNCH_NAMED(name, (affine_tile_kernel<MODE, NTV, TRV>), dim3((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TRV)), dim3(256), 0, s, A, lda, \
+                     rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out)
+    if (env_nt()) { if (small) AFFINE_LAUNCH(true, 32); else AFFINE_LAUNCH(true, 64); }
+    else { if (small) AFFINE_LAUNCH(false, 32); else AFFINE_LAUNCH(false, 64); }
+#undef AFFINE_LAUNCH
     return check_launch("affine_tile_kernel");
 }
 

@@ -654,7 +654,11 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     else if (variant == 1) SK_LAUNCH(2, 16, PMT_SK_WPS);
     else SK_LAUNCH(2, 32, 2);
 #else
-    PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    // 32-row stages pay off for tall matrices (+1 % at r = 16384, -3 % at r = 4096: profiles/r01b_gram_variants.txt); same summation order,
+    // same bits.  (Keeping this second instantiation also keeps the register allocation of the first at 246 VGPRs: compiled alone it takes
+    // 256 + 7 spilled, and the two 16-VGPR kernels of the node's side stream are no longer co-resident with it — measured +9 % per step.)
+    if (rows >= 16384) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 32, 2, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
 #endif
 #ifdef PMT_TUNING
 #undef SK_LAUNCH

@@ -35,6 +35,11 @@ struct pmt_plan {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     char recording_tag = 0;   // &recording_tag is the recording handle
+    // staged (overlapped) uploads of host-updated Parameter values: a copy stream of its own and two events
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged = nullptr;     // recorded on the copy stream behind every staged upload
+    hipEvent_t consumed = nullptr;   // recorded on the plan stream behind every commit (the staging buffer may be overwritten after it)
+    bool consumed_recorded = false;
 };
 
 namespace pmt {
@@ -216,6 +221,9 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     }
     (void)hipSetDevice(plan->device);
     (void)hipStreamSynchronize(plan->stream);
+    if (plan->copy_stream) { (void)hipStreamSynchronize(plan->copy_stream); (void)hipStreamDestroy(plan->copy_stream); }
+    if (plan->staged) (void)hipEventDestroy(plan->staged);
+    if (plan->consumed) (void)hipEventDestroy(plan->consumed);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
     for (void *p : plan->allocations) (void)hipFree(p);
@@ -305,6 +313,89 @@ extern "C" int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitc
     if (width_bytes == 0 || height == 0) return PMT_OK;
     PMT_REQUIRE(host_dst && device_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_fetch_2d: bad argument");
     PMT_HIP_CHECK(hipMemcpy2DAsync(host_dst, dst_pitch, device_src, src_pitch, width_bytes, height, hipMemcpyDeviceToHost, plan->stream));
+    return PMT_OK;
+}
+
+// ---- staged uploads: host-updated Parameters without the serial PCIe copy (src/parameter.jl:88,101-102) ------------
+// The reference's `Parameter(model, val=buf)` is a host buffer the user overwrites between solves; update!() reads it when the Parameter
+// is evaluated.  Uploading it on the plan's stream puts the PCIe copy serially in front of the kernels (config 2 with host-updated A, b,
+// C, d: 151 MB = 2.4 ms before 1.25 ms of kernels).  A STAGED upload goes through a copy stream into a second device buffer instead and
+// can therefore run while the previous re-evaluation's kernels are still busy; the next update commits it with a device-to-device copy
+// (or the transposition / permutation kernel the Parameter needs anyway) on the plan's stream, ordered by events:
+//     copy stream:  [wait consumed(k-1)] H2D values(k) -> staging   [record staged]
+//     plan stream:  [wait staged] staging -> parameter buffer [record consumed]   kernels(k) ...
+static int ensure_copy_stream(pmt_plan *plan) {
+    if (plan->copy_stream) return PMT_OK;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking));
+    PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->staged, hipEventDisableTiming));
+    PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->consumed, hipEventDisableTiming));
+    return PMT_OK;
+}
+
+static int stage_prologue(pmt_plan *plan) {
+    if (int rc = ensure_copy_stream(plan)) return rc;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    // the staging buffers may still be being read by the commits of the previous update
+    if (plan->consumed_recorded) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed, 0));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_stage_upload(pmt_plan *plan, void *device_staging, const void *host_src, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_stage_upload: null plan");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(device_staging && host_src, PMT_INVALID_ARGUMENT, "plan_stage_upload: null pointer");
+    if (int rc = stage_prologue(plan)) return rc;
+    PMT_HIP_CHECK(hipMemcpyAsync(device_staging, host_src, bytes, hipMemcpyHostToDevice, plan->copy_stream));
+    PMT_HIP_CHECK(hipEventRecord(plan->staged, plan->copy_stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_stage_upload_2d(pmt_plan *plan, void *device_staging, size_t dst_pitch, const void *host_src, size_t src_pitch,
+                                        size_t width_bytes, size_t height) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_stage_upload_2d: null plan");
+    if (width_bytes == 0 || height == 0) return PMT_OK;
+    PMT_REQUIRE(device_staging && host_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_stage_upload_2d: bad argument");
+    if (int rc = stage_prologue(plan)) return rc;
+    PMT_HIP_CHECK(hipMemcpy2DAsync(device_staging, dst_pitch, host_src, src_pitch, width_bytes, height, hipMemcpyHostToDevice, plan->copy_stream));
+    PMT_HIP_CHECK(hipEventRecord(plan->staged, plan->copy_stream));
+    return PMT_OK;
+}
+
+// plan stream: wait for every staged upload issued so far; the caller then enqueues whatever consumes the staging buffers on the plan's
+// stream (pmt_plan_commit_staged, or a transposition / permutation kernel) and finishes with pmt_plan_staging_consumed
+extern "C" int pmt_plan_wait_staged(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_wait_staged: null plan");
+    if (!plan->copy_stream) return PMT_OK;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->staged, 0));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_commit_staged(pmt_plan *plan, void *device_dst, const void *device_staging, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_commit_staged: null plan");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(device_dst && device_staging, PMT_INVALID_ARGUMENT, "plan_commit_staged: null pointer");
+    if (int rc = pmt_plan_wait_staged(plan)) return rc;
+    PMT_HIP_CHECK(hipMemcpyAsync(device_dst, device_staging, bytes, hipMemcpyDeviceToDevice, plan->stream));
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_staging_consumed(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_staging_consumed: null plan");
+    if (int rc = ensure_copy_stream(plan)) return rc;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipEventRecord(plan->consumed, plan->stream));
+    plan->consumed_recorded = true;
+    return PMT_OK;
+}
+
+// host: block until the staged uploads issued so far have left the HOST buffers (which may then be overwritten)
+extern "C" int pmt_plan_staged_synchronize(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_staged_synchronize: null plan");
+    if (!plan->copy_stream) return PMT_OK;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipStreamSynchronize(plan->copy_stream));
     return PMT_OK;
 }
 

@@ -45,6 +45,10 @@ __global__ void sparse_assemble_kernel(const double *__restrict__ nzval, const i
 // eventually used in full.  Within a row the terms of a slab are contiguous in the row-major output, so a wave owns a (row, slab)
 // segment: it stages 64 coefficients and variable indices in LDS and writes the 24-byte terms as 16-byte chunks.
 // slab_ptr[row * (nslab + 1) + s] = index of the first term of `row` whose column lies in slab s (host, once: pmt_sparse_slab_ptr).
+// Round 2: the kernel was LATENCY bound, not bandwidth bound (46 us = 2.9 TB/s at config 5): a wave walked its four row segments one
+// 64-term chunk at a time, and every chunk is a chain of two dependent memory round trips (perm[t], then nzval[perm[t]]) before its
+// store.  Now the four rows of a wave advance together ("rounds"): four independent perm / variable-index loads are in flight, then four
+// gathers, and the index loads of the NEXT round are issued before the current round is staged and written.
 constexpr int SP_ROWS_PER_WAVE = 4;
 
 template <bool VAT_OUT>
@@ -53,49 +57,63 @@ __global__ __launch_bounds__(256) void sparse_slab_kernel(const double *__restri
                                                           int64_t rows, int nslab, const int64_t *__restrict__ varmap, int64_t row_offset,
                                                           unsigned long long *__restrict__ out) {
     typedef unsigned long long u64;
-    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     constexpr int W = VAT_OUT ? 3 : 2;                           // 8-byte words per term
+    constexpr int R = SP_ROWS_PER_WAVE;
     __shared__ u64 s_coeff[4][64];
     __shared__ u64 s_var[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slab = blockIdx.x % nslab;
-    const int64_t rowbase = ((int64_t)(blockIdx.x / nslab) * 4 + wave) * SP_ROWS_PER_WAVE;
-    for (int i = 0; i < SP_ROWS_PER_WAVE; ++i) {
+    const int64_t rowbase = ((int64_t)(blockIdx.x / nslab) * 4 + wave) * R;
+    int64_t t0[R], t1[R];
+    int64_t longest = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
         const int64_t row = rowbase + i;
-        if (row >= rows) break;
-        const int64_t t0 = slab_ptr[row * (nslab + 1) + slab], t1 = slab_ptr[row * (nslab + 1) + slab + 1];
-        const u64 rowword = (u64)(row_offset + row + 1);
-        for (int64_t ts = t0; ts < t1; ts += 64) {
-            const int cnt = (int)min((int64_t)64, t1 - ts);
+        t0[i] = t1[i] = 0;
+        if (row < rows) { t0[i] = slab_ptr[row * (nslab + 1) + slab]; t1[i] = slab_ptr[row * (nslab + 1) + slab + 1]; }
+        longest = max(longest, t1[i] - t0[i]);
+    }
+    // index loads of round 0
+    int64_t pidx[R], var[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int64_t t = t0[i] + lane;
+        const bool ok = t < t1[i];
+        pidx[i] = ok ? perm[t] : 0;
+        var[i] = ok ? term_var[t] : 1;
+    }
+    for (int64_t base = 0; base < longest; base += 64) {
+        double val[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) val[i] = (t0[i] + base + lane < t1[i]) ? nzval[pidx[i]] : 0.0;      // four independent gathers
+        int64_t pn[R], vn[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {                                                                   // next round's indices, in flight meanwhile
+            const int64_t t = t0[i] + base + 64 + lane;
+            const bool ok = t < t1[i];
+            pn[i] = ok ? perm[t] : 0;
+            vn[i] = ok ? term_var[t] : 1;
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int64_t ts = t0[i] + base;
+            const int cnt = (int)max((int64_t)0, min((int64_t)64, t1[i] - ts));
+            if (cnt == 0) continue;                                                                     // wave-uniform
             if (lane < cnt) {
-                const int64_t t = ts + lane;
-                s_coeff[wave][lane] = (u64)__double_as_longlong(nzval[perm[t]]);
-                const int64_t v = term_var[t];
-                s_var[wave][lane] = (u64)(VAT_OUT ? map_var(varmap, v) : v);
+                s_coeff[wave][lane] = (u64)__double_as_longlong(val[i]);
+                s_var[wave][lane] = (u64)(VAT_OUT ? map_var(varmap, var[i]) : var[i]);
             }
             __builtin_amdgcn_wave_barrier();                      // one wave: LDS writes above are visible to its own reads below
-            u64 *seg = out + ts * W;
-            const int nwords = cnt * W;
-            auto word = [&](int q) -> u64 {
+            const u64 rowword = (u64)(row_offset + rowbase + i + 1);
+            wave_write_words<W>(out + ts * W, cnt, lane, [&](int q) -> u64 {
                 const int t = q / W, f = q - W * t;
                 if (VAT_OUT) return f == 0 ? rowword : (f == 1 ? s_coeff[wave][t] : s_var[wave][t]);
                 return f == 0 ? s_coeff[wave][t] : s_var[wave][t];
-            };
-            const int lead = (int)((reinterpret_cast<uintptr_t>(seg) >> 3) & 1);
-            if (lead && lane == 0) seg[0] = word(0);
-            for (int c = lane; lead + 2 * c < nwords; c += 64) {
-                const int q0 = lead + 2 * c;
-                if (q0 + 1 < nwords) {
-                    u64x2 v;
-                    v.x = word(q0);
-                    v.y = word(q0 + 1);
-                    *reinterpret_cast<u64x2 *>(seg + q0) = v;
-                } else {
-                    seg[q0] = word(q0);
-                }
-            }
+            });
             __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
+        for (int i = 0; i < R; ++i) { pidx[i] = pn[i]; var[i] = vn[i]; }
     }
 }
 

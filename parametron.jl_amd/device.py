@@ -22,6 +22,8 @@ class DeviceContext:
         self.rec = C.c_void_p(self.lib.pmt_plan_recording_stream(self.plan))
         self.recording = False
         self._keep = []          # host arrays that must outlive asynchronous uploads
+        self._keep_staged = []   # ... and staged uploads (copy stream)
+        self._staging_dirty = False
 
     def close(self):
         if self.plan:
@@ -83,6 +85,28 @@ class DeviceContext:
     def synchronize(self):
         _lib.call("pmt_plan_synchronize", self.plan)
         self._keep.clear()
+
+    # ---- staged uploads (copy stream; include/parametron_hip.h "Staged (overlapped) uploads")
+    def stage_upload(self, staging_ptr, host):
+        host = np.ascontiguousarray(host)
+        if host.nbytes == 0:
+            return
+        self._keep_staged.append(host)
+        _lib.call("pmt_plan_stage_upload", self.plan, C.c_void_p(staging_ptr), host.ctypes.data_as(C.c_void_p), host.nbytes)
+
+    def commit_staged(self, dptr, staging_ptr, nbytes):
+        _lib.call("pmt_plan_commit_staged", self.plan, C.c_void_p(dptr), C.c_void_p(staging_ptr), int(nbytes))
+
+    def wait_staged(self):
+        _lib.call("pmt_plan_wait_staged", self.plan)
+
+    def staging_consumed(self):
+        _lib.call("pmt_plan_staging_consumed", self.plan)
+
+    def staged_synchronize(self):
+        """host: the staged uploads issued so far have left the host buffers"""
+        _lib.call("pmt_plan_staged_synchronize", self.plan)
+        self._keep_staged.clear()
 
     # ---- launches: immediate on the plan's stream, or appended to the tape while recording
     def launch_stream(self):
@@ -188,6 +212,40 @@ class DMat(DV):
         ctx._keep.append(m)
         _lib.call("pmt_plan_upload_2d", ctx.plan, C.c_void_p(self.buf), 8 * self.lda, m.ctypes.data_as(C.c_void_p), 8 * self.rows,
                   8 * self.rows, self.cols)
+
+    def stage(self, ctx, m):
+        """start a STAGED upload of the value (copy stream): a column-major array goes into a second buffer with the padded layout, a
+        row-major one is staged as it is and transposed by the commit"""
+        m = np.asarray(m, dtype=np.float64)
+        if not (self.rows and self.cols):
+            self._staged_kind = None
+            return
+        if m.flags.c_contiguous and not m.flags.f_contiguous:
+            if getattr(self, "_stage", None) is None:
+                self._stage = ctx.alloc(8 * self.rows * self.cols)
+            ctx.stage_upload(self._stage, m)
+            self._staged_kind = "rowmajor"
+            return
+        if getattr(self, "_staging", None) is None:
+            self._staging = ctx.alloc(8 * self.lda * self.cols)
+            if self.lda != self.rows:
+                ctx.zero(self._staging, 8 * self.lda * self.cols)
+                ctx.synchronize()                                  # (setup: the padding rows are zero before the copy stream writes beside them)
+        m = np.asfortranarray(m)
+        ctx._keep_staged.append(m)
+        _lib.call("pmt_plan_stage_upload_2d", ctx.plan, C.c_void_p(self._staging), 8 * self.lda, m.ctypes.data_as(C.c_void_p), 8 * self.rows,
+                  8 * self.rows, self.cols)
+        self._staged_kind = "colmajor"
+
+    def commit(self, ctx):
+        """plan stream: the staged value becomes the Parameter's value"""
+        kind = getattr(self, "_staged_kind", None)
+        if kind == "rowmajor":
+            ctx.wait_staged()
+            _lib.call("pmt_transpose_f64", C.c_void_p(self._stage), self.cols, self.cols, self.rows, C.c_void_p(self.buf), self.lda, ctx.stream)
+        elif kind == "colmajor":
+            ctx.commit_staged(self.buf, self._staging, 8 * self.lda * self.cols)
+        self._staged_kind = None
 
     def fetch(self, ctx):
         out = np.empty((self.rows, self.cols), dtype=np.float64, order="F")

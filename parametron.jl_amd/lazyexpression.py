@@ -122,6 +122,13 @@ def device_value_of(x, ctx=None):
         return x.out
     if isinstance(x, Parameter):
         ctx = ctx or x.model.device()
+        if getattr(x, "_staged_pending", False) and x._dev is not None:
+            # the value of this solve was evaluated and put on the copy stream by Model.stage_parameters(): consume it on the plan's stream
+            _commit_staged_value(ctx, x._dev)
+            x._staged_pending = False
+            x._dev_version = x.version
+            ctx._staging_dirty = True
+            return x._dev
         val = Parameter.__call__(x)                 # evalarg(::Parameter) (src/lazyexpression.jl:51)
         if x._dev is None:
             if getattr(x, "device_resident", False):
@@ -174,6 +181,40 @@ def _upload_value(ctx, dv, val):
         ctx.upload(dv.buf, np.asarray(val.data, dtype=np.float64))
     else:
         raise ArgumentError("cannot upload into %s" % type(dv).__name__)
+
+
+def _stage_value(ctx, dv, val):
+    """Start the staged upload of a host value (copy stream) into the second buffer of its device mirror."""
+    if isinstance(dv, DMat):
+        m = np.asarray(val, dtype=np.float64)
+        if m.shape != (dv.rows, dv.cols):
+            raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.rows, dv.cols), m.shape))
+        dv.stage(ctx, m)
+        return
+    if isinstance(dv, DNum):
+        host, nbytes = np.array([val], dtype=np.float64), 8
+    elif isinstance(dv, DVec):
+        host = np.asarray(val, dtype=np.float64)
+        if host.shape != (dv.n,):
+            raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.n,), host.shape))
+        nbytes = 8 * dv.n
+    elif isinstance(dv, DSpMat):
+        if not dv.same_pattern(val):
+            raise DimensionMismatch("the sparsity pattern of a sparse Parameter must stay fixed across re-evaluations")
+        host, nbytes = np.asarray(val.data, dtype=np.float64), 8 * dv.nnz
+    else:
+        raise ArgumentError("cannot stage an upload into %s" % type(dv).__name__)
+    if getattr(dv, "_staging", None) is None:
+        dv._staging = ctx.alloc(max(nbytes, 8))
+    dv._staged_bytes = nbytes
+    ctx.stage_upload(dv._staging, host)
+
+
+def _commit_staged_value(ctx, dv):
+    if isinstance(dv, DMat):
+        dv.commit(ctx)
+    elif getattr(dv, "_staged_bytes", 0):
+        ctx.commit_staged(dv.buf, dv._staging, dv._staged_bytes)
 
 
 def const_device_value(ctx, x):

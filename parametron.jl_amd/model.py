@@ -172,6 +172,36 @@ class Model:
         for p in self.params:
             p.setdirty()
 
+    # ---- overlapped uploads of host-updated Parameters
+    def stage_parameters(self):
+        """Evaluate the host-updated Parameters NOW — exactly what the next update!() would do with them (setdirty! + call,
+        src/parameter.jl:93-104) — and start copying their values to the device on the plan's COPY stream.  The call returns at once; the
+        PCIe copy runs while the device is still busy with the previous re-evaluation, and the next update!() / solve!() consumes the
+        staged values on the device instead of uploading (they are not evaluated a second time).  Call it as soon as the values of the
+        next solve are in their host buffers; the buffers must not be overwritten again before wait_staged() returns (page-locked
+        buffers from parameter_array() make the copy truly asynchronous).  Without this call nothing changes: update!() uploads serially."""
+        if not self.initialized:
+            raise ErrorException("stage_parameters needs an initialized model (call initialize!(model) or solve!(model) once)")
+        if not self._records:
+            return
+        from .lazyexpression import _stage_value
+        from .parameter import DerivedParameter
+        ctx = self.device()
+        if len(ctx._keep_staged) > 64:           # the caller never waits: do not let the references to old host values pile up
+            ctx.staged_synchronize()
+        for x in self._order:
+            if not isinstance(x, Parameter) or getattr(x, "device_resident", False) or isinstance(x, DerivedParameter) or x._dev is None:
+                continue
+            x.setdirty()
+            val = Parameter.__call__(x)
+            _stage_value(ctx, x._dev, val)
+            x._staged_pending = True
+
+    def wait_staged(self):
+        """Block until the staged uploads have left the host buffers (which may then be overwritten for the solve after next)."""
+        if self._ctx is not None:
+            self._ctx.staged_synchronize()
+
     def addparameter(self, p):                                         # src/model.jl:42
         self.params.append(p)
         return p
@@ -274,9 +304,13 @@ class Model:
     def _refresh_parameters(self):
         ctx = self.device()
         from .lazyexpression import device_value_of
+        ctx._staging_dirty = False
         for x in self._order:
             if isinstance(x, Parameter):
                 device_value_of(x, ctx)
+        if ctx._staging_dirty:
+            ctx.staging_consumed()               # behind the commits: the staging buffers may be overwritten by the next stage_parameters()
+            ctx._staging_dirty = False
 
     def _run_tape(self, fetch=True):
         ctx = self.device()
@@ -290,14 +324,17 @@ class Model:
         for r in self._records:
             r.finish_fetch()
 
-    def update(self):                                                  # src/model.jl:132-143
-        self.setdirty()
+    def update(self, synchronize=True):                                # src/model.jl:132-143
+        for p in self.params:                                          # setdirty!(model) — except what stage_parameters() has already
+            if not getattr(p, "_staged_pending", False):               # evaluated for this solve
+                p.setdirty()
         if self.device_qp is not None:
             # device hand-off: the MOI buffers never leave HBM; the solver's CSC data is rebuilt right behind the tape
             if self._records:
                 self._run_tape(fetch=False)
             self.device_qp.refresh()
-            self.device().synchronize()
+            if synchronize:                                            # synchronize=False: the caller overlaps the next stage_parameters()
+                self.device().synchronize()                            # with this re-evaluation and synchronises later
             if hasattr(self.optimizer, "set_device_qp"):
                 self.optimizer.set_device_qp(self.device_qp)
             return
