@@ -325,6 +325,33 @@ int pmt_profile_filter(const char *substring);
 int64_t pmt_profile_report(char *host_buf, size_t cap);
 
 /* ---------------------------------------------------------------------------------------
+ * Multi-GPU exchange of the batched configuration (BASELINE config 4): one process per GPU, rank g owns the instances
+ * [g * per_rank, (g + 1) * per_rank); after the exchange every rank holds every slab (`gathered`: nranks * per_rank slabs of `stride`
+ * doubles, global instance order).  The reference has no counterpart (a batch is many independent Models, src/model.jl:1-22).
+ * RCCL (librccl.so, dlopen'ed on first use) is driven from inside the library: the host only carries the 128-byte unique id from
+ * rank 0 to the others (any launcher: torch.distributed, MPI, a file).  xGMI is point-to-point, so the exchange is the DIRECT schedule
+ * — one grouped ncclSend / ncclRecv pair per peer, each over that peer's own link — not a ring.
+ *   pmt_comm_unique_id        rank 0: a fresh id (128 bytes)
+ *   pmt_comm_init_rank        every rank; nranks == 1 needs neither an id nor RCCL
+ *   pmt_batch_num_chunks / pmt_batch_chunk_range / pmt_batch_gathered_offset
+ *                             the chunk schedule, pure host arithmetic: chunk c of a rank = local instances [c * chunk, min(., per_rank))
+ *                             (chunk <= 0: one chunk); the slab of global instance i sits at i * stride doubles of `gathered`
+ *   pmt_batch_allgather_f64   exchange of slabs that are already computed, chunk by chunk, enqueued on `stream`
+ *   pmt_batch_step_f64        pmt_batch_lsq_coeffs_f64 over this rank's instances chunk by chunk on `stream`, chunk c on the wire (the
+ *                             communicator's own stream) while chunk c + 1 is computed; `stream` is joined with the last exchange.
+ *                             `stream` must be a HIP stream (not a plan's recording handle).
+ * ------------------------------------------------------------------------------------- */
+int pmt_comm_unique_id(void *out_id_128_bytes);
+int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_128_bytes, int device, void **out_comm);
+int pmt_comm_destroy(void *comm);
+int64_t pmt_batch_num_chunks(int64_t per_rank, int64_t chunk);
+int pmt_batch_chunk_range(int64_t per_rank, int64_t chunk, int64_t c, int64_t *lo, int64_t *hi);
+int64_t pmt_batch_gathered_offset(int rank, int64_t per_rank, int64_t local_instance, int64_t stride);
+int pmt_batch_allgather_f64(void *comm, const double *local, double *gathered, int64_t per_rank, int64_t stride, int64_t chunk, void *stream);
+int pmt_batch_step_f64(void *comm, const double *A, const double *b, const double *C, const double *d, int64_t per_rank, int64_t n, int64_t r,
+                       int64_t m, int sign_b, int sign_d, double *local, double *gathered, int64_t stride, int64_t chunk, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Plan = a recorded re-evaluation: device buffers + a tape of the launches above.
  * Built once by the host from the lazy-expression DAG (↔ `dest = deepcopy(expr())` pre-allocation,
  * src/lazyexpression.jl:202,230,243), replayed by every update!(model) (src/model.jl:132-143) with no

@@ -102,6 +102,8 @@ def lib():
             "pmo_lsq_eval_objective": (ci, [vp, vp, vp, vp, ci, i64]),
             "pmo_lsq_eval_vecdot": (ci, [vp, i64]),
             "pmo_fill_uniform": (None, [vp, i64, C.c_uint64, f64]),
+            "pmo_canonical_quad_samples": (ci, [vp, i64, i64, i64, vp, vp, i64, vp, vp]),
+            "pmo_canonical_lin_samples": (ci, [vp, i64, i64, i64, vp, ci, vp, i64, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -431,6 +433,24 @@ def fill_uniform(n, seed, scale=1.0):
     out = np.empty(int(n), dtype=np.float64)
     lib().pmo_fill_uniform(_ptr(out), out.size, C.c_uint64(seed), scale)
     return out
+
+
+def canonical_quad_samples(A_colmajor, lda, rows, cols, pj, pk):
+    """MOI coefficients of the canonical quadratic terms at the sampled 1-based pairs (pj[i] <= pk[i]): (double-precision literal sum,
+    long-double sum of the same products) — see pmo_canonical_quad_samples."""
+    pj = np.ascontiguousarray(pj, dtype=np.int64)
+    pk = np.ascontiguousarray(pk, dtype=np.int64)
+    out, out_ld = np.empty(len(pj)), np.empty(len(pj))
+    _check(lib().pmo_canonical_quad_samples(_ptr(A_colmajor), int(lda), int(rows), int(cols), _ptr(pj), _ptr(pk), len(pj), _ptr(out), _ptr(out_ld)))
+    return out, out_ld
+
+
+def canonical_lin_samples(A_colmajor, lda, rows, cols, b, sign, pj):
+    """MOI coefficients of the canonical affine terms at the sampled 1-based variables: (double sum, long-double sum)."""
+    pj = np.ascontiguousarray(pj, dtype=np.int64)
+    out, out_ld = np.empty(len(pj)), np.empty(len(pj))
+    _check(lib().pmo_canonical_lin_samples(_ptr(A_colmajor), int(lda), int(rows), int(cols), _ptr(b), int(sign), _ptr(pj), len(pj), _ptr(out), _ptr(out_ld)))
+    return out, out_ld
 
 
 class LsqWorkspace:

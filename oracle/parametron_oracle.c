@@ -630,3 +630,63 @@ void pmo_fill_uniform(double *dst, int64_t n, uint64_t seed, double scale) {
     for (int64_t i = 0; i < n; i++)
         dst[i] = scale * ((double)(splitmix64(base + (uint64_t)i) >> 11) * 0x1.0p-53);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Canonical MOI coefficients of SAMPLED terms of residual . residual at sizes where the literal objective cannot be
+ * materialised (n = r = 4096: 1.65 TB).  For residual = A*x (+|-) b the literal function (functions.jl:702-709 over
+ * :548-576) holds, for every row i, the quadratic terms coeff = A[i,j]*A[i,k] at (j,k) for ALL ordered pairs and the
+ * affine terms (c_i*A[i,j], x_j) twice (:566-573), c_i = 0.0 (+|-) b[i].  canonicalize! (:381-386, util.jl:9-26) adds up
+ * the terms that share an unordered pair {j,k} (resp. a variable) in QuickSort order — an order the reference does not
+ * specify — and the MOI copy doubles the diagonal (moi_interop.jl:58).  Restated per sampled pair, one product per
+ * literal term, summed in row order, the (j,k) term of a row before its (k,j) term; no FMA (-ffp-contract=off):
+ *     off-diagonal (j < k):  sum_i [ A[i,j]*A[i,k] ] + [ A[i,k]*A[i,j] ]  (2r terms)
+ *     diagonal     (j = k):  2 * sum_i A[i,j]*A[i,j]                      (r terms, then the MOI doubling)
+ *     affine       j:        sum_i [ c_i*A[i,j] ] + [ c_i*A[i,j] ]        (2r terms)
+ * `out` gets that double-precision sum; `out_ld` (optional) the same sum of the SAME rounded products accumulated in
+ * long double — the reference point for "how far is any summation order from the exact sum of the literal terms".
+ * A is column-major with leading dimension lda; pairs are 1-based positions (j <= k). */
+int pmo_canonical_quad_samples(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *pj, const int64_t *pk,
+                               int64_t npairs, double *out, double *out_ld) {
+    if (rows < 0 || cols < 0 || lda < rows) return PMO_DIMENSION_MISMATCH;
+    for (int64_t p = 0; p < npairs; p++) {
+        int64_t j = pj[p] - 1, k = pk[p] - 1;
+        if (j < 0 || k < j || k >= cols) return PMO_ARGUMENT_ERROR;
+        const double *aj = A + j * lda, *ak = A + k * lda;
+        double s = 0.0;
+        long double sl = 0.0L;
+        if (j == k) {
+            for (int64_t i = 0; i < rows; i++) { double pr = aj[i] * aj[i]; s = s + pr; sl += (long double)pr; }
+            s = 2 * s; sl = 2 * sl;
+        } else {
+            for (int64_t i = 0; i < rows; i++) {
+                double p1 = aj[i] * ak[i], p2 = ak[i] * aj[i];
+                s = s + p1; s = s + p2;
+                sl += (long double)p1; sl += (long double)p2;
+            }
+        }
+        out[p] = s;
+        if (out_ld) out_ld[p] = (double)sl;
+    }
+    return PMO_OK;
+}
+
+int pmo_canonical_lin_samples(const double *A, int64_t lda, int64_t rows, int64_t cols, const double *b, int sign, const int64_t *pj,
+                              int64_t n, double *out, double *out_ld) {
+    if (rows < 0 || cols < 0 || lda < rows) return PMO_DIMENSION_MISMATCH;
+    for (int64_t p = 0; p < n; p++) {
+        int64_t j = pj[p] - 1;
+        if (j < 0 || j >= cols) return PMO_ARGUMENT_ERROR;
+        const double *aj = A + j * lda;
+        double s = 0.0;
+        long double sl = 0.0L;
+        for (int64_t i = 0; i < rows; i++) {
+            double c = sign > 0 ? 0.0 + b[i] : (sign < 0 ? 0.0 - b[i] : 0.0);
+            double pr = c * aj[i];
+            s = s + pr; s = s + pr;
+            sl += (long double)pr; sl += (long double)pr;
+        }
+        out[p] = s;
+        if (out_ld) out_ld[p] = (double)sl;
+    }
+    return PMO_OK;
+}

@@ -86,6 +86,14 @@ SIGNATURES = {
     "pmt_batch_lsq_slab_doubles": (_i64, [_i64, _i64]),
     "pmt_batch_lsq_coeffs_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
     "pmt_batch_expand_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_comm_unique_id": (_ci, [_vp]),
+    "pmt_comm_init_rank": (_ci, [_ci, _ci, _vp, _ci, C.POINTER(_vp)]),
+    "pmt_comm_destroy": (_ci, [_vp]),
+    "pmt_batch_num_chunks": (_i64, [_i64, _i64]),
+    "pmt_batch_chunk_range": (_ci, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "pmt_batch_gathered_offset": (_i64, [_ci, _i64, _i64, _i64]),
+    "pmt_batch_allgather_f64": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "pmt_batch_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _vp, _i64, _i64, _vp]),
     "pmt_consts_f64": (_ci, [_vp, _i64, _ci, _vp, _vp]),
     "pmt_fill_uniform_f64": (_ci, [_vp, _i64, _u64, _f64, _vp]),
     "pmt_fill_uniform_offset_f64": (_ci, [_vp, _i64, _u64, _u64, _f64, _vp]),

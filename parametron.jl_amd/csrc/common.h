@@ -34,6 +34,7 @@ int fail(int code, const std::string &msg);
 // appended to that plan's tape (plan.cpp).
 using Launch = std::function<int(hipStream_t)>;
 int dispatch(void *stream, Launch launch);
+bool is_recording_handle(void *stream);        // `stream` is a plan's recording handle, not a HIP stream
 
 // Per-kernel timing (the analogue of the reference's per-node `findallocs` report, src/debug.jl:4-23): when enabled
 // through pmt_profile_enable(), every launch is bracketed by HIP events on its own stream.

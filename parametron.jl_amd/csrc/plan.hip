@@ -83,6 +83,8 @@ int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream) 
     return PMT_OK;
 }
 
+bool is_recording_handle(void *stream) { return recording_plan(stream) != nullptr; }
+
 int dispatch(void *stream, Launch launch) {
     if (stream) {
         pmt_plan *plan = nullptr;

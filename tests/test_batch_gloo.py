@@ -55,6 +55,56 @@ def _worker(rank, world, port, total, n, r, m, q):
         dist.destroy_process_group()
 
 
+def _worker_chunked(rank, world, port, total, n, r, m, chunk, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import parametron_jl_amd  # noqa: F401
+    from parametron_jl_amd import batch
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        lo, hi = batch.shard_range(total, rank, world)
+        off, L = batch.slab_layout(n, m)
+        local = torch.from_numpy(np.stack([oracle_slab(i, n, r, m) for i in range(lo, hi)]))
+        gathered = torch.full((total, L), float("nan"), dtype=torch.float64)
+        batch.exchange_chunks(dist, local, gathered, rank, world, chunk)           # the library's chunk schedule, chunk by chunk
+        full = np.stack([oracle_slab(i, n, r, m) for i in range(total)])
+        q.put((rank, batch.chunk_schedule(hi - lo, chunk), bool(np.array_equal(gathered.numpy(), full))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,chunk,want", [(10, 2, [(0, 2), (2, 4), (4, 5)]), (10, 5, [(0, 5)]), (10, 0, [(0, 5)]), (14, 3, [(0, 3), (3, 6), (6, 7)])])
+def test_two_rank_chunked_exchange_follows_the_library_schedule(total, chunk, want):
+    """The N > 1 path of pmt_batch_step_f64 on CPU: the chunk schedule and the gathered offsets are the LIBRARY's own host functions
+    (pmt_batch_num_chunks / pmt_batch_chunk_range / pmt_batch_gathered_offset, the same calls comm.hip makes), driven here over gloo with
+    one send / receive pair per peer and chunk — chunk order, offsets, and an uneven last chunk."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, r, m = 5, 4, 2
+    procs = [ctx.Process(target=_worker_chunked, args=(rank, 2, port, total, n, r, m, chunk, q)) for rank in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r_[1] == want for r_ in results)                               # both ranks walk the same chunks in the same order
+    assert all(r_[2] for r_ in results)                                       # every rank holds every slab, in global instance order
+
+
+def test_chunk_schedule_edge_cases():
+    from parametron_jl_amd import batch
+    assert batch.chunk_schedule(0, 4) == []
+    assert batch.chunk_schedule(1024, 128) == [(k * 128, (k + 1) * 128) for k in range(8)]
+    assert batch.chunk_schedule(1000, 128)[-1] == (896, 1000)
+    assert batch.chunk_schedule(5, 100) == [(0, 5)]
+    assert batch.gathered_offset(3, 1024, 17, 10449) == (3 * 1024 + 17) * 10449
+
+
 def test_two_rank_instance_sharding_and_allgather():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

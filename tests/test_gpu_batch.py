@@ -146,3 +146,26 @@ def test_batch_many_instances_per_workgroup():
     assert np.array_equal(got[:, off["const"]], seq)
     assert np.array_equal(got[:, off["C"]:off["C"] + m * n].reshape(total, m, n), wl.Cm.view(total, n, m).transpose(1, 2).cpu().numpy())
     assert np.array_equal(got[:, off["dconst"]:], 0.0 - wl.d.view(total, m).cpu().numpy())
+
+
+def test_batch_step_through_the_library_communicator_single_rank():
+    """pmt_batch_step_f64 (computation in chunks + exchange on the communicator's stream) with one rank: the gathered buffer equals the
+    plain computation, for an uneven last chunk and for a single chunk; steps can be issued back to back."""
+    from parametron_jl_amd import batch
+    total, n, r, m = 37, 128, 64, 16
+    ref = batch.BatchLSQ(torch, total, n, r, m)
+    ref.compute()
+    torch.cuda.synchronize()
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.gathered = torch.full_like(wl.local, float("nan"))                  # a separate gathered buffer, as with world > 1
+    comm = batch.Communicator(torch, None, 0, 1, torch.cuda.current_device())
+    try:
+        for chunk in (8, 0, 37, 100):
+            wl.local.fill_(float("nan")); wl.gathered.fill_(float("nan"))
+            torch.cuda.synchronize()
+            wl.step_pipelined(comm, chunk)
+            wl.step_pipelined(comm, chunk)
+            torch.cuda.synchronize()
+            assert torch.equal(wl.gathered, ref.local) and torch.equal(wl.local, ref.local)
+    finally:
+        comm.close()

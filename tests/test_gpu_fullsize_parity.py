@@ -1,0 +1,100 @@
+"""-m gpu: the canonical objective at FULL size against a CPU sum — not against another GPU computation.
+
+At config 2 (n = r = 4096) the literal objective the reference would build is 1.65 TB, so the oracle restates the canonical
+coefficient of SAMPLED terms instead (oracle/parametron_oracle.c pmo_canonical_*_samples: one product per literal term, summed on
+the CPU in row order; src/functions.jl:548-576,702-709 + :381-386 + src/moi_interop.jl:58).  Tolerance: north_star's 1e-12
+relative.  The test also reports how far both sides are from the long-double sum of the same products (DESIGN.md records the
+figures): the worst-case bound of ANY summation order of 2r positive terms is ~2r * eps/2 = 4.5e-13 at r = 4096."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+
+def _gram(g, r, n, seedA=1, seedb=2, lda=None):
+    lda = lda or r
+    A, b = g.empty_f64(lda * n), g.empty_f64(r)
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(A), r, n, lda, C.c_uint64(seedA), 1.0, g.stream())
+    g.call("pmt_fill_uniform_f64", g.ptr(b), r, C.c_uint64(seedb), 1.0, g.stream())
+    xvar = torch.arange(1, n + 1, dtype=torch.int64, device=g.DEV)
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(g.lib().pmt_quad_gram_workspace_bytes(r, n) // 8)
+    g.call("pmt_quad_gram_f64", g.ptr(A), lda, r, n, g.ptr(xvar), g.ptr(b), -1, 1, None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), g.stream())
+    return g.terms_to_host(oq, nq, g.QT), g.terms_to_host(ol, n, g.LT), float(g.f64_to_host(oc, 1)[0])
+
+
+def _sample_pairs(rng, n, count):
+    j = rng.integers(1, n + 1, size=count)
+    k = rng.integers(1, n + 1, size=count)
+    j, k = np.minimum(j, k), np.maximum(j, k)
+    diag = rng.integers(1, n + 1, size=count // 10)                  # diagonal terms too (the MOI doubling)
+    edge = np.array([1, n, 1, n // 2, 127, 128, 129, n - 1])          # tile corners / edges
+    return np.concatenate([j, diag, edge[:4], edge[4:]]), np.concatenate([k, diag, [1, n, n, n // 2], [128, 128, 129, n]])
+
+
+@pytest.mark.parametrize("r,n,count", [(4096, 4096, 10000), (16384, 1024, 6000), (4090, 1000, 4000)])
+def test_canonical_objective_against_cpu_sampled_sums(r, n, count, record_property):
+    import gpu_util as g
+    q, l, const = _gram(g, r, n)
+    A = O.fill_uniform(r * n, 1)                                      # the same stream as the device fill, bit for bit
+    b = O.fill_uniform(r, 2)
+    rng = np.random.default_rng(r + n)
+    pj, pk = _sample_pairs(rng, n, count)
+    pos = (pj - 1) * n - ((pj - 1) * (pj - 2)) // 2 + (pk - pj)        # canonical row-major upper-triangular position
+    assert np.array_equal(q["row"][pos], pj) and np.array_equal(q["col"][pos], pk)          # indices exactly
+    want, want_ld = O.canonical_quad_samples(A, r, r, n, pj, pk)
+    got = q["coeff"][pos]
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(got, want_ld, rtol=1e-12, atol=0)
+    jl = np.arange(1, n + 1, dtype=np.int64)
+    lw, lw_ld = O.canonical_lin_samples(A, r, r, n, b, -1, jl)
+    assert np.array_equal(l["var"], jl)
+    np.testing.assert_allclose(l["coeff"], lw, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(l["coeff"], lw_ld, rtol=1e-12, atol=0)
+    seq = 0.0
+    for v in 0.0 - b:
+        seq = seq + v * v
+    assert const == seq                                               # the constant is a left-to-right sum: bit for bit
+    err_hip = float(np.max(np.abs(got - want_ld) / np.abs(want_ld)))
+    err_cpu = float(np.max(np.abs(want - want_ld) / np.abs(want_ld)))
+    err_lin = float(np.max(np.abs(l["coeff"] - lw_ld) / np.abs(lw_ld)))
+    print("\nr=%d n=%d: max rel. error vs long-double sum of the literal terms: HIP quadratic %.2e, CPU row-order sum %.2e, HIP affine %.2e; bound 2r*eps/2 = %.2e"
+          % (r, n, err_hip, err_cpu, err_lin, r * 2.220446049250313e-16))
+    record_property("max_rel_err_hip_quadratic", err_hip)
+    assert err_hip < 1e-12 and err_lin < 1e-12
+
+
+def test_config4_slabs_against_cpu_sampled_sums():
+    """Config 4: every coefficient of sampled instances' slabs against the oracle (all 8256 quadratic terms, all 128 affine terms,
+    the constant bit for bit, the constraint block exactly) — not against the single-instance HIP kernel."""
+    from parametron_jl_amd import batch
+    total, n, r, m = 8192, 128, 128, 16
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.compute()
+    torch.cuda.synchronize()
+    off, L = batch.slab_layout(n, m)
+    nq = n * (n + 1) // 2
+    iu = np.triu_indices(n)
+    for inst in (0, 1, 255, 256, 4097, total - 1):
+        slab = wl.local[inst].cpu().numpy()
+        A = O.fill_uniform((inst + 1) * r * n, 101)[inst * r * n:]
+        b = O.fill_uniform((inst + 1) * r, 102)[inst * r:]
+        Cm = O.fill_uniform((inst + 1) * m * n, 103)[inst * m * n:].reshape(n, m).T
+        d = O.fill_uniform((inst + 1) * m, 104, 2.0)[inst * m:]
+        want, want_ld = O.canonical_quad_samples(np.ascontiguousarray(A), r, r, n, iu[0] + 1, iu[1] + 1)
+        np.testing.assert_allclose(slab[:nq], want, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(slab[:nq], want_ld, rtol=1e-12, atol=0)
+        lw, lw_ld = O.canonical_lin_samples(np.ascontiguousarray(A), r, r, n, np.ascontiguousarray(b), -1, np.arange(1, n + 1))
+        np.testing.assert_allclose(slab[off["q"]:off["q"] + n], lw, rtol=1e-12, atol=0)
+        seq = 0.0
+        for v in 0.0 - b:
+            seq = seq + v * v
+        assert slab[off["const"]] == seq
+        assert np.array_equal(slab[off["C"]:off["C"] + m * n].reshape(m, n), Cm)
+        assert np.array_equal(slab[off["dconst"]:], 0.0 - d)

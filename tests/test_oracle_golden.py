@@ -422,3 +422,26 @@ def test_oracle_reproduces_the_independent_config1_golden_vectors():
     Q = g["Q"].reshape(n, n).T
     _, bq, _ = O.Quad().bilinearmul(Q, xi, xi).moi(vm)
     assert np.array_equal(bq.view(np.int64), g["bilinear_quad"].view(np.int64))
+
+
+def test_sampled_canonical_entries_equal_the_full_canonicalize():
+    """pmo_canonical_*_samples (used by the full-size GPU parity tests, where the literal objective cannot be materialised) against
+    canonicalize!(literal) + the MOI copy of the same oracle at sizes where the literal form exists: same indices, coefficients to
+    rounding (the summation ORDER is the only difference, and the reference's QuickSort does not pin one)."""
+    import numpy as np
+    from oracle import oracle as O
+    for n, r in ((6, 5), (17, 33), (40, 12)):
+        A = O.fill_uniform(r * n, 1)
+        b = O.fill_uniform(r, 2)
+        x = np.arange(1, n + 1, dtype=np.int64)
+        w = O.LsqWorkspace(n, r, 1)
+        w.eval_objective(A, b, x)
+        w.objective.canonicalize()
+        at, qt, _ = w.objective.moi()
+        iu = np.triu_indices(n)
+        assert np.array_equal(qt["row"], iu[0] + 1) and np.array_equal(qt["col"], iu[1] + 1)
+        q, q_ld = O.canonical_quad_samples(A, r, r, n, iu[0] + 1, iu[1] + 1)
+        np.testing.assert_allclose(q, qt["coeff"], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(q_ld, qt["coeff"], rtol=1e-14, atol=0)
+        l, l_ld = O.canonical_lin_samples(A, r, r, n, b, -1, x)
+        np.testing.assert_allclose(l, at["coeff"], rtol=1e-14, atol=0)
