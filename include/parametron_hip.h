@@ -224,6 +224,14 @@ int pmt_canonical_order_quadratic(int64_t n, const int64_t *host_rows, const int
                                   int64_t *host_out_rows, int64_t *host_out_cols, int64_t *nseg);
 int pmt_segment_sum_f64(const void *in_terms, int64_t in_stride_bytes, const int64_t *perm, const int64_t *seg_ptr, int64_t nseg,
                         void *out_terms, int64_t out_stride_bytes, void *stream);
+/* The same ordering computed ON THE DEVICE from the term buffer where it lies (no copy of the indices to the host, no single-threaded
+ * sort): a stable radix sort by the packed canonical key, the run boundaries by stream compaction.  perm: int64[n], seg_ptr: int64[n + 1],
+ * both device; *nseg_host receives the number of distinct terms (the only bytes that cross PCIe — the host sizes the output from them).
+ * Setup-time call on a HIP stream (synchronises).  PMT_INVALID_ARGUMENT when an index does not fit the packed key (>= 2^32): use the
+ * host functions above.  pmt_canonical_init_terms then writes the static part of the canonical function, out_terms[s] = (0.0, indices of
+ * run s), with the reference's conventions (a run of one keeps its original (row, col), util.jl:18-19). */
+int pmt_canonical_order_device(const void *terms, int64_t n, int term_bytes, int64_t *perm, int64_t *seg_ptr, int64_t *nseg_host, void *stream);
+int pmt_canonical_init_terms(const void *terms, int term_bytes, const int64_t *perm, const int64_t *seg_ptr, int64_t nseg, void *out_terms, void *stream);
 
 /* prune_zero!(f; atol) (src/functions.jl:294-297, 409-413): out_terms = the terms with abs(coeff) > atol, in order; *out_count (DEVICE
  * memory) = how many.  term_bytes: 16 (pmt_linear_term) or 24 (pmt_quadratic_term).  Not on the solve path: the count is data

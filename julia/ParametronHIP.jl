@@ -1,6 +1,8 @@
 # ParametronHIP.jl — the reference-side binding a Parametron.jl maintainer would add to route the update! hot path
-# through libparametron_hip.so (include/parametron_hip.h).  NOT EXECUTED in this repository's CI: the build image has no
-# Julia (SURVEY.md §0.4); the same C ABI is exercised from Python (parametron.jl_amd/_lib.py) by tests/.
+# through libparametron_hip.so (include/parametron_hip.h): the thin ccall layer.  ParametronHIPBackend.jl (next to this file) builds the
+# plan from a Parametron.Model and overrides update! / solve!.  The build image has no Julia (SURVEY.md §0.4): tests/test_cabi_exports.py
+# checks every ccall against the header statically (symbol, argument count, argument type classes), tests/test_gpu_julia.py runs
+# julia/example1_parity.jl when a julia binary exists on the GPU box; the same C ABI is exercised from Python by tests/.
 #
 # Usage sketch (README Example 1, README.md:23-57 of the reference):
 #
@@ -150,6 +152,43 @@ sparse_pack_vector!(out_terms::DevPtr, nzval::DevPtr, perm::DevPtr, term_var::De
     check(ccall((:pmt_sparse_pack_vector_slabs_f64, lib), Cint,
                 (DevPtr, DevPtr, DevPtr, DevPtr, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
                 nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream))
+
+"dst (cols x rows, leading dimension ldd) = transpose of src (rows x cols, leading dimension lds) — the adjoint rule, src/lazyexpression.jl:206-217"
+transpose!(dst::DevPtr, ldd, src::DevPtr, lds, rows, cols, stream) =
+    check(ccall((:pmt_transpose_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, Int64, Ptr{Cvoid}), src, lds, rows, cols, dst, ldd, stream))
+
+"bytes of workspace pmt_quad_gram_f64 needs for an r x n problem"
+quad_gram_workspace_bytes(rows, cols) = ccall((:pmt_quad_gram_workspace_bytes, lib), Csize_t, (Int64, Int64), rows, cols)
+
+# ---- staged (overlapped) uploads of host-updated Parameters (`Parameter(model, val=buf)`, src/parameter.jl:88): copy stream + commit
+stage_upload!(plan::Plan, staging::DevPtr, src::Array) =
+    check(ccall((:pmt_plan_stage_upload, lib), Cint, (Ptr{Cvoid}, DevPtr, Ptr{Cvoid}, Csize_t), plan.handle, staging, src, sizeof(src)))
+stage_upload_matrix!(plan::Plan, staging::DevPtr, ldd, A::Matrix{Float64}) =
+    check(ccall((:pmt_plan_stage_upload_2d, lib), Cint, (Ptr{Cvoid}, DevPtr, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
+                plan.handle, staging, 8 * ldd, A, 8 * size(A, 1), 8 * size(A, 1), size(A, 2)))
+commit_staged!(plan::Plan, dst::DevPtr, staging::DevPtr, bytes) =
+    check(ccall((:pmt_plan_commit_staged, lib), Cint, (Ptr{Cvoid}, DevPtr, DevPtr, Csize_t), plan.handle, dst, staging, bytes))
+staging_consumed!(plan::Plan) = check(ccall((:pmt_plan_staging_consumed, lib), Cint, (Ptr{Cvoid},), plan.handle))
+staged_synchronize(plan::Plan) = check(ccall((:pmt_plan_staged_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
+
+# ---- batched independent models across GPUs (BASELINE config 4): the library's own RCCL communicator
+"rank 0: a fresh 128-byte id; carry it to the other ranks with whatever launcher is at hand (MPI.jl, Distributed, a file)"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:pmt_comm_unique_id, lib), Cint, (Ptr{Cvoid},), id))
+    id
+end
+function comm_init_rank(nranks::Integer, rank::Integer, id::Vector{UInt8}, device::Integer)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmt_comm_init_rank, lib), Cint, (Cint, Cint, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), nranks, rank, id, device, ref))
+    ref[]
+end
+comm_destroy(comm::Ptr{Cvoid}) = check(ccall((:pmt_comm_destroy, lib), Cint, (Ptr{Cvoid},), comm))
+"one re-evaluation of this rank's instances, chunk c on the wire while chunk c + 1 is computed; `gathered` ends up with every rank's slabs"
+batch_step!(comm::Ptr{Cvoid}, A::DevPtr, b::DevPtr, C::DevPtr, d::DevPtr, per_rank, n, r, m, local_slabs::DevPtr, gathered::DevPtr, stride, chunk, stream) =
+    check(ccall((:pmt_batch_step_f64, lib), Cint,
+                (Ptr{Cvoid}, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Int64, Cint, Cint, DevPtr, DevPtr, Int64, Int64, Ptr{Cvoid}),
+                comm, A, b, C, d, per_rank, n, r, m, -1, -1, local_slabs, gathered, stride, chunk, stream))
 
 "device-side `rand!` Parameter callback (README.md:36-43): U[0,1)*scale, counter based"
 device_uniform!(dst::DevPtr, n, seed, scale, stream) =

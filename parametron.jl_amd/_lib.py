@@ -71,6 +71,8 @@ SIGNATURES = {
     "pmt_pack_vector_affine_f64": (_ci, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "pmt_canonical_order_affine": (_ci, [_i64, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pmt_canonical_order_quadratic": (_ci, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pmt_canonical_order_device": (_ci, [_vp, _i64, _ci, _vp, _vp, C.POINTER(_i64), _vp]),
+    "pmt_canonical_init_terms": (_ci, [_vp, _ci, _vp, _vp, _i64, _vp, _vp]),
     "pmt_segment_sum_f64": (_ci, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp]),
     "pmt_prune_zero_workspace_bytes": (_sz, [_i64, _ci]),
     "pmt_prune_zero_f64": (_ci, [_vp, _i64, _ci, _f64, _vp, _vp, _vp, _sz, _vp]),

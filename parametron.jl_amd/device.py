@@ -115,6 +115,10 @@ class DeviceContext:
     def call(self, name, *args):
         _lib.call(name, *args, self.launch_stream())
 
+    def call_now(self, name, *args):
+        """setup-time call on the plan's stream even while recording (e.g. the one-off device ordering of canonicalize!)"""
+        _lib.call(name, *args, self.stream)
+
     def begin_record(self):
         _lib.call("pmt_plan_begin_record", self.plan)
         self.recording = True

@@ -763,34 +763,47 @@ def _rule_canonicalize(model, ctx, x):
         raise ArgumentError("canonicalize on the device needs an AffineFunction or QuadraticFunction expression")
     if isinstance(dx, DQuad):
         dx.materialize()
-    evaluate(ctx, [x])                                                     # once (prepare + emit), to learn the (static) indices
+    evaluate(ctx, [x])                                                     # once (prepare + emit): the (static) indices are in HBM now
 
-    def order_affine(terms_ptr, nterms):
-        t = fetch_terms(ctx, terms_ptr, nterms, LT); ctx.synchronize()
-        perm, seg, (ov,) = _canonical_order("aff", t["var"])
-        out = np.zeros(len(ov), dtype=LT); out["var"] = ov
-        return perm, seg, out
+    def order(terms_ptr, nterms, dtype):
+        """(perm, seg_ptr) device buffers, nseg, and an initialiser for the output terms.  The ordering is computed on the device from
+        the term buffer where it lies (pmt_canonical_order_device: radix sort + run boundaries; only the run count comes back); indices
+        that do not fit the packed key (>= 2^32) take the host ordering instead."""
+        nbytes = dtype.itemsize
+        dperm, dseg = ctx.alloc(8 * max(nterms, 1)), ctx.alloc(8 * (nterms + 1))
+        nseg = C.c_int64()
+        try:
+            ctx.synchronize()
+            ctx.call_now("pmt_canonical_order_device", P(terms_ptr), nterms, nbytes, P(dperm), P(dseg), C.byref(nseg))
+        except ArgumentError:
+            t = fetch_terms(ctx, terms_ptr, nterms, dtype); ctx.synchronize()
+            if dtype is LT:
+                perm, seg, (ov,) = _canonical_order("aff", t["var"])
+                init = np.zeros(len(ov), dtype=LT); init["var"] = ov
+            else:
+                perm, seg, (orow, ocol) = _canonical_order("quad", t["row"], t["col"])
+                init = np.zeros(len(orow), dtype=QT); init["row"] = orow; init["col"] = ocol
+            return ctx.upload_new(perm), ctx.upload_new(seg), len(init), lambda out_ptr: ctx.upload(out_ptr, init)
+        n = int(nseg.value)
+        return dperm, dseg, n, lambda out_ptr: ctx.call_now("pmt_canonical_init_terms", P(terms_ptr), nbytes, P(dperm), P(dseg), n, P(out_ptr))
 
     if isinstance(dx, DAff):
-        perm, seg, init = order_affine(dx.terms, dx.nterms)
-        out = DAff(ctx, len(init)); ctx.upload(out.terms, init)
-        dperm, dseg = ctx.upload_new(perm), ctx.upload_new(seg)
+        dperm, dseg, nseg, init = order(dx.terms, dx.nterms, LT)
+        out = DAff(ctx, nseg)
+        init(out.terms)
 
         def emit(c):
-            c.call("pmt_segment_sum_f64", P(dx.terms), 16, P(dperm), P(dseg), len(init), P(out.terms), 16)
+            c.call("pmt_segment_sum_f64", P(dx.terms), 16, P(dperm), P(dseg), nseg, P(out.terms), 16)
             c.call("pmt_copy_bytes", P(out.const), P(dx.const), 8)
         return DeviceNode(model, "canonicalize!", [x], out, emit)
-    q = fetch_terms(ctx, dx.quad, dx.nq, QT); ctx.synchronize()
-    qperm, qseg, (orow, ocol) = _canonical_order("quad", q["row"], q["col"])
-    qinit = np.zeros(len(orow), dtype=QT); qinit["row"] = orow; qinit["col"] = ocol
-    lperm, lseg, linit = order_affine(dx.lin, dx.nl)
-    out = DQuad(ctx, len(qinit), len(linit))
-    ctx.upload(out.quad, qinit); ctx.upload(out.lin, linit)
-    dqperm, dqseg, dlperm, dlseg = ctx.upload_new(qperm), ctx.upload_new(qseg), ctx.upload_new(lperm), ctx.upload_new(lseg)
+    dqperm, dqseg, nq, qinit = order(dx.quad, dx.nq, QT)
+    dlperm, dlseg, nl, linit = order(dx.lin, dx.nl, LT)
+    out = DQuad(ctx, nq, nl)
+    qinit(out.quad); linit(out.lin)
 
     def emit(c):
-        c.call("pmt_segment_sum_f64", P(dx.quad), 24, P(dqperm), P(dqseg), len(qinit), P(out.quad), 24)
-        c.call("pmt_segment_sum_f64", P(dx.lin), 16, P(dlperm), P(dlseg), len(linit), P(out.lin), 16)
+        c.call("pmt_segment_sum_f64", P(dx.quad), 24, P(dqperm), P(dqseg), nq, P(out.quad), 24)
+        c.call("pmt_segment_sum_f64", P(dx.lin), 16, P(dlperm), P(dlseg), nl, P(out.lin), 16)
         c.call("pmt_copy_bytes", P(out.const), P(dx.const), 8)
     return DeviceNode(model, "canonicalize!", [x], out, emit)
 

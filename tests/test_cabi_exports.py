@@ -79,29 +79,78 @@ def test_header_is_plain_c_and_layouts_hold_for_a_c_compiler(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
-def test_julia_binding_stub_matches_the_header():
-    """julia/ParametronHIP.jl cannot be executed here (no julia); keep it honest statically: every ccall names a declared symbol and
-    passes exactly as many arguments as the C declaration has parameters."""
+def _c_param_class(decl):
+    """class of a C parameter declaration: 'ptr' | 'i64' | 'int' | 'f64' | 'size' | 'u64' | 'cstr'"""
+    d = re.sub(r"/\*.*?\*/", "", decl).strip()
+    if "*" in d:
+        return "cstr" if re.match(r"(const\s+)?char\s*\*", d) else "ptr"
+    if re.search(r"\buint64_t\b", d):
+        return "u64"
+    if re.search(r"\bint64_t\b", d):
+        return "i64"
+    if re.search(r"\bsize_t\b", d):
+        return "size"
+    if re.search(r"\bdouble\b", d):
+        return "f64"
+    if re.search(r"\bint\b", d):
+        return "int"
+    raise AssertionError("unclassified C parameter %r" % decl)
+
+
+def _julia_type_class(t):
+    t = t.strip()
+    if t in ("DevPtr", "Cstring") or t.startswith(("Ptr{", "Ref{")):
+        return "cstr" if t == "Cstring" else "ptr"
+    return {"Int64": "i64", "Cint": "int", "Cdouble": "f64", "Float64": "f64", "Csize_t": "size", "UInt64": "u64"}.get(t) or \
+        (_ for _ in ()).throw(AssertionError("unclassified Julia ccall type %r" % t))
+
+
+def test_julia_sources_match_the_header():
+    """julia/*.jl cannot be executed here (no julia); keep them honest statically: every ccall names a declared symbol, passes exactly as
+    many arguments as the C declaration has parameters, each of the matching TYPE CLASS (pointer / Int64 / Cint / Cdouble / Csize_t /
+    UInt64 / Cstring), and declares the matching return type."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "parametron_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(pmt_\w+)\s*\(([^;{]*?)\)\s*;", header):
-        params = m.group(2).strip()
-        decls[m.group(1)] = 0 if params in ("", "void") else params.count(",") + 1
-    src = open(os.path.join(root, "julia", "ParametronHIP.jl")).read()
-    calls = list(re.finditer(r"ccall\(\(:(pmt_\w+), lib\),\s*[\w{}.]+,\s*\(", src))
-    assert len(calls) >= 20
-    for m in calls:
-        name = m.group(1)
-        assert name in decls, "%s is not declared in the header" % name
-        depth, i = 1, m.end()
-        while depth:                                                       # the argument-type tuple, balanced parentheses
-            depth += {"(": 1, ")": -1}.get(src[i], 0)
-            i += 1
-        types = src[m.end():i - 1].strip().rstrip(",")
-        ntypes = 0 if not types else len([t for t in re.split(r",(?![^{]*})", types) if t.strip()])
-        assert ntypes == decls[name], "%s: %d argument types in the Julia stub, %d parameters in the header" % (name, ntypes, decls[name])
+    for m in re.finditer(r"([\w\s\*]+?)\b(pmt_\w+)\s*\(([^;{]*?)\)\s*;", header):
+        params = m.group(3).strip()
+        plist = [] if params in ("", "void") else [x.strip() for x in params.split(",")]
+        ret = m.group(1).strip()
+        decls[m.group(2)] = ([_c_param_class(x) for x in plist], ret)
+    ncalls = 0
+    for fname in sorted(os.listdir(os.path.join(root, "julia"))):
+        if not fname.endswith(".jl"):
+            continue
+        src = open(os.path.join(root, "julia", fname)).read()
+        for m in re.finditer(r"ccall\(\(:(pmt_\w+), lib\),\s*([\w{}.]+),\s*\(", src):
+            ncalls += 1
+            name, jret = m.group(1), m.group(2)
+            assert name in decls, "%s: %s is not declared in the header" % (fname, name)
+            depth, i = 1, m.end()
+            while depth:                                                       # the argument-type tuple, balanced parentheses
+                depth += {"(": 1, ")": -1}.get(src[i], 0)
+                i += 1
+            types = src[m.end():i - 1].strip().rstrip(",")
+            tlist = [] if not types else [t for t in re.split(r",(?![^{]*})", types) if t.strip()]
+            want, cret = decls[name]
+            assert len(tlist) == len(want), "%s: %s has %d argument types in Julia, %d parameters in the header" % (fname, name, len(tlist), len(want))
+            got = [_julia_type_class(t) for t in tlist]
+            assert got == want, "%s: %s argument classes %r, header %r" % (fname, name, got, want)
+            rclass = ("cstr" if "char" in cret else "ptr") if "*" in cret else _c_param_class(cret + " x")
+            jclass = "ptr" if jret.startswith("Ptr{") else _julia_type_class(jret)
+            assert jclass == rclass or (rclass == "cstr" and jclass in ("cstr", "ptr")), "%s: %s returns %s in Julia, %s in the header" % (fname, name, jret, cret)
+    assert ncalls >= 30
+
+
+def test_julia_backend_only_uses_bound_wrappers():
+    """ParametronHIPBackend.jl calls the binding as `H.<name>(...)`: every such name must be defined in ParametronHIP.jl."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binding = open(os.path.join(root, "julia", "ParametronHIP.jl")).read()
+    backend = open(os.path.join(root, "julia", "ParametronHIPBackend.jl")).read()
+    defined = set(re.findall(r"^(?:function\s+)?([A-Za-z_!0-9]+)\(", binding, flags=re.M)) | set(re.findall(r"^(?:mutable\s+)?struct\s+(\w+)", binding, flags=re.M)) | {"DevPtr"}
+    used = set(re.findall(r"\bH\.([A-Za-z_!0-9]+)", backend))
+    assert used and used <= defined, "ParametronHIPBackend.jl uses unbound wrappers: %r" % sorted(used - defined)
 
 
 def test_shipped_library_reads_no_environment_switches():

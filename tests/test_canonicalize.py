@@ -90,3 +90,60 @@ def test_canonical_mode_applies_generic_canonicalize_to_non_gram_objectives():
         results.append((P.value(model, x), len(model.objective.f.quadratic_terms)))
     np.testing.assert_allclose(results[0][0], results[1][0], rtol=1e-9)
     assert results[0][1] == (n + 2) * n * n and results[1][1] == n * (n + 1) // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,nvars", [("quad", 20000, 37), ("quad", 1, 5), ("aff", 5000, 11), ("quad", 300, 300), ("aff", 0, 3)])
+def test_device_ordering_equals_host_ordering(kind, n, nvars):
+    """pmt_canonical_order_device (radix sort + run boundaries in HBM) against the host ordering pmt_canonical_order_* on random term lists
+    with many duplicates: the same permutation (both are stable), the same run boundaries, the same output indices — including the
+    reference's convention that a run of one keeps its original (row, col) (src/util.jl:18-19)."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    import gpu_util as g
+    from parametron_jl_amd.lazyexpression import _canonical_order
+    rng = np.random.default_rng(n + nvars)
+    dtype = g.QT if kind == "quad" else g.LT
+    t = np.zeros(n, dtype=dtype)
+    t["coeff"] = rng.random(n)
+    empty = (np.zeros(0, np.int64), np.zeros(1, np.int64))
+    if kind == "quad":
+        t["row"] = rng.integers(1, nvars + 1, n); t["col"] = rng.integers(1, nvars + 1, n)
+        perm, seg, (orow, ocol) = _canonical_order("quad", t["row"], t["col"]) if n else empty + ((np.zeros(0, np.int64),) * 2,)
+    else:
+        t["var"] = rng.integers(1, nvars + 1, n)
+        perm, seg, (ov,) = _canonical_order("aff", t["var"]) if n else empty + ((np.zeros(0, np.int64),),)
+    dt = g.to_dev(t) if n else g.empty_terms(1, dtype)
+    dperm = torch.full((max(n, 1),), -1, dtype=torch.int64, device=g.DEV)
+    dseg = torch.full((n + 1,), -1, dtype=torch.int64, device=g.DEV)
+    nseg = C.c_int64(-1)
+    torch.cuda.synchronize()
+    g.call("pmt_canonical_order_device", g.ptr(dt), n, dtype.itemsize, g.ptr(dperm), g.ptr(dseg), C.byref(nseg), g.stream())
+    torch.cuda.synchronize()
+    assert nseg.value == len(seg) - 1
+    assert np.array_equal(dperm.cpu().numpy()[:n], perm)
+    assert np.array_equal(dseg.cpu().numpy()[:nseg.value + 1], seg)
+    out = g.empty_terms(max(nseg.value, 1), dtype)
+    g.call("pmt_canonical_init_terms", g.ptr(dt), dtype.itemsize, g.ptr(dperm), g.ptr(dseg), nseg.value, g.ptr(out), g.stream())
+    got = g.terms_to_host(out, nseg.value, dtype)
+    assert np.all(got["coeff"] == 0.0)
+    if kind == "quad":
+        assert np.array_equal(got["row"], orow) and np.array_equal(got["col"], ocol)
+    else:
+        assert np.array_equal(got["var"], ov)
+
+
+@pytest.mark.gpu
+def test_device_ordering_reports_indices_beyond_the_packed_key():
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    import gpu_util as g
+    from parametron_jl_amd import _lib
+    t = np.zeros(4, dtype=g.QT)
+    t["row"] = [1, 2, 1 << 33, 4]; t["col"] = [1, 1, 2, 4]
+    dt = g.to_dev(t)
+    dperm = torch.zeros(4, dtype=torch.int64, device=g.DEV); dseg = torch.zeros(5, dtype=torch.int64, device=g.DEV)
+    nseg = C.c_int64()
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.ArgumentError, match="host ordering"):
+        g.call("pmt_canonical_order_device", g.ptr(dt), 4, 24, g.ptr(dperm), g.ptr(dseg), C.byref(nseg), g.stream())
