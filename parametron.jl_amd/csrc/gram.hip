@@ -22,9 +22,6 @@ namespace pmt {
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s);
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
-size_t gram2_workspace_bytes();
-int launch_gram2(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                 pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s, bool *taken);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s);
 
@@ -95,7 +92,7 @@ static SideStream *side_stream(hipStream_t s) {
 using namespace pmt;
 
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
-    return std::max(gram_sk_workspace_bytes(rows, cols), gram2_workspace_bytes());
+    return gram_sk_workspace_bytes(rows, cols);
 }
 
 // the whole node: contraction on the main stream, q = 2A'c and c'c on a side stream.  out_quad (term structs) and out_csc (solver
@@ -122,7 +119,11 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             s2 = side->stream;
         }
         int rc = PMT_OK;
+#ifdef PMT_GRAM_NO_SIDE_KERNELS                          // ablation builds only (tools/): what the co-resident reductions cost the contraction
+        if (false) {
+#else
         if (cols > 0) {
+#endif
             PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s2, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
             rc = check_launch("gram_linear_kernel");
         }
@@ -131,12 +132,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
         }
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));
-        if (!rc && cols > 0) {
-            // aligned shapes: the specialised-wave kernel (gram2.hip); everything else: the general stream-K kernel (gram_sk.hip)
-            bool taken = false;
-            rc = launch_gram2(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, s, &taken);
-            if (!rc && !taken) rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, s);
-        }
+        if (!rc && cols > 0) rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, s);
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
         return rc;
     });

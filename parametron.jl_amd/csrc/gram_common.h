@@ -1,5 +1,5 @@
-// Definitions shared by the two implementations of the canonical least-squares contraction (gram_sk.hip: general shapes;
-// gram2.hip: specialised waves, aligned shapes): argument block, tile geometry, the XCD-aware tile order, the accumulator lane map.
+// Geometry of the canonical least-squares contraction (gram_sk.hip), kept apart from the kernel bodies: argument block, tile geometry,
+// work-unit numbering, the XCD-aware tile order, the accumulator lane map, the term store.
 #pragma once
 #include "common.h"
 

@@ -495,12 +495,6 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     }
 }
 
-// the fix-up pass for a contraction whose partials were written by another kernel with the same protocol (gram2.hip)
-int launch_gram_fixup(const SKArgs &g, int64_t R, hipStream_t s) {
-    PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<2>, dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
-    return check_launch("gram_sk_fixup_kernel");
-}
-
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
     (void)rows; (void)cols;
     return (size_t)MAXG * 2 * SLOT * sizeof(double);
