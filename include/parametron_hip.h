@@ -289,6 +289,15 @@ int pmt_sparse_pack_vector_slabs_f64(const double *nzval, const int64_t *perm, c
                                      pmt_vector_affine_term *out_terms, void *stream);
 int pmt_sparse_assemble_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
                                   int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream);
+/* the same two entry points with 32-bit perm / term_var (same values; half the index stream).  Usable when nnz and every variable index
+ * (after varmap, if the caller folds it in — see below) are below 2^32.
+ * Folding varmap in: pass term_var[t] = varmap[x-variable of term t] and varmap = NULL; the per-term varmap gather disappears (the map
+ * only changes when the optimizer's index map does, src/model.jl:100-107, not per re-evaluation). */
+int pmt_sparse_pack_vector_slabs_u32_f64(const double *nzval, const uint32_t *perm, const uint32_t *term_var, const int64_t *slab_ptr,
+                                         int64_t rows, int nslab, const int64_t *varmap, int64_t row_offset,
+                                         pmt_vector_affine_term *out_terms, void *stream);
+int pmt_sparse_assemble_slabs_u32_f64(const double *nzval, const uint32_t *perm, const uint32_t *term_var, const int64_t *slab_ptr,
+                                      int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream);
 /* constants of the same node: out[i] = 0.0 (+|-) d[i]  (vecadd!/vecsubtract! on zero!'d functions, src/functions.jl:244,452,474) */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 

@@ -51,17 +51,19 @@ __global__ void sparse_assemble_kernel(const double *__restrict__ nzval, const i
 // gathers, and the index loads of the NEXT round are issued before the current round is staged and written.
 constexpr int SP_ROWS_PER_WAVE = 4;
 
-template <bool VAT_OUT>
-__global__ __launch_bounds__(256) void sparse_slab_kernel(const double *__restrict__ nzval, const int64_t *__restrict__ perm,
-                                                          const int64_t *__restrict__ term_var, const int64_t *__restrict__ slab_ptr,
-                                                          int64_t rows, int nslab, const int64_t *__restrict__ varmap, int64_t row_offset,
-                                                          unsigned long long *__restrict__ out) {
+// IDX: element type of perm / term_var — int64_t (the reference's Int64 indices) or uint32_t (same values, half the index stream, for
+// patterns and variable indices below 2^32: pmt_sparse_*_slabs_u32_f64).  62-64 VGPRs: eight waves per SIMD, i.e. all eight workgroups
+// that config 5 puts on a CU are resident at once.
+template <bool VAT_OUT, typename IDX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void sparse_slab_kernel(
+    const double *__restrict__ nzval, const IDX *__restrict__ perm, const IDX *__restrict__ term_var, const int64_t *__restrict__ slab_ptr,
+    int64_t rows, int nslab, const int64_t *__restrict__ varmap, int64_t row_offset, unsigned long long *__restrict__ out) {
     typedef unsigned long long u64;
     constexpr int W = VAT_OUT ? 3 : 2;                           // 8-byte words per term
     constexpr int R = SP_ROWS_PER_WAVE;
     __shared__ u64 s_coeff[4][64];
     __shared__ u64 s_var[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: row bounds live in SGPRs
     const int slab = blockIdx.x % nslab;
     const int64_t rowbase = ((int64_t)(blockIdx.x / nslab) * 4 + wave) * R;
     int64_t t0[R], t1[R];
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void sparse_slab_kernel(const double *__restri
     for (int i = 0; i < R; ++i) {
         const int64_t t = t0[i] + lane;
         const bool ok = t < t1[i];
-        pidx[i] = ok ? perm[t] : 0;
-        var[i] = ok ? term_var[t] : 1;
+        pidx[i] = ok ? (int64_t)perm[t] : 0;
+        var[i] = ok ? (int64_t)term_var[t] : 1;
     }
     for (int64_t base = 0; base < longest; base += 64) {
         double val[R];
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(256) void sparse_slab_kernel(const double *__restri
         for (int i = 0; i < R; ++i) {                                                                   // next round's indices, in flight meanwhile
             const int64_t t = t0[i] + base + 64 + lane;
             const bool ok = t < t1[i];
-            pn[i] = ok ? perm[t] : 0;
-            vn[i] = ok ? term_var[t] : 1;
+            pn[i] = ok ? (int64_t)perm[t] : 0;
+            vn[i] = ok ? (int64_t)term_var[t] : 1;
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -189,17 +191,19 @@ extern "C" int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const 
     return PMT_OK;
 }
 
-static int launch_sparse_slab(bool vat, const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr, int64_t rows,
+template <typename IDX>
+static int launch_sparse_slab(bool vat, const double *nzval, const IDX *perm, const IDX *term_var, const int64_t *slab_ptr, int64_t rows,
                               int nslab, const int64_t *varmap, int64_t row_offset, void *out, void *stream) {
     PMT_REQUIRE(rows >= 0 && nslab >= 1 && nslab <= 64, PMT_DIMENSION_MISMATCH, "sparse_pack_slabs: bad dimensions");
     if (rows == 0) return PMT_OK;
     PMT_REQUIRE(nzval && perm && term_var && slab_ptr && out, PMT_INVALID_ARGUMENT, "sparse_pack_slabs: null pointer");
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)(cdiv(rows, 4 * SP_ROWS_PER_WAVE) * nslab);
-        if (vat) PMT_LAUNCH_NAMED("sparse_slab_kernel<VAT>", sparse_slab_kernel<true>, dim3(blocks), dim3(256), 0, s, nzval, perm, term_var, slab_ptr, rows, nslab,
-                                  varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
-        else PMT_LAUNCH_NAMED("sparse_slab_kernel<LT>", sparse_slab_kernel<false>, dim3(blocks), dim3(256), 0, s, nzval, perm, term_var, slab_ptr, rows, nslab,
-                              varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
+        constexpr bool narrow = sizeof(IDX) == 4;
+        if (vat) PMT_LAUNCH_NAMED(narrow ? "sparse_slab_kernel<VAT,u32>" : "sparse_slab_kernel<VAT>", (sparse_slab_kernel<true, IDX>), dim3(blocks), dim3(256), 0, s,
+                                  nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
+        else PMT_LAUNCH_NAMED(narrow ? "sparse_slab_kernel<LT,u32>" : "sparse_slab_kernel<LT>", (sparse_slab_kernel<false, IDX>), dim3(blocks), dim3(256), 0, s,
+                              nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
         return check_launch("sparse_slab_kernel");
     });
 }
@@ -212,5 +216,16 @@ extern "C" int pmt_sparse_pack_vector_slabs_f64(const double *nzval, const int64
 
 extern "C" int pmt_sparse_assemble_slabs_f64(const double *nzval, const int64_t *perm, const int64_t *term_var, const int64_t *slab_ptr,
                                              int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream) {
-    return launch_sparse_slab(false, nzval, perm, term_var, slab_ptr, rows, nslab, nullptr, 0, out_terms, stream);
+    return launch_sparse_slab(false, nzval, perm, term_var, slab_ptr, rows, nslab, (const int64_t *)nullptr, 0, out_terms, stream);
+}
+
+extern "C" int pmt_sparse_pack_vector_slabs_u32_f64(const double *nzval, const uint32_t *perm, const uint32_t *term_var, const int64_t *slab_ptr,
+                                                    int64_t rows, int nslab, const int64_t *varmap, int64_t row_offset,
+                                                    pmt_vector_affine_term *out_terms, void *stream) {
+    return launch_sparse_slab(true, nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream);
+}
+
+extern "C" int pmt_sparse_assemble_slabs_u32_f64(const double *nzval, const uint32_t *perm, const uint32_t *term_var, const int64_t *slab_ptr,
+                                                 int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream) {
+    return launch_sparse_slab(false, nzval, perm, term_var, slab_ptr, rows, nslab, (const int64_t *)nullptr, 0, out_terms, stream);
 }

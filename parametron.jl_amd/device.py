@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import LT, QT, VAT, ArgumentError
+from ._lib import LT, QT, VAT, ArgumentError, DimensionMismatch
 
 
 class DeviceContext:
@@ -384,8 +384,8 @@ class DSpMat(DV):
         _lib.call("pmt_sparse_rowmajor_order", self.rows, self.cols, colptr.ctypes.data_as(vp), rowval.ctypes.data_as(vp),
                   self.perm.ctypes.data_as(vp), self.term_row.ctypes.data_as(vp), self.term_col.ctypes.data_as(vp), self.row_ptr.ctypes.data_as(vp))
         self.buf = ctx.alloc(8 * max(self.nnz, 1))                                # nzval
-        self.perm_buf = ctx.upload_new(self.perm) if self.nnz else ctx.alloc(8)
-        self.term_row_buf = ctx.upload_new(self.term_row) if self.nnz else ctx.alloc(8)
+        self.narrow = self.nnz < 2 ** 32                                        # 32-bit index streams (sparse.hip, IDX = uint32_t)
+        self.perm_buf = (ctx.upload_new(self.perm.astype(np.uint32) if self.narrow else self.perm)) if self.nnz else ctx.alloc(8)
         # XCD-aware scatter: per-row boundaries of 8 column slabs (one per XCD), see sparse.hip
         self.nslab = 8
         self.slab_ptr = np.zeros(max(self.rows, 1) * (self.nslab + 1), dtype=np.int64)
@@ -409,8 +409,22 @@ class DSparseAff(DAffVec):
             self.row_ptr_buf = ctx.upload_new(self.row_ptr)
         self.spmat, self.xvars, self.vec, self.sign = spmat, xvars, vec, sign
         self.term_var = xvars.vars[spmat.term_col - 1] if spmat.nnz else np.zeros(0, dtype=np.int64)
-        self.term_var_buf = ctx.upload_new(self.term_var) if spmat.nnz else ctx.alloc(8)
+        self._term_var_buf = None
         self.need_terms = False
+
+    def index_stream(self, values):
+        """device copy of a per-term index array in the width the matrix's perm stream has (both streams of a launch share one type)"""
+        if not self.spmat.nnz:
+            return self.ctx.alloc(8)
+        if self.spmat.narrow and (values.max() >= 2 ** 32 or values.min() < 0):
+            raise DimensionMismatch("sparse node: variable indices of 2^32 or more with a 32-bit pattern")
+        return self.ctx.upload_new(values.astype(np.uint32) if self.spmat.narrow else np.ascontiguousarray(values, dtype=np.int64))
+
+    @property
+    def term_var_buf(self):
+        if self._term_var_buf is None:
+            self._term_var_buf = self.index_stream(self.term_var)
+        return self._term_var_buf
 
     def uniform(self):
         return False

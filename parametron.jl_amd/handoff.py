@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib, moi
 from ._lib import ArgumentError, ErrorException
-from .device import P
+from .device import DSparseAff, P
 
 _SET_KIND = {moi.EqualTo: 0, moi.Zeros: 0, moi.GreaterThan: 1, moi.Nonnegatives: 1, moi.LessThan: 2, moi.Nonpositives: 2}
 DEFAULT_INFTY = 1e20
@@ -41,8 +41,9 @@ def _csc_order(rows, cols, nrows, ncols, upper):
 class _Block:
     """One source of matrix entries: a device term buffer (or host values for constant functions) and where its runs go."""
 
-    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None):
+    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None, source_perm=None):
         self.rows, self.cols, self.coeff_ptr, self.stride, self.host_coeff = rows, cols, coeff_ptr, stride, host_coeff
+        self.source_perm = source_perm            # entry i's coefficient sits at coeff_ptr + source_perm[i] * stride (None: i * stride)
 
 
 class CSC:
@@ -126,7 +127,13 @@ class DeviceQP:
                     ablocks.append(_Block(t["out"] + row0, vm[t["var"] - 1], host_coeff=t["coeff"].copy()))
                     bounds.append((row0, c.nrows, kind, value, None, np.asarray(c.f.constants, dtype=np.float64).copy()))
                 else:
-                    ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8, 24))
+                    out = c.expr.out
+                    if isinstance(out, DSparseAff) and not out.need_terms:
+                        # a sparse block's coefficients are read where they already are — the Parameter's nzval (CSC order) — not out of
+                        # the 24-byte terms the scatter kernel wrote for the MOI side
+                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), out.spmat.buf, 8, source_perm=out.spmat.perm))
+                    else:
+                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8, 24))
                     bounds.append((row0, c.nrows, kind, value, c.dev["consts"], None))
             row0 += c.nrows
         self.nrows = m = row0
@@ -162,6 +169,13 @@ class DeviceQP:
         col_ptr = np.zeros(ncols + 1, dtype=np.int64)
         np.add.at(col_ptr, ucols + 1, 1)
         col_ptr = np.cumsum(col_ptr)
+        if len(local) == 1 and alpha == 1.0 and local[0][0].host_coeff is None and len(ukey):
+            # one block whose entries already lie in the matrix's CSC order, one entry per run (a sparse constraint matrix handed over
+            # as it came): the values ARE the source buffer; nothing to launch per re-evaluation
+            b, perm, seg = local[0][0], local[0][1], local[0][2]
+            src = perm if b.source_perm is None else b.source_perm[perm]
+            if b.stride == 8 and len(seg) == len(perm) + 1 and np.array_equal(src, np.arange(len(src))):
+                return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), b.coeff_ptr)
         values = ctx.alloc(8 * max(len(ukey), 1))
         static = np.zeros(max(len(ukey), 1))
         pos = 0
@@ -174,6 +188,8 @@ class DeviceQP:
                 static[dst] = alpha * sums
             elif k:
                 identity = len(local) == 1
+                if b.source_perm is not None:
+                    perm = np.ascontiguousarray(b.source_perm[perm], dtype=np.int64)
                 self._launches.append(("pmt_csc_values_f64", (P(b.coeff_ptr), b.stride, len(perm), P(ctx.upload_new(perm)), P(ctx.upload_new(seg)), k,
                                                               alpha, None if identity else P(ctx.upload_new(dst)), P(values))))
         ctx.upload(values, static)

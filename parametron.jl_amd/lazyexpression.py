@@ -413,7 +413,8 @@ def _emit_sparse_terms(c, out):
     if not out.need_terms:
         return
     sp = out.spmat
-    c.call("pmt_sparse_assemble_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf), P(sp.slab_ptr_buf), sp.rows, sp.nslab, P(out.terms))
+    c.call("pmt_sparse_assemble_slabs_u32_f64" if sp.narrow else "pmt_sparse_assemble_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf),
+           P(sp.slab_ptr_buf), sp.rows, sp.nslab, P(out.terms))
     if out.vec is not None:
         c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(out.consts))
 

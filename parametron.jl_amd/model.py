@@ -300,6 +300,9 @@ class Model:
         self.model_var_to_optimizer = np.asarray(indexmap["variables"], dtype=np.int64).copy()
         if self._records:
             self.device().upload(self._varmap_buf, self.model_var_to_optimizer)
+            for r in self._records:
+                for hook in getattr(r, "varmap_hooks", ()):
+                    hook(self.model_var_to_optimizer)
 
     def _refresh_parameters(self):
         ctx = self.device()

@@ -8,7 +8,7 @@ constant records are converted once on the host at setup, as in the reference (`
 """
 import numpy as np
 
-from ._lib import LT, QT, VAT, ArgumentError
+from ._lib import LT, QT, VAT, ArgumentError, DimensionMismatch
 from .device import DAff, DAffVec, DDenseAff, DQuad, DSparseAff, DVarsAff, P
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
 from .lazyexpression import DeviceNode, kind_of
@@ -169,6 +169,7 @@ class _Record:
         device hand-off only): the final model_var_to_optimizer; a Gram objective whose variables stay in increasing order under it
         writes the solver's CSC values of P directly from the contraction's epilogue and no quadratic term structs at all."""
         out = self.expr.out
+        self.varmap_hooks = []                                            # called with the new host varmap whenever it changes
         if self.kind == "aff":
             n = out.nterms
             self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
@@ -244,10 +245,22 @@ class _Record:
             dc = ctx.alloc(8 * max(out.rows, 1))
             self.dev = {"terms": dt, "consts": dc}
             sp = out.spmat
+            # varmap folded into the per-term variable stream: it changes with the optimizer's index map (mapindices!, src/model.jl:100-107),
+            # not per re-evaluation, so the kernel streams varmap[x[col]] instead of gathering it for every term
+            mapped = ctx.alloc((4 if sp.narrow else 8) * max(sp.nnz, 1))
+
+            def refresh(varmap_host):
+                if sp.nnz:
+                    v = out.term_var if varmap_host is None else np.asarray(varmap_host, dtype=np.int64)[out.term_var - 1]
+                    if sp.narrow and (v.max() >= 2 ** 32 or v.min() < 0):
+                        raise DimensionMismatch("sparse constraint: optimizer variable indices of 2^32 or more with a 32-bit pattern")
+                    ctx.upload(mapped, v.astype(np.uint32) if sp.narrow else np.ascontiguousarray(v))
+            self.varmap_hooks.append(refresh)
+            refresh(handoff_varmap)
 
             def emit(c):
-                c.call("pmt_sparse_pack_vector_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf), P(sp.slab_ptr_buf), sp.rows, sp.nslab,
-                       P(varmap_buf), 0, P(dt))
+                c.call("pmt_sparse_pack_vector_slabs_u32_f64" if sp.narrow else "pmt_sparse_pack_vector_slabs_f64", P(sp.buf), P(sp.perm_buf), P(mapped),
+                       P(sp.slab_ptr_buf), sp.rows, sp.nslab, None, 0, P(dt))
                 if out.vec is not None:
                     c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
             return emit

@@ -337,3 +337,42 @@ def test_config2_full_size_device_handoff_properties():
     assert np.array_equal(ax.reshape(n, m).T, Ch)                          # column by column = C's own column-major order
     assert np.array_equal(got["l"], dh) and np.array_equal(got["u"], dh)
     model.close()
+
+
+@pytest.mark.parametrize("case", ["alone", "stacked", "permuted"])
+def test_sparse_constraint_block_is_handed_over_from_nzval(case):
+    """A sparse constraint matrix (config 5 shape) reaches the solver's CSC `A` from the Parameter's nzval, not through the 24-byte terms:
+    alone and in the optimizer's variable order its values ARE the nzval buffer (no launch); stacked under another block, or with permuted
+    optimizer indices, it is one gather out of nzval.  Values must track the Parameter across updates either way."""
+    m, n, g = 23, 40, 3
+    rng = np.random.default_rng(13)
+    Cs = sp.random(m, n, density=0.2, format="csc", random_state=rng, data_rvs=lambda k: rng.random(k) + 0.1)
+    Cs.sort_indices()
+    opt = DenseQPOptimizer(permute_seed=6) if case == "permuted" else P.MockOptimizer()
+    model = P.Model(opt, quadratic_mode="canonical", handoff="device")
+    x = [Variable(model) for _ in range(n)]
+    Cp = P.Parameter(model, val=Cs.copy())
+    d = P.Parameter(model, val=rng.random(m))
+    G = P.Parameter(model, val=rng.random((g, n)))
+    h = P.Parameter(model, val=rng.random(g))
+    P.objective(model, P.Minimize, P.dot(np.ones(n), x))
+    if case == "stacked":
+        P.constraint(model, G * x <= h)
+    P.constraint(model, Cp * x == d)
+    model.initialize()
+    qp = model.device_qp
+    rows = m + (g if case == "stacked" else 0)
+    assert (qp.A.values_ptr == list(model.constraints)[-1].expr.out.spmat.buf) == (case == "alone")
+    for k in range(3):
+        Cp.val.data[...] = rng.random(Cs.nnz) + 0.1 * k
+        d.val[...] = rng.random(m)
+        model.update()
+        got = qp.fetch()
+        check_csc_canonical(got["A"])
+        want = np.zeros((rows, n))
+        vm = model.model_var_to_optimizer - 1
+        want[rows - m:, vm] = Cp.val.toarray()
+        if case == "stacked":
+            want[:g, vm] = G.val
+        assert np.array_equal(dense_of(got["A"], (rows, n)), want)
+        assert np.array_equal(got["l"][rows - m:], d.val) and np.array_equal(got["u"][rows - m:], d.val)

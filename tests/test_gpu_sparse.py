@@ -78,7 +78,7 @@ def test_config5_size_properties():
     assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
 
 
-@pytest.mark.parametrize("m,n,density,nslab", [(37, 61, 0.08, 8), (5, 3, 0.9, 8), (200, 1000, 0.3, 8), (64, 500, 0.02, 3), (9, 40, 0.0, 8)])
+@pytest.mark.parametrize("m,n,density,nslab", [(37, 61, 0.08, 8), (5, 3, 0.9, 8), (200, 1000, 0.3, 8), (64, 500, 0.02, 3), (9, 40, 0.0, 8), (300, 2100, 0.2, 8), (1, 700, 0.5, 8)])
 def test_xcd_aware_slab_kernels_equal_the_flat_scatter(m, n, density, nslab):
     """pmt_sparse_pack_vector_slabs_f64 / pmt_sparse_assemble_slabs_f64 (one column slab per XCD, 16-byte chunk writes) write the same
     bytes as the flat gather kernels — rows with no entry in a slab, slabs wider than the matrix, segments longer than one wave
@@ -108,9 +108,20 @@ def test_xcd_aware_slab_kernels_equal_the_flat_scatter(m, n, density, nslab):
     g.call("pmt_sparse_pack_vector_slabs_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), g.ptr(d_slab), m, nslab, g.ptr(d_vm), 7, g.ptr(slab_v), g.stream())
     g.call("pmt_sparse_assemble_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), nnz, g.ptr(flat_l), g.stream())
     g.call("pmt_sparse_assemble_slabs_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_var), g.ptr(d_slab), m, nslab, g.ptr(slab_l), g.stream())
+    # 32-bit index streams, once with the varmap gather and once with varmap folded into the variable stream
+    d_perm32, d_var32, d_mapped32 = g.to_dev(perm.astype(np.uint32)), g.to_dev(tvar.astype(np.uint32)), g.to_dev(varmap[tvar - 1].astype(np.uint32))
+    d_mapped = g.to_dev(varmap[tvar - 1])
+    n32_v, f32_v, f64_v, n32_l = g.empty_terms(max(nnz, 1), g.VAT), g.empty_terms(max(nnz, 1), g.VAT), g.empty_terms(max(nnz, 1), g.VAT), g.empty_terms(max(nnz, 1), g.LT)
+    g.call("pmt_sparse_pack_vector_slabs_u32_f64", g.ptr(d_nz), g.ptr(d_perm32), g.ptr(d_var32), g.ptr(d_slab), m, nslab, g.ptr(d_vm), 7, g.ptr(n32_v), g.stream())
+    g.call("pmt_sparse_pack_vector_slabs_u32_f64", g.ptr(d_nz), g.ptr(d_perm32), g.ptr(d_mapped32), g.ptr(d_slab), m, nslab, None, 7, g.ptr(f32_v), g.stream())
+    g.call("pmt_sparse_pack_vector_slabs_f64", g.ptr(d_nz), g.ptr(d_perm), g.ptr(d_mapped), g.ptr(d_slab), m, nslab, None, 7, g.ptr(f64_v), g.stream())
+    g.call("pmt_sparse_assemble_slabs_u32_f64", g.ptr(d_nz), g.ptr(d_perm32), g.ptr(d_var32), g.ptr(d_slab), m, nslab, g.ptr(n32_l), g.stream())
     if nnz:
         g.assert_terms_equal(g.terms_to_host(slab_v, nnz, g.VAT), g.terms_to_host(flat_v, nnz, g.VAT))
         g.assert_terms_equal(g.terms_to_host(slab_l, nnz, g.LT), g.terms_to_host(flat_l, nnz, g.LT))
+        for other in (n32_v, f32_v, f64_v):
+            g.assert_terms_equal(g.terms_to_host(other, nnz, g.VAT), g.terms_to_host(flat_v, nnz, g.VAT))
+        g.assert_terms_equal(g.terms_to_host(n32_l, nnz, g.LT), g.terms_to_host(flat_l, nnz, g.LT))
         t = g.terms_to_host(slab_v, nnz, g.VAT)
         model_var = np.argsort(varmap)[t["var"] - 1] + 1                   # undo varmap; column c carries Variable n - c
         dense = np.zeros((m, n))

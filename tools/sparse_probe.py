@@ -52,11 +52,20 @@ def main():
 
     def assemble_slabs():
         _lib.call("pmt_sparse_assemble_slabs_f64", dptr(nz), dptr(dperm), dptr(dvar), dptr(dslab), m, nslab, dptr(outlt2), stream)
+    def pack_slabs_premapped():                      # varmap folded into term_var beforehand: no second gather
+        _lib.call("pmt_sparse_pack_vector_slabs_f64", dptr(nz), dptr(dperm), dptr(dvar), dptr(dslab), m, nslab, None, 0, dptr(out2), stream)
+    dperm32, dvar32 = torch.from_numpy(perm.astype(np.uint32).view(np.int32)).to(dev), torch.from_numpy(tcol.astype(np.uint32).view(np.int32)).to(dev)
+    out3 = torch.empty(nnz * 3, dtype=torch.int64, device=dev)
+
+    def pack_slabs_u32_premapped():
+        _lib.call("pmt_sparse_pack_vector_slabs_u32_f64", dptr(nz), dptr(dperm32), dptr(dvar32), dptr(dslab), m, nslab, None, 0, dptr(out3), stream)
+    pack_slabs_u32_premapped()
     pack(); assemble(); pack_slabs(); assemble_slabs()
     torch.cuda.synchronize()
-    print("slab kernels bit-identical to the flat kernels:", bool(torch.equal(out, out2)), bool(torch.equal(outlt, outlt2)), flush=True)
+    print("slab kernels bit-identical to the flat kernels:", bool(torch.equal(out, out2)), bool(torch.equal(outlt, outlt2)), bool(torch.equal(out, out3)), flush=True)
     for name, fn, bytes_per in (("sparse_pack_vector_kernel", pack, 56), ("sparse_assemble_kernel", assemble, 40),
-                                ("sparse_slab_kernel<VAT>", pack_slabs, 48), ("sparse_slab_kernel<LT>", assemble_slabs, 40)):
+                                ("sparse_slab_kernel<VAT>", pack_slabs, 48), ("sparse_slab_kernel<LT>", assemble_slabs, 40),
+                                ("sparse_slab_kernel<VAT>", pack_slabs_premapped, 48), ("sparse_slab_kernel<VAT,u32>", pack_slabs_u32_premapped, 40)):
         for _ in range(30):
             fn()
         torch.cuda.synchronize()
