@@ -279,7 +279,7 @@ def config_c4(torch, _lib, steps):
 
 def config_c5(torch, P, _lib, steps):
     from parametron_jl_amd import workloads
-    model, Cs = workloads.config5(handoff="device")
+    model, Cs = workloads.config5(pinned=True, handoff="device")
     P.solve(model)
     ctx = model.device()
 
@@ -303,7 +303,8 @@ def config_c5(torch, P, _lib, steps):
     ctx.synchronize()
     kern = profile_report(_lib)
     _lib.call("pmt_profile_enable", 0)
-    out["ms_per_step"] = out["staged_upload"]["ms_per_step"]
+    best = min(("staged_upload", "serial_upload"), key=lambda k: out[k]["ms_per_step"])   # the 27 MB copy is the step either way
+    out["ms_per_step"], out["upload_mode"] = out[best]["ms_per_step"], best
     out["kernels"] = kern
     name = next((k for k in kern if k.startswith("sparse_")), None)
     if name:

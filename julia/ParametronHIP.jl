@@ -153,6 +153,14 @@ sparse_pack_vector!(out_terms::DevPtr, nzval::DevPtr, perm::DevPtr, term_var::De
                 (DevPtr, DevPtr, DevPtr, DevPtr, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
                 nzval, perm, term_var, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream))
 
+"the same with UInt32 perm / variable streams (nnz and indices below 2^32: half the index bytes).  Fold the optimizer's index map into
+`term_var` (term_var[t] = varmap[x[col]]) and pass `varmap = C_NULL` to drop the per-term map gather; refresh it after mapindices!."
+sparse_pack_vector_u32!(out_terms::DevPtr, nzval::DevPtr, perm32::DevPtr, term_var32::DevPtr, slab_ptr::DevPtr, rows, nslab, varmap::DevPtr,
+                        row_offset, stream) =
+    check(ccall((:pmt_sparse_pack_vector_slabs_u32_f64, lib), Cint,
+                (DevPtr, DevPtr, DevPtr, DevPtr, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
+                nzval, perm32, term_var32, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream))
+
 "dst (cols x rows, leading dimension ldd) = transpose of src (rows x cols, leading dimension lds) — the adjoint rule, src/lazyexpression.jl:206-217"
 transpose!(dst::DevPtr, ldd, src::DevPtr, lds, rows, cols, stream) =
     check(ccall((:pmt_transpose_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, Int64, Ptr{Cvoid}), src, lds, rows, cols, dst, ldd, stream))
