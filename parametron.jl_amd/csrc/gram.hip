@@ -20,7 +20,8 @@
 namespace pmt {
 
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
-int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *out, hipStream_t s);
+int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
+size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s);
@@ -50,6 +51,45 @@ __global__ __launch_bounds__(256) void gram_linear_kernel(const double *__restri
         t.var = moi ? map_var(varmap, v) : v;
         out_lin[col] = t;
     }
+}
+
+// Tall matrices (rows >> cols): one wave per column leaves most of the chip idle (cols = 128: 128 waves read 1 GB) — the rows are cut
+// into `nsplit` chunks, one wave per (column, chunk), and the chunk sums of a column are added in chunk order (deterministic).
+__global__ __launch_bounds__(256) void gram_linear_split_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
+                                                                const double *__restrict__ b, int sign, int64_t chunk,
+                                                                double *__restrict__ partial) {
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= cols) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i0 = (int64_t)blockIdx.y * chunk;
+    const int len = (int)(min(rows, i0 + chunk) - i0);                   // 32-bit loop state: 16 VGPRs, co-resident with the contraction
+    const double *a = A + col * lda + i0, *bb = b + i0;
+    double acc = 0.0;
+    for (int i = lane; i < len; i += 64) acc += signed_const(bb[i], sign) * a[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) partial[(int64_t)blockIdx.y * cols + col] = acc;
+}
+
+__global__ __launch_bounds__(256) void gram_linear_finish_kernel(const double *__restrict__ partial, int nsplit, int64_t cols,
+                                                                 const int64_t *__restrict__ xvar, int moi, const int64_t *__restrict__ varmap,
+                                                                 LT *__restrict__ out_lin) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    double acc = 0.0;
+    for (int k = 0; k < nsplit; ++k) acc += partial[(int64_t)k * cols + col];
+    LT t;
+    t.coeff = 2 * acc;
+    const int64_t v = xvar[col];
+    t.var = moi ? map_var(varmap, v) : v;
+    out_lin[col] = t;
+}
+
+constexpr int64_t LIN_CHUNK_MIN = 4096;      // rows per (column, chunk) wave at least: 64 iterations of 64 lanes
+constexpr int64_t LIN_WAVES = 8192;          // waves that fill the chip (256 CUs x 32)
+static int linear_splits(int64_t rows, int64_t cols) {
+    if (cols <= 0) return 1;
+    return (int)std::max<int64_t>(1, std::min(cdiv(LIN_WAVES, cols), rows / LIN_CHUNK_MIN));
 }
 
 }  // namespace pmt
@@ -92,7 +132,9 @@ static SideStream *side_stream(hipStream_t s) {
 using namespace pmt;
 
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
-    return gram_sk_workspace_bytes(rows, cols);
+    // behind the contraction's partial tiles: chunk sums of q (tall matrices) and the chains of the constant (long vectors)
+    return gram_sk_workspace_bytes(rows, cols) + sizeof(double) * ((size_t)linear_splits(rows, cols) * (size_t)std::max<int64_t>(cols, 0) +
+                                                                   blocked_dot_scratch_doubles());
 }
 
 // the whole node: contraction on the main stream, q = 2A'c and c'c on a side stream.  out_quad (term structs) and out_csc (solver
@@ -119,16 +161,20 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             s2 = side->stream;
         }
         int rc = PMT_OK;
-#ifdef PMT_GRAM_NO_SIDE_KERNELS                          // ablation builds only (tools/): what the co-resident reductions cost the contraction
-        if (false) {
-#else
-        if (cols > 0) {
-#endif
+        double *scratch = workspace ? reinterpret_cast<double *>(static_cast<char *>(workspace) + gram_sk_workspace_bytes(rows, cols)) : nullptr;
+        const int nsplit = (scratch && b && sign) ? linear_splits(rows, cols) : 1;
+        if (cols > 0 && nsplit > 1) {
+            const int64_t chunk = 64 * cdiv(cdiv(rows, nsplit), 64);
+            PMT_LAUNCH(gram_linear_split_kernel, dim3((unsigned)cdiv(cols, 4), (unsigned)nsplit), dim3(256), 0, s2, A, lda, rows, cols, b, sign, chunk, scratch);
+            PMT_LAUNCH(gram_linear_finish_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, s2, scratch, nsplit, cols, xvar, moi, varmap, out_lin);
+            rc = check_launch("gram_linear_split_kernel");
+        } else if (cols > 0) {
             PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s2, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
             rc = check_launch("gram_linear_kernel");
         }
         if (!rc) {
-            if (b && sign && rows > 0) rc = launch_seq_dot(b, sign, b, sign, rows, out_const, s2);
+            double *chains = scratch ? scratch + (size_t)linear_splits(rows, cols) * (size_t)cols : nullptr;
+            if (b && sign && rows > 0) rc = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2);
             else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
         }
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));

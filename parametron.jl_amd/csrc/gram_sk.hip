@@ -439,7 +439,9 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
 }
 
 // one workgroup per tile: if the tile was split, add its partials in ascending workgroup order and write the terms
-template <int TN>
+// APB = accumulators per thread handled by one workgroup: 4 normally; 1 when only a few tiles are split (tall matrices: one tile summed
+// over up to 256 partials) so that the sum is spread over NACC instead of NACC/4 workgroups per tile
+template <int TN, int APB>
 __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     using C = Cfg<TN>;
     const int rtile = blockIdx.x;                                              // index among the remainder (split) tiles
@@ -455,40 +457,43 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     };
     const int blo = owner(ub), bhi = owner(ue);
     if (blo == bhi) return;                                                   // one workgroup did the whole tile
-    // blockIdx.y selects 4 of the NACC accumulators of every thread, so a tile split many ways is summed by NACC/4 workgroups
-    const int r0 = (int)blockIdx.y * 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // blockIdx.y selects APB of the NACC accumulators of every thread, so a tile split many ways is summed by NACC/APB workgroups
+    const int r0 = (int)blockIdx.y * APB;
+    double acc[APB];
+#pragma unroll
+    for (int r = 0; r < APB; ++r) acc[r] = 0.0;
     auto slot_ptr = [&](int b) {
         const int64_t bu0 = sk_unit_begin(g, b);
         const int first_rtile = (int)(bu0 / g.nchunk);
         const int slot = 2 * b + (first_rtile == rtile ? 0 : 1);
         return g.ws + (int64_t)slot * SLOT + (int64_t)r0 * C::NT + tid;
     };
-    // partials are ADDED in ascending workgroup order (deterministic) but LOADED four workgroups at a time, so the kernel is not a
+    // partials are ADDED in ascending workgroup order (deterministic) but LOADED LB workgroups at a time, so the kernel is not a
     // chain of dependent L2 round trips
+    constexpr int LB = APB == 1 ? 16 : 4;
     int b = blo;
-    for (; b + 3 <= bhi; b += 4) {
-        double v[4][4];
+    for (; b + LB - 1 <= bhi; b += LB) {
+        double v[LB][APB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < LB; ++q) {
             const double *w = slot_ptr(b + q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[q][r] = w[r * C::NT];
+            for (int r = 0; r < APB; ++r) v[q][r] = w[r * C::NT];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < LB; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = acc[r] + v[q][r];
+            for (int r = 0; r < APB; ++r) acc[r] = acc[r] + v[q][r];
     }
     for (; b <= bhi; ++b) {
         const double *w = slot_ptr(b);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = acc[r] + w[r * C::NT];
+        for (int r = 0; r < APB; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
     sk_seq_unrank(tile, g.ntiles, jb, kb);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < APB; ++r) {
         int row, col;
         sk_acc_pos<TN>(tid, r0 + r, row, col);
         sk_store_term(g, jb, kb, row, col, acc[r]);
@@ -559,8 +564,9 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
     if (g.nchunk > 1 && R > 0) {
-        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<4>, dim3((unsigned)R, Cfg<4>::NACC / 4), dim3(Cfg<4>::NT), 0, s, g);
-        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", gram_sk_fixup_kernel<2>, dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
+        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<4, 4>), dim3((unsigned)R, Cfg<4>::NACC / 4), dim3(Cfg<4>::NT), 0, s, g);
+        else if (R * (Cfg<2>::NACC / 4) < 256) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }
     return rc;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64) void seq_dot_kernel(const double *__restrict__ 
         if (i >= n) return 0.0;
         const double av = sign_a == 2 ? a[i] : signed_const(a[i], sign_a);
         if (SAME) return av * av;
+        if (sign_b == 3) return av;                        // plain sum of a (second level of launch_blocked_dot)
         const double bv = sign_b == 2 ? b[i] : signed_const(b[i], sign_b);
         return av * bv;
     };
@@ -143,6 +144,41 @@ int launch_seq_dot(const double *a, int sign_a, const double *b, int sign_b, int
     if (a == b && sign_a == sign_b) PMT_LAUNCH_NAMED("seq_dot_kernel", seq_dot_kernel<true>, dim3(1), dim3(64), 0, s, a, sign_a, b, sign_b, (int)n, out);
     else PMT_LAUNCH_NAMED("seq_dot_kernel", seq_dot_kernel<false>, dim3(1), dim3(64), 0, s, a, sign_a, b, sign_b, (int)n, out);
     return check_launch("seq_dot_kernel");
+}
+
+// Long vectors (least squares with many rows): r dependent additions are r x ~25 cycles on one wave — 15 ms at r = 10^6, far more than the
+// contraction they sit beside.  Above DOT_EXACT_MAX elements the sum is taken in DOT_CHAINS interleaved chains (thread t adds the products
+// of elements t, t + DOT_CHAINS, ... in order) and the chain totals are then added left to right by the one-wave kernel above.  Fixed
+// order, so deterministic, but NOT the reference's sequential order: for these lengths the constant is within (n / DOT_CHAINS + DOT_CHAINS)
+// * eps / 2 relative of the exact sum of the same products (positive terms), well inside the 1e-12 of the parity bar.
+constexpr int DOT_EXACT_MAX = 8192;
+constexpr int DOT_CHAINS = 2048;
+
+template <bool SAME>
+__global__ __launch_bounds__(256) void dot_chains_kernel(const double *__restrict__ a, int sign_a, const double *__restrict__ b, int sign_b,
+                                                         int n, double *__restrict__ chains) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0.0;
+    for (int i = t; i < n; i += DOT_CHAINS) {
+        const double av = sign_a == 2 ? a[i] : signed_const(a[i], sign_a);
+        double p;
+        if (SAME) p = av * av;
+        else p = av * (sign_b == 2 ? b[i] : signed_const(b[i], sign_b));
+        acc = acc + p;
+    }
+    chains[t] = acc;
+}
+
+size_t blocked_dot_scratch_doubles() { return DOT_CHAINS; }
+
+// launch_seq_dot for vectors of any length; `scratch` (DOT_CHAINS doubles, device) is only touched above DOT_EXACT_MAX elements
+int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s) {
+    if (n <= DOT_EXACT_MAX || !scratch) return launch_seq_dot(a, sign_a, b, sign_b, n, out, s);
+    if (n >= ((int64_t)1 << 31) - DOT_CHAINS) return fail(PMT_DIMENSION_MISMATCH, "blocked_dot: vector too long");
+    if (a == b && sign_a == sign_b) PMT_LAUNCH_NAMED("dot_chains_kernel", dot_chains_kernel<true>, dim3(DOT_CHAINS / 256), dim3(256), 0, s, a, sign_a, b, sign_b, (int)n, scratch);
+    else PMT_LAUNCH_NAMED("dot_chains_kernel", dot_chains_kernel<false>, dim3(DOT_CHAINS / 256), dim3(256), 0, s, a, sign_a, b, sign_b, (int)n, scratch);
+    if (int rc = check_launch("dot_chains_kernel")) return rc;
+    return launch_seq_dot(scratch, 2, scratch, 3, DOT_CHAINS, out, s);
 }
 
 // ---- bilinearmul!: one block row per x index.  The coefficients of the NEXT row are fetched into registers while the current row's

@@ -38,7 +38,7 @@ def _sample_pairs(rng, n, count):
     return np.concatenate([j, diag, edge[:4], edge[4:]]), np.concatenate([k, diag, [1, n, n, n // 2], [128, 128, 129, n]])
 
 
-@pytest.mark.parametrize("r,n,count", [(4096, 4096, 10000), (16384, 1024, 6000), (4090, 1000, 4000)])
+@pytest.mark.parametrize("r,n,count", [(4096, 4096, 10000), (16384, 1024, 6000), (4090, 1000, 4000), (131072, 256, 3000)])
 def test_canonical_objective_against_cpu_sampled_sums(r, n, count, record_property):
     import gpu_util as g
     q, l, const = _gram(g, r, n)
@@ -57,10 +57,25 @@ def test_canonical_objective_against_cpu_sampled_sums(r, n, count, record_proper
     assert np.array_equal(l["var"], jl)
     np.testing.assert_allclose(l["coeff"], lw, rtol=1e-12, atol=0)
     np.testing.assert_allclose(l["coeff"], lw_ld, rtol=1e-12, atol=0)
-    seq = 0.0
-    for v in 0.0 - b:
-        seq = seq + v * v
-    assert const == seq                                               # the constant is a left-to-right sum: bit for bit
+    if r <= 8192:
+        seq = 0.0
+        for v in 0.0 - b:
+            seq = seq + v * v
+        assert const == seq                                           # the constant is a left-to-right sum: bit for bit
+    else:
+        # long vectors: 2048 interleaved chains, chain totals added left to right (quad.hip, launch_blocked_dot) — the same fixed order here
+        nb = 0.0 - b
+        chains = np.zeros(2048)
+        for i0 in range(0, r, 2048):
+            seg = nb[i0:i0 + 2048]
+            chains[:len(seg)] = chains[:len(seg)] + seg * seg
+        seq = 0.0
+        for v in chains:
+            seq = seq + v
+        assert const == seq
+        import math
+        assert abs(const - math.fsum(nb * nb)) <= 1e-13 * const
+        assert _gram(g, r, n)[2] == const                             # deterministic
     err_hip = float(np.max(np.abs(got - want_ld) / np.abs(want_ld)))
     err_cpu = float(np.max(np.abs(want - want_ld) / np.abs(want_ld)))
     err_lin = float(np.max(np.abs(l["coeff"] - lw_ld) / np.abs(lw_ld)))
