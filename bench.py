@@ -58,6 +58,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 / host-API sections")
     p.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (no per-kernel events)")
+    p.add_argument("--no-side-lane", action="store_true", help="record the constraint pack on the plan's own stream (A/B of the side lane)")
     return p.parse_args()
 
 
@@ -99,7 +100,7 @@ class C2Workload:
 
     n, r, m = 4096, 4096, 512
 
-    def __init__(self, torch, _lib, rank):
+    def __init__(self, torch, _lib, rank, side_lane=True):
         self.torch, self._lib = torch, _lib
         n, r, m = self.n, self.r, self.m
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -132,6 +133,9 @@ class C2Workload:
         _lib.call("pmt_plan_begin_record", self.plan)
         _lib.call("pmt_quad_gram_f64", dptr(self.A), self.lda, r, n, dptr(self.xvar), dptr(self.b), -1, 1, dptr(self.varmap),
                   dptr(self.Q), dptr(self.q), dptr(self.const), dptr(self.ws), rec)
+        # the constraint's MOI copy reads Parameter values only: side lane, exactly as Model.initialize() records it
+        if side_lane:
+            _lib.call("pmt_plan_set_lane", self.plan, 1)
         _lib.call("pmt_affine_pack_vector_f64", dptr(self.Cm), self.ldc, m, n, dptr(self.xvar), dptr(self.d), -1, dptr(self.varmap), 0,
                   dptr(self.Ct), dptr(self.Cc), rec)
         _lib.call("pmt_plan_end_record", self.plan)
@@ -466,7 +470,7 @@ def main():
     if args.workload == "batch":
         return run_batch(args, torch, dist, _lib, rank, world)
 
-    wl = C2Workload(torch, _lib, rank)
+    wl = C2Workload(torch, _lib, rank, side_lane=not args.no_side_lane)
     if args.graph:
         _lib.call("pmt_plan_instantiate_graph", wl.plan)
     for _ in range(args.warmup):

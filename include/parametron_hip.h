@@ -425,6 +425,14 @@ int pmt_plan_staged_synchronize(pmt_plan *plan);
  * pmt_plan_recording_stream(plan) is appended to the plan's tape instead of being launched */
 int pmt_plan_begin_record(pmt_plan *plan);
 int pmt_plan_end_record(pmt_plan *plan);
+/* While recording: lane 1 marks the following calls as SIDE-LANE entries, lane 0 (the default) returns to the plan's stream.  A side-lane
+ * entry must read only buffers that are complete before pmt_plan_update starts (Parameter values) and write outputs that no other
+ * entry of the tape reads — the MOI copy of a constraint built straight from its Parameters (update! of one Constraint,
+ * src/moi_interop.jl:168-175, is independent of every other record).  At replay these entries fork from the plan's stream at the
+ * top of the tape and join at its end; they are queued on the stream's side stream BEHIND the two small reductions of a canonical
+ * least-squares objective, so they are dispatched when the contraction's workgroups are already placed and run while those drain and
+ * while the fix-up pass runs, instead of adding their own kernels and in-stream gaps behind it. */
+int pmt_plan_set_lane(pmt_plan *plan, int lane);
 void *pmt_plan_recording_stream(pmt_plan *plan);
 int64_t pmt_plan_tape_length(const pmt_plan *plan);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls

@@ -62,6 +62,8 @@ synchronize(plan::Plan) = check(ccall((:pmt_plan_synchronize, lib), Cint, (Ptr{C
 recording_stream(plan::Plan) = ccall((:pmt_plan_recording_stream, lib), Ptr{Cvoid}, (Ptr{Cvoid},), plan.handle)
 begin_record!(plan::Plan) = check(ccall((:pmt_plan_begin_record, lib), Cint, (Ptr{Cvoid},), plan.handle))
 end_record!(plan::Plan) = check(ccall((:pmt_plan_end_record, lib), Cint, (Ptr{Cvoid},), plan.handle))
+"while recording: lane 1 = the following calls only read Parameter values and are independent of the rest of the tape (side lane), 0 = back"
+set_lane!(plan::Plan, lane::Integer) = check(ccall((:pmt_plan_set_lane, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, lane))
 "One update!(model) worth of kernels (src/model.jl:132-143): replays the tape, no allocation."
 update!(plan::Plan) = check(ccall((:pmt_plan_update, lib), Cint, (Ptr{Cvoid},), plan.handle))
 

@@ -229,7 +229,12 @@ function record_constraint!(hm::HIPModel, constraint, rec)
     xvar = upload_indices(hm.plan, Int64[v.index for v in da.x])
     b = da.b === nothing ? DevPtr(C_NULL) : device_param!(hm, da.b).buf
     terms, constants = H.alloc(hm.plan, 24 * r * n), H.alloc(hm.plan, 8 * max(r, 1))
+    # A constraint that reads Parameter values only (no transposition recorded on the tape for it) is independent of every other record
+    # (update! of one Constraint, src/moi_interop.jl:168-175): beside a canonical least-squares objective it goes to the plan's side lane
+    side = !da.transposed && hm.objective !== nothing && hm.objective.nquad == div(n * (n + 1), 2) && hm.objective.nlin == n
+    side && H.set_lane!(hm.plan, 1)
     H.affine_pack_vector!(terms, constants, A, lda, r, n, xvar, b, da.sign, hm.varmap, 0, rec)
+    side && H.set_lane!(hm.plan, 0)
     HIPConstraint(constraint, terms, constants, r * n, r)
 end
 

@@ -127,6 +127,13 @@ static SideStream *side_stream(hipStream_t s) {
     return &ss;
 }
 
+// the side stream of calling stream `s` for other users (the plan's side lane, plan.hip): work queued here lines up BEHIND the Gram
+// node's two small reductions, i.e. it is dispatched once the contraction's workgroups are placed and runs as they drain
+hipStream_t side_stream_of(hipStream_t s) {
+    SideStream *ss = side_stream(s);
+    return ss ? ss->stream : nullptr;
+}
+
 }  // namespace pmt
 
 using namespace pmt;

@@ -32,6 +32,9 @@ struct pmt_plan {
     std::vector<void *> allocations;
     size_t bytes = 0;
     std::vector<pmt::Launch> tape;
+    std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane (pmt_plan_set_lane)
+    char record_lane = 0;
+    hipEvent_t lane_fork = nullptr, lane_join = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     char recording_tag = 0;   // &recording_tag is the recording handle
@@ -96,6 +99,7 @@ int dispatch(void *stream, Launch launch) {
         if (plan) {
             if (!plan->recording) return fail(PMT_STATE_ERROR, "plan is not recording (call pmt_plan_begin_record first)");
             plan->tape.push_back(std::move(launch));
+            plan->lanes.push_back(plan->record_lane);
             return PMT_OK;
         }
     }
@@ -226,6 +230,8 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     if (plan->copy_stream) { (void)hipStreamSynchronize(plan->copy_stream); (void)hipStreamDestroy(plan->copy_stream); }
     if (plan->staged) (void)hipEventDestroy(plan->staged);
     if (plan->consumed) (void)hipEventDestroy(plan->consumed);
+    if (plan->lane_fork) (void)hipEventDestroy(plan->lane_fork);
+    if (plan->lane_join) (void)hipEventDestroy(plan->lane_join);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
     for (void *p : plan->allocations) (void)hipFree(p);
@@ -420,14 +426,48 @@ extern "C" int pmt_plan_end_record(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_end_record: null plan");
     PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan is not recording");
     plan->recording = false;
+    plan->record_lane = 0;
     return PMT_OK;
 }
 
+namespace pmt { hipStream_t side_stream_of(hipStream_t s); }
+
+// Side-lane entries (pmt_plan_set_lane) only read buffers that were complete BEFORE the replay started (Parameter values) and write
+// outputs nothing else in the tape reads, so they fork at the top of the replay and join at its end; they are queued on the calling
+// stream's side stream, where a Gram node's small reductions go first — see pmt_plan_set_lane in the header.
 static int replay(pmt_plan *plan, hipStream_t s) {
-    for (auto &l : plan->tape) {
-        int rc = l(s);
+    hipStream_t side = nullptr;
+    bool any = false;
+    for (char l : plan->lanes) any |= (l != 0);
+    if (any && (side = pmt::side_stream_of(s))) {
+        if (!plan->lane_fork) {
+            PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->lane_fork, hipEventDisableTiming));
+            PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->lane_join, hipEventDisableTiming));
+        }
+        PMT_HIP_CHECK(hipEventRecord(plan->lane_fork, s));
+    }
+    bool forked = false;
+    for (size_t i = 0; i < plan->tape.size(); ++i) {
+        hipStream_t target = s;
+        if (side && plan->lanes[i]) {
+            if (!forked) { PMT_HIP_CHECK(hipStreamWaitEvent(side, plan->lane_fork, 0)); forked = true; }
+            target = side;
+        }
+        int rc = plan->tape[i](target);
         if (rc) return rc;
     }
+    if (forked) {
+        PMT_HIP_CHECK(hipEventRecord(plan->lane_join, side));
+        PMT_HIP_CHECK(hipStreamWaitEvent(s, plan->lane_join, 0));
+    }
+    return PMT_OK;
+}
+
+extern "C" int pmt_plan_set_lane(pmt_plan *plan, int lane) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_set_lane: null plan");
+    PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan_set_lane: the plan is not recording");
+    PMT_REQUIRE(lane == 0 || lane == 1, PMT_INVALID_ARGUMENT, "plan_set_lane: lane must be 0 or 1");
+    plan->record_lane = (char)lane;
     return PMT_OK;
 }
 

@@ -127,6 +127,10 @@ class DeviceContext:
         _lib.call("pmt_plan_end_record", self.plan)
         self.recording = False
 
+    def set_lane(self, lane):
+        """while recording: 1 = the following calls are side-lane entries (independent of the rest of the tape), 0 = back to the plan's stream"""
+        _lib.call("pmt_plan_set_lane", self.plan, int(lane))
+
     def replay(self):
         _lib.call("pmt_plan_update", self.plan)
 

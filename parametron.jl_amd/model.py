@@ -121,7 +121,7 @@ class _Backend:
 
 
 class Model:
-    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False, handoff="moi"):       # src/model.jl:10-22
+    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False, handoff="moi", side_lane=True):       # src/model.jl:10-22
         if quadratic_mode not in ("auto", "literal", "canonical"):
             raise ArgumentError("quadratic_mode must be 'auto', 'literal' or 'canonical'")
         if handoff not in ("moi", "device"):
@@ -140,6 +140,7 @@ class Model:
         self._device_index = device
         self._ctx = None
         self._use_graph = use_graph
+        self._side_lane = side_lane
         self._records = []
 
     def __repr__(self):
@@ -278,8 +279,19 @@ class Model:
                 for x in self._order:
                     if isinstance(x, DeviceNode):
                         x.emit(ctx)
-                for e in emitters:
+                # MOI copies of constraints built straight from their Parameters are independent of every other record (update! of one
+                # Constraint, src/moi_interop.jl:168-175).  Beside a canonical least-squares objective they go to the plan's side lane:
+                # queued behind the contraction's small reductions, they run while its workgroups drain and its fix-up pass runs,
+                # instead of adding their kernels and in-stream gaps behind it.
+                gram = any(getattr(r, "mode", "").startswith("canonical") and r.kind == "quad" and getattr(r.expr, "gram_candidate", None) is not None
+                           for r in records)
+                for r, e in zip(records, emitters):
+                    side = gram and self._side_lane and self._side_lane_ok(r)
+                    if side:
+                        ctx.set_lane(1)
                     e(ctx)
+                    if side:
+                        ctx.set_lane(0)
             finally:
                 ctx.end_record()
             # first evaluation with the identity map so that copy_to sees sized, filled functions (src/moi_interop.jl:127,157)
@@ -293,6 +305,16 @@ class Model:
         if self.handoff == "device":
             from .handoff import DeviceQP
             self.device_qp = DeviceQP(self)
+
+    @staticmethod
+    def _side_lane_ok(r):
+        from .device import DDenseAff, DSparseAff, DVarsAff
+        if not getattr(r, "side_lane_ok", False) or not isinstance(r.expr, DeviceNode):
+            return False
+        for x in schedule([r.expr]):                # every node below the record is an implicit block: nothing of it is in the tape
+            if isinstance(x, DeviceNode) and not (isinstance(x.out, (DDenseAff, DVarsAff, DSparseAff)) and not x.out.need_terms):
+                return False
+        return True
 
     def _mapindices(self, indexmap):                                   # src/model.jl:100-107
         for c in self.constraints:

@@ -170,6 +170,7 @@ class _Record:
         writes the solver's CSC values of P directly from the contraction's epilogue and no quadratic term structs at all."""
         out = self.expr.out
         self.varmap_hooks = []                                            # called with the new host varmap whenever it changes
+        self.side_lane_ok = False
         if self.kind == "aff":
             n = out.nterms
             self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
@@ -228,6 +229,7 @@ class _Record:
         if isinstance(out, DDenseAff) and not out.need_terms:
             dc = ctx.alloc(8 * max(out.rows, 1))
             self.dev = {"terms": dt, "consts": dc}
+            self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
             vec = out.vec.buf if out.vec is not None else None
 
             def emit(c):
@@ -237,6 +239,7 @@ class _Record:
         if isinstance(out, DVarsAff) and not out.need_terms:
             dc = ctx.alloc(8 * max(out.rows, 1))
             self.dev = {"terms": dt, "consts": dc}
+            self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
 
             def emit(c):
                 c.call("pmt_vars_addsub_f64", P(out.xvars.buf), out.rows, P(out.vec.buf), out.sign, P(varmap_buf), 0, None, P(dt), P(dc))
@@ -244,6 +247,7 @@ class _Record:
         if isinstance(out, DSparseAff) and not out.need_terms:
             dc = ctx.alloc(8 * max(out.rows, 1))
             self.dev = {"terms": dt, "consts": dc}
+            self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
             sp = out.spmat
             # varmap folded into the per-term variable stream: it changes with the optimizer's index map (mapindices!, src/model.jl:100-107),
             # not per re-evaluation, so the kernel streams varmap[x[col]] instead of gathering it for every term

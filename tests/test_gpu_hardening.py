@@ -92,3 +92,56 @@ def test_recorded_gram_node_rejects_unsorted_xvar():
     g.call("pmt_plan_end_record", plan)
     assert L.pmt_plan_tape_length(plan) == 1
     g.call("pmt_plan_destroy", plan)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_lane_results_equal_the_single_stream_tape(use_graph):
+    """Constraint MOI copies recorded on the plan's side lane (pmt_plan_set_lane; Model.initialize beside a canonical least-squares
+    objective) must give the bytes of the single-stream tape, update after update, with the launch tape and with hipGraph replay."""
+    import parametron_jl_amd as P
+    from parametron_jl_amd import Variable
+
+    def build(side_lane):
+        n, r, m = 300, 520, 70
+        model = P.Model(P.MockOptimizer(variable_offset=3), quadratic_mode="canonical", use_graph=use_graph, side_lane=side_lane)
+        x = [Variable(model) for _ in range(n)]
+        rng = np.random.default_rng(77)
+        fill = lambda a: a.__setitem__(Ellipsis, rng.random(a.shape) - 0.25)
+        A = P.Parameter(fill, np.zeros((r, n)), model)
+        b = P.Parameter(fill, np.zeros(r), model)
+        Cm = P.Parameter(fill, np.zeros((m, n)), model)
+        d = P.Parameter(fill, np.zeros(m), model)
+        lo = P.Parameter(fill, np.zeros(n), model)
+        residual = A * x - b
+        P.objective(model, P.Minimize, P.dot(residual, residual))
+        P.constraint(model, Cm * x == d)
+        P.constraint(model, x, ">=", lo)
+        return model
+
+    a, b = build(True), build(False)
+    a.initialize(); b.initialize()
+    lanes_a = [r for r in a._records if a._side_lane_ok(r)]
+    assert len(lanes_a) == 2                                           # both constraints are eligible; only model `a` uses the lane
+    for _ in range(3):
+        a.update(); b.update()
+        assert a.objective.f.quadratic_terms.tobytes() == b.objective.f.quadratic_terms.tobytes()
+        assert a.objective.f.affine_terms.tobytes() == b.objective.f.affine_terms.tobytes() and a.objective.f.constant == b.objective.f.constant
+        for ca, cb in zip(a.constraints, b.constraints):
+            assert ca.f.terms.tobytes() == cb.f.terms.tobytes() and np.array_equal(ca.f.constants, cb.f.constants)
+    a.close(); b.close()
+
+
+def test_set_lane_state_and_argument_errors():
+    import gpu_util as g
+    import parametron_jl_amd as P
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, None, C.byref(plan))
+    with pytest.raises(P.ErrorException):
+        g.call("pmt_plan_set_lane", plan, 1)                            # not recording
+    g.call("pmt_plan_begin_record", plan)
+    with pytest.raises(P.ArgumentError):
+        g.call("pmt_plan_set_lane", plan, 2)
+    g.call("pmt_plan_set_lane", plan, 1)
+    g.call("pmt_plan_set_lane", plan, 0)
+    g.call("pmt_plan_end_record", plan)
+    g.call("pmt_plan_destroy", plan)
