@@ -73,6 +73,12 @@ int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t rows, int64
                                const int64_t *xvar, const double *b, int sign,
                                const int64_t *varmap, int64_t row_offset,
                                pmt_vector_affine_term *out_terms, double *out_consts, void *stream);
+/* The same node in its BACKGROUND form (identical output): a kernel of at most 16 VGPRs and no LDS, slow on an idle chip but co-resident
+ * with the persistent contraction of pmt_quad_gram_f64 (which leaves 16 of a SIMD's 512 VGPRs free).  Recorded on a plan's side lane
+ * (pmt_plan_set_lane) it runs inside the contraction instead of behind it. */
+int pmt_affine_pack_vector_background_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
+                                          int sign, const int64_t *varmap, int64_t row_offset, pmt_vector_affine_term *out_terms,
+                                          double *out_consts, void *stream);
 
 /* dest[i] = x[i] (+|-) v[i] for x::Vector{Variable}: one term (1.0, xvar[i]) per row, constant 0.0 (+|-) v[i]
  * (`x - l` bounds, test/model.jl:162-163).  vecadd!/vecsubtract! with copyto!(f, ::Variable)
@@ -266,6 +272,15 @@ int pmt_csc_values_f64(const void *src_coeff, int64_t src_stride_bytes, int64_t 
                        int64_t nnz_out, double alpha, const int64_t *dst_index, double *dst_values, void *stream);
 int pmt_qp_bounds_f64(const double *consts, int64_t rows, int set_kind, double set_value, double infty, double *l, double *u,
                       void *stream);
+/* Several term buffers feeding one matrix / several constraint blocks in ONE launch each (a model with k constraint blocks otherwise
+ * pays 2k small kernels and their in-stream gaps per re-evaluation):
+ *   pmt_csc_values_gather_f64: as pmt_csc_values_f64 with term_ptr[p] = device address of the coefficient of the p-th term in CSC order
+ *     (the caller folds base pointer, stride and permutation of every block into it, once);
+ *   pmt_qp_bounds_rows_f64: row i reads its constant through const_ptr[i] and has its own set kind / value. */
+int pmt_csc_values_gather_f64(const double *const *term_ptr, int64_t nnz_in, const int64_t *seg_ptr, int64_t nnz_out, double alpha,
+                              const int64_t *dst_index, double *dst_values, void *stream);
+int pmt_qp_bounds_rows_f64(const double *const *const_ptr, const int *set_kind, const double *set_value, int64_t rows, double infty,
+                           double *l, double *u, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse constraint matrix (BASELINE config 5): C given in CSC (Julia SparseMatrixCSC: colptr/rowval

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pmt_device_count": (_ci, []),
     "pmt_affine_assemble_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_affine_pack_vector_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _i64, _vp, _vp, _vp]),
+    "pmt_affine_pack_vector_background_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _i64, _vp, _vp, _vp]),
     "pmt_vars_addsub_f64": (_ci, [_vp, _i64, _vp, _ci, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pmt_affvec_combine_f64": (_ci, [_i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _i64, _vp, _vp]),
     "pmt_affvec_scale_f64": (_ci, [_i64, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _vp]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "pmt_csc_order": (_ci, [_i64, _vp, _vp, _i64, _i64, _ci, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pmt_csc_values_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "pmt_qp_bounds_f64": (_ci, [_vp, _i64, _ci, _f64, _f64, _vp, _vp, _vp]),
+    "pmt_csc_values_gather_f64": (_ci, [_vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp]),
+    "pmt_qp_bounds_rows_f64": (_ci, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_sparse_assemble_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pmt_sparse_pack_vector_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),

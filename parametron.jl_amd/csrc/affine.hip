@@ -150,6 +150,31 @@ __global__ void consts_kernel(const double *__restrict__ d, int64_t n, int sign,
     if (i < n) out[i] = signed_const(d[i], sign);
 }
 
+// "Background" form of the MOI constraint pack (same output as affine_tile_kernel<VAT>): at most 16 VGPRs and no LDS, so that its
+// waves are CO-RESIDENT with the persistent Gram kernel, which leaves 16 of a SIMD's 512 VGPRs free (gram.hip) — on the plan's side
+// lane it then runs inside the contraction instead of behind it.  One wave per (row, 256-column chunk); lanes read one element of
+// 64 different columns (8-byte reads, one cache line each — the 8 rows that share those lines are handled by the next 7 waves, so
+// they come from L2) and write their 24-byte term.  Slow on its own (it is not the kernel to use on an idle chip), free where it runs.
+__global__ __launch_bounds__(256) void affine_pack_background_kernel(const double *__restrict__ A, int64_t lda, int rows, int cols,
+                                                                     const int64_t *__restrict__ xvar, const int64_t *__restrict__ varmap,
+                                                                     int64_t row_offset, unsigned long long *__restrict__ out) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int chunk = wave / rows, row = wave - chunk * rows;
+    const int c0 = chunk * 256 + lane;
+    const double *a = A + row;
+    unsigned long long *o = out + (int64_t)row * cols * 3;
+    const unsigned long long rowword = (unsigned long long)(row_offset + row + 1);
+#pragma unroll 1
+    for (int c = c0; c < min(cols, chunk * 256 + 256); c += 64) {
+        const double v = a[(int64_t)c * lda];
+        const int64_t var = map_var(varmap, xvar[c]);
+        unsigned long long *p = o + (int64_t)c * 3;
+        p[0] = rowword;
+        p[1] = (unsigned long long)__double_as_longlong(v);
+        p[2] = (unsigned long long)var;
+    }
+}
+
 // ---- MOI copies of materialised native functions (src/moi_interop.jl:35-81)
 __global__ void pack_scalar_affine_kernel(const LT *__restrict__ in, int64_t n, const int64_t *__restrict__ varmap, LT *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,6 +316,27 @@ extern "C" int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t 
                          : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
     return dispatch(stream, [=](hipStream_t s) {
         return launch_affine<1>(A, lda, rows, cols, xvar, b, sign, varmap, row_offset, out_terms, out_consts, s);
+    });
+}
+
+extern "C" int pmt_affine_pack_vector_background_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
+                                                     int sign, const int64_t *varmap, int64_t row_offset, pmt_vector_affine_term *out_terms,
+                                                     double *out_consts, void *stream) {
+    int rc = validate_affine(A, lda, rows, cols, xvar, b, sign, out_terms);
+    if (rc) return rc;
+    PMT_REQUIRE(rows < (1 << 30) && cols < (1 << 30) && cdiv(cols, 256) * rows < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH,
+                "affine_pack_vector_background: block too large");
+    if (rows > 0 && out_consts) {
+        rc = b && sign ? pmt_consts_f64(b, rows, sign, out_consts, stream)
+                       : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
+        if (rc) return rc;
+    }
+    if (rows == 0 || cols == 0) return PMT_OK;
+    return dispatch(stream, [=](hipStream_t s) {
+        const int64_t waves = cdiv(cols, 256) * rows;
+        PMT_LAUNCH(affine_pack_background_kernel, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, s, A, lda, (int)rows, (int)cols, xvar, varmap, row_offset,
+                   reinterpret_cast<unsigned long long *>(out_terms));
+        return check_launch("affine_pack_background_kernel");
     });
 }
 

@@ -30,6 +30,18 @@ __global__ __launch_bounds__(256) void csc_values_thread_kernel(const char *__re
     dst[dst_index ? dst_index[s] : s] = alpha * acc;
 }
 
+// The same with one ABSOLUTE coefficient address per term (several term buffers feeding one matrix in a single launch)
+__global__ __launch_bounds__(256) void csc_values_gather_kernel(const double *const *__restrict__ term_ptr, const int64_t *__restrict__ seg_ptr,
+                                                                int64_t nseg, double alpha, const int64_t *__restrict__ dst_index,
+                                                                double *__restrict__ dst) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    const int64_t p0 = seg_ptr[s], p1 = seg_ptr[s + 1];
+    double acc = *term_ptr[p0];
+    for (int64_t p = p0 + 1; p < p1; ++p) acc += *term_ptr[p];
+    dst[dst_index ? dst_index[s] : s] = alpha * acc;
+}
+
 // One WAVE per run for long runs (literal r*n^2 objectives: every (j,k) has r duplicates): lanes stride the run, fixed butterfly.
 __global__ __launch_bounds__(256) void csc_values_wave_kernel(const char *__restrict__ src, int64_t stride, const int64_t *__restrict__ perm,
                                                               const int64_t *__restrict__ seg_ptr, int64_t nseg, double alpha,
@@ -52,6 +64,18 @@ __global__ __launch_bounds__(256) void qp_bounds_kernel(const double *__restrict
     const double b = value - consts[i];
     l[i] = kind == PMT_SET_LESS ? -infty : b;
     u[i] = kind == PMT_SET_GREATER ? infty : b;
+}
+
+// rows of several constraint blocks in one launch: row i reads its constant through const_ptr[i]
+__global__ __launch_bounds__(256) void qp_bounds_rows_kernel(const double *const *__restrict__ const_ptr, const int *__restrict__ kind,
+                                                             const double *__restrict__ value, int64_t rows, double infty,
+                                                             double *__restrict__ l, double *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const double b = value[i] - *const_ptr[i];
+    const int k = kind[i];
+    l[i] = k == PMT_SET_LESS ? -infty : b;
+    u[i] = k == PMT_SET_GREATER ? infty : b;
 }
 
 }  // namespace pmt
@@ -123,5 +147,27 @@ extern "C" int pmt_qp_bounds_f64(const double *consts, int64_t rows, int set_kin
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(qp_bounds_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, s, consts, rows, set_kind, set_value, infty, l, u);
         return check_launch("qp_bounds_kernel");
+    });
+}
+
+extern "C" int pmt_csc_values_gather_f64(const double *const *term_ptr, int64_t nnz_in, const int64_t *seg_ptr, int64_t nseg, double alpha,
+                                         const int64_t *dst_index, double *dst_values, void *stream) {
+    PMT_REQUIRE(nseg >= 0 && nnz_in >= nseg, PMT_DIMENSION_MISMATCH, "csc_values_gather: need 0 <= nseg <= nnz_in");
+    if (nseg == 0) return PMT_OK;
+    PMT_REQUIRE(term_ptr && seg_ptr && dst_values, PMT_INVALID_ARGUMENT, "csc_values_gather: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_LAUNCH(csc_values_gather_kernel, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s, term_ptr, seg_ptr, nseg, alpha, dst_index, dst_values);
+        return check_launch("csc_values_gather_kernel");
+    });
+}
+
+extern "C" int pmt_qp_bounds_rows_f64(const double *const *const_ptr, const int *set_kind, const double *set_value, int64_t rows, double infty,
+                                      double *l, double *u, void *stream) {
+    PMT_REQUIRE(rows >= 0, PMT_DIMENSION_MISMATCH, "qp_bounds_rows: negative row count");
+    if (rows == 0) return PMT_OK;
+    PMT_REQUIRE(const_ptr && set_kind && set_value && l && u, PMT_INVALID_ARGUMENT, "qp_bounds_rows: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_LAUNCH(qp_bounds_rows_kernel, dim3((unsigned)cdiv(rows, 256)), dim3(256), 0, s, const_ptr, set_kind, set_value, rows, infty, l, u);
+        return check_launch("qp_bounds_rows_kernel");
     });
 }

@@ -219,6 +219,8 @@ extern "C" int pmt_plan_create(int device, void *stream, pmt_plan **out) {
     return PMT_OK;
 }
 
+namespace pmt { hipStream_t side_stream_of(hipStream_t s); void release_side_stream(hipStream_t s); }
+
 extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     if (!plan) return PMT_OK;
     {
@@ -227,6 +229,7 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     }
     (void)hipSetDevice(plan->device);
     (void)hipStreamSynchronize(plan->stream);
+    pmt::release_side_stream(plan->stream);
     if (plan->copy_stream) { (void)hipStreamSynchronize(plan->copy_stream); (void)hipStreamDestroy(plan->copy_stream); }
     if (plan->staged) (void)hipEventDestroy(plan->staged);
     if (plan->consumed) (void)hipEventDestroy(plan->consumed);
@@ -430,7 +433,6 @@ extern "C" int pmt_plan_end_record(pmt_plan *plan) {
     return PMT_OK;
 }
 
-namespace pmt { hipStream_t side_stream_of(hipStream_t s); }
 
 // Side-lane entries (pmt_plan_set_lane) only read buffers that were complete BEFORE the replay started (Parameter values) and write
 // outputs nothing else in the tape reads, so they fork at the top of the replay and join at its end; they are queued on the calling

@@ -54,7 +54,7 @@ class CSC:
 
 
 class DeviceQP:
-    def __init__(self, model, infty=DEFAULT_INFTY):
+    def __init__(self, model, infty=DEFAULT_INFTY, in_tape=False):
         if not model.initialized:
             raise ErrorException("DeviceQP needs an initialized model (initialize!(model) / solve!(model) first)")
         self.model, self.infty = model, float(infty)
@@ -139,16 +139,36 @@ class DeviceQP:
         self.nrows = m = row0
         self.A = self._build_matrix(ablocks, m, n, upper=False, alpha=1.0)
         self.l_ptr, self.u_ptr = ctx.alloc(8 * max(m, 1)), ctx.alloc(8 * max(m, 1))
-        for (r0, nr, kind, value, dev_consts, host_consts) in bounds:
-            if dev_consts is None:                                     # constant function: bounds never change
+        if m and any(dev_consts is not None for (_, _, _, _, dev_consts, _) in bounds):
+            # all rows in one launch: row i reads its constant through an address (constant functions get a device copy of theirs)
+            cptr, kinds, values_ = np.zeros(m, dtype=np.uint64), np.zeros(m, dtype=np.int32), np.zeros(m)
+            for (r0, nr, kind, value, dev_consts, host_consts) in bounds:
+                base = dev_consts if dev_consts is not None else ctx.upload_new(np.ascontiguousarray(host_consts, dtype=np.float64))
+                cptr[r0:r0 + nr] = np.uint64(base) + np.uint64(8) * np.arange(nr, dtype=np.uint64)
+                kinds[r0:r0 + nr], values_[r0:r0 + nr] = kind, value
+            self._launches.append(("pmt_qp_bounds_rows_f64", (P(ctx.upload_new(cptr)), P(ctx.upload_new(kinds)), P(ctx.upload_new(values_)), m, self.infty,
+                                                              P(self.l_ptr), P(self.u_ptr))))
+        else:
+            for (r0, nr, kind, value, dev_consts, host_consts) in bounds:          # constant functions only: bounds never change
                 b = value - host_consts
                 lo = np.full(nr, -self.infty) if kind == 2 else b
                 hi = np.full(nr, self.infty) if kind == 1 else b
                 ctx.upload(self.l_ptr + 8 * r0, lo); ctx.upload(self.u_ptr + 8 * r0, hi)
-            else:
-                self._launches.append(("pmt_qp_bounds_f64", (P(dev_consts), nr, kind, value, self.infty, P(self.l_ptr + 8 * r0), P(self.u_ptr + 8 * r0))))
         ctx.synchronize()
-        self.refresh()
+        self._in_tape = False
+        if in_tape and self._launches:
+            ctx.begin_record()
+            try:
+                ctx.set_lane(1)
+                for name, args in self._launches:
+                    ctx.call(name, *args)
+                ctx.set_lane(0)
+            finally:
+                ctx.end_record()
+            self._in_tape = True
+            model._run_tape(fetch=False)
+        else:
+            self.refresh()
 
     # ---- structure
     def _build_matrix(self, blocks, nrows, ncols, upper, alpha):
@@ -179,6 +199,7 @@ class DeviceQP:
         values = ctx.alloc(8 * max(len(ukey), 1))
         static = np.zeros(max(len(ukey), 1))
         pos = 0
+        addr, segs, dsts, nterms = [], [], [], 0            # the device blocks, folded into ONE gather launch (term addresses are static)
         for (b, perm, seg, cols, row_idx) in local:
             k = len(row_idx)
             dst = np.ascontiguousarray(inverse[pos:pos + k], dtype=np.int64)
@@ -187,12 +208,18 @@ class DeviceQP:
                 sums = np.add.reduceat(b.host_coeff[perm], seg[:-1]) if k else np.zeros(0)
                 static[dst] = alpha * sums
             elif k:
-                identity = len(local) == 1
-                if b.source_perm is not None:
-                    perm = np.ascontiguousarray(b.source_perm[perm], dtype=np.int64)
-                self._launches.append(("pmt_csc_values_f64", (P(b.coeff_ptr), b.stride, len(perm), P(ctx.upload_new(perm)), P(ctx.upload_new(seg)), k,
-                                                              alpha, None if identity else P(ctx.upload_new(dst)), P(values))))
+                src = perm if b.source_perm is None else b.source_perm[perm]
+                addr.append(np.uint64(b.coeff_ptr) + src.astype(np.uint64) * np.uint64(b.stride))
+                segs.append(seg[:-1] + nterms)
+                dsts.append(dst)
+                nterms += len(perm)
         ctx.upload(values, static)
+        if addr:
+            seg_all = np.concatenate(segs + [np.array([nterms], dtype=np.int64)]).astype(np.int64)
+            dst_all = np.concatenate(dsts)
+            identity = len(dst_all) == len(ukey) and np.array_equal(dst_all, np.arange(len(dst_all)))
+            self._launches.append(("pmt_csc_values_gather_f64", (P(ctx.upload_new(np.concatenate(addr))), nterms, P(ctx.upload_new(seg_all)), len(dst_all),
+                                                                 alpha, None if identity else P(ctx.upload_new(dst_all)), P(values))))
         return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), values)
 
     def _add_vector_block(self, b, n, q_ptr, alpha):
@@ -211,6 +238,8 @@ class DeviceQP:
     # ---- per re-evaluation
     def refresh(self):
         """Rebuild P.x, q, A.x, l, u from the model's current device MOI buffers (call after update!(model) / solve!(model))."""
+        if self._in_tape:
+            return                                  # part of the model's tape (side lane): rebuilt by update!(model) itself
         for name, args in self._launches:
             self.ctx.call(name, *args)
 

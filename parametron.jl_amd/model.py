@@ -285,10 +285,13 @@ class Model:
                 # instead of adding their kernels and in-stream gaps behind it.
                 gram = any(getattr(r, "mode", "").startswith("canonical") and r.kind == "quad" and getattr(r.expr, "gram_candidate", None) is not None
                            for r in records)
+                self._lane_records = []
                 for r, e in zip(records, emitters):
                     side = gram and self._side_lane and self._side_lane_ok(r)
                     if side:
                         ctx.set_lane(1)
+                        self._lane_records.append(r)
+                        r.on_side_lane = True
                     e(ctx)
                     if side:
                         ctx.set_lane(0)
@@ -299,12 +302,19 @@ class Model:
         if not early:
             indexmap = self.optimizer.copy_to(backend)
             self._mapindices(indexmap)
-        if records and self._use_graph:
-            self.device().instantiate_graph()
         self.initialized = True
         if self.handoff == "device":
             from .handoff import DeviceQP
-            self.device_qp = DeviceQP(self)
+            # When every constraint's MOI copy sits on the side lane and the objective is the Gram node (whose affine part is written on
+            # the same side stream), the hand-off launches read side-stream outputs only: they are appended to the tape as side-lane
+            # entries too and leave the plan's stream to the contraction.  Otherwise they are launched behind the tape on every update.
+            obj = self.objective
+            in_tape = bool(records) and (obj.isconstant or "P_values" in (obj.dev or {})) and \
+                all(c.isconstant or any(c is r for r in getattr(self, "_lane_records", [])) for c in self.constraints) and \
+                any(not c.isconstant for c in self.constraints)
+            self.device_qp = DeviceQP(self, in_tape=in_tape)
+        if records and self._use_graph:
+            self.device().instantiate_graph()
 
     @staticmethod
     def _side_lane_ok(r):

@@ -171,6 +171,7 @@ class _Record:
         out = self.expr.out
         self.varmap_hooks = []                                            # called with the new host varmap whenever it changes
         self.side_lane_ok = False
+        self.on_side_lane = False
         if self.kind == "aff":
             n = out.nterms
             self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
@@ -233,8 +234,10 @@ class _Record:
             vec = out.vec.buf if out.vec is not None else None
 
             def emit(c):
-                c.call("pmt_affine_pack_vector_f64", P(out.mat.buf), out.mat.lda, out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec),
-                       out.sign if vec else 0, P(varmap_buf), 0, P(dt), P(dc))
+                # on the side lane (Model.initialize sets on_side_lane before recording): the low-footprint kernel that is co-resident with
+                # the contraction it runs beside
+                c.call("pmt_affine_pack_vector_background_f64" if self.on_side_lane else "pmt_affine_pack_vector_f64", P(out.mat.buf), out.mat.lda,
+                       out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec), out.sign if vec else 0, P(varmap_buf), 0, P(dt), P(dc))
             return emit
         if isinstance(out, DVarsAff) and not out.need_terms:
             dc = ctx.alloc(8 * max(out.rows, 1))

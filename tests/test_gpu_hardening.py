@@ -145,3 +145,23 @@ def test_set_lane_state_and_argument_errors():
     g.call("pmt_plan_set_lane", plan, 0)
     g.call("pmt_plan_end_record", plan)
     g.call("pmt_plan_destroy", plan)
+
+
+@pytest.mark.parametrize("rows,cols,sign", [(1, 1, 0), (7, 300, -1), (130, 257, 1), (512, 1030, -1)])
+def test_background_constraint_pack_writes_the_bytes_of_the_tile_kernel(rows, cols, sign):
+    """pmt_affine_pack_vector_background_f64 (<= 16 VGPRs, no LDS: co-resident with the contraction on the side lane) against
+    pmt_affine_pack_vector_f64 on the same padded-lda input: terms and constants byte for byte."""
+    import gpu_util as g
+    rng = np.random.default_rng(rows * cols)
+    lda = rows + 3
+    A = np.zeros((cols, lda)); A[:, :rows] = rng.random((cols, rows)) - 0.5          # column-major with padding rows
+    b = rng.random(rows)
+    xvar = rng.permutation(cols + 5)[:cols].astype(np.int64) + 1
+    varmap = rng.permutation(cols + 5).astype(np.int64) + 1
+    dA, db, dx, dv = g.to_dev(A.ravel()), g.to_dev(b), g.to_dev(xvar), g.to_dev(varmap)
+    t0, t1 = g.empty_terms(rows * cols, g.VAT), g.empty_terms(rows * cols, g.VAT)
+    c0, c1 = g.empty_f64(rows), g.empty_f64(rows)
+    for name, t, c in (("pmt_affine_pack_vector_f64", t0, c0), ("pmt_affine_pack_vector_background_f64", t1, c1)):
+        g.call(name, g.ptr(dA), lda, rows, cols, g.ptr(dx), g.ptr(db) if sign else None, sign, g.ptr(dv), 11, g.ptr(t), g.ptr(c), g.stream())
+    g.assert_terms_equal(g.terms_to_host(t1, rows * cols, g.VAT), g.terms_to_host(t0, rows * cols, g.VAT))
+    assert np.array_equal(g.f64_to_host(c1, rows), g.f64_to_host(c0, rows))
