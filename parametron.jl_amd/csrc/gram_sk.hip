@@ -565,7 +565,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     if (rc) return rc;
     if (g.nchunk > 1 && R > 0) {
         if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<4, 4>), dim3((unsigned)R, Cfg<4>::NACC / 4), dim3(Cfg<4>::NT), 0, s, g);
-        else if (R * (Cfg<2>::NACC / 4) < 256) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        else if (R * (Cfg<2>::NACC / 4) < 64) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }
