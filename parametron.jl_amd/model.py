@@ -286,8 +286,12 @@ class Model:
                 gram = any(getattr(r, "mode", "").startswith("canonical") and r.kind == "quad" and getattr(r.expr, "gram_candidate", None) is not None
                            for r in records)
                 self._lane_records = []
+                # one small kernel on the lane does not pay (config 2: the co-resident pack slows the contraction by what it saves); several
+                # do (config 3: -0.15 ms), and so does the device hand-off, whose launches join them on the lane
+                eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane) else []
+                use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and self.handoff == "device")
                 for r, e in zip(records, emitters):
-                    side = gram and self._side_lane and self._side_lane_ok(r)
+                    side = use_lane and any(r is x for x in eligible)
                     if side:
                         ctx.set_lane(1)
                         self._lane_records.append(r)

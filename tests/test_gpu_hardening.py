@@ -121,7 +121,7 @@ def test_side_lane_results_equal_the_single_stream_tape(use_graph):
     a, b = build(True), build(False)
     a.initialize(); b.initialize()
     lanes_a = [r for r in a._records if a._side_lane_ok(r)]
-    assert len(lanes_a) == 2                                           # both constraints are eligible; only model `a` uses the lane
+    assert len(lanes_a) == 2 and len(a._lane_records) == 2 and len(b._lane_records) == 0     # both eligible; only model `a` uses the lane
     for _ in range(3):
         a.update(); b.update()
         assert a.objective.f.quadratic_terms.tobytes() == b.objective.f.quadratic_terms.tobytes()

@@ -30,7 +30,7 @@ json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 tr = sorted(csv.DictReader(open(glob.glob(out + "/stats/*/*kernel_trace.csv")[0])), key=lambda r: int(r["Start_Timestamp"]))
 bu = json.load(open(out + "/bench_under_rocprof.json"))
 lines = ["rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`, per-launch durations split at the timed region (last %d launches):" % bu["steps"]]
-for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_pack_background_kernel"):
+for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if name in r["Kernel_Name"]]
     last = d[-bu["steps"]:]
     lines.append("%-28s %3d launches; timed region: avg %.1f us, min %.1f, max %.1f; before it: avg %.1f us" %
