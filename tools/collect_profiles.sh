@@ -29,12 +29,16 @@ json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 # per-launch durations of the timed region only (the stats CSV averages over spin-up and warm-up launches too)
 tr = sorted(csv.DictReader(open(glob.glob(out + "/stats/*/*kernel_trace.csv")[0])), key=lambda r: int(r["Start_Timestamp"]))
 bu = json.load(open(out + "/bench_under_rocprof.json"))
-lines = ["rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`, per-launch durations split at the timed region (last %d launches):" % bu["steps"]]
+# launches of a step's kernel in start order: setup spin-up, W warm-up steps, then the K timed steps (everything later in the process —
+# the separate all-kernel pass, the refresh variant, the other configurations — comes after them)
+first = bu["config"]["setup_spinup_steps"] + bu["warmup"]
+lines = ["rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`, per-launch durations of the TIMED REGION (launches %d..%d of each kernel):"
+         % (first, first + bu["steps"] - 1)]
 for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if name in r["Kernel_Name"]]
-    last = d[-bu["steps"]:]
-    lines.append("%-28s %3d launches; timed region: avg %.1f us, min %.1f, max %.1f; before it: avg %.1f us" %
-                 (name, len(d), sum(last) / len(last), min(last), max(last), sum(d[:-len(last)]) / max(1, len(d) - len(last))))
+    reg = d[first:first + bu["steps"]]
+    lines.append("%-28s %3d launches in the process; timed region: avg %.1f us, min %.1f, max %.1f; spin-up + warm-up before it: avg %.1f us" %
+                 (name, len(d), sum(reg) / len(reg), min(reg), max(reg), sum(d[:first]) / max(1, first)))
 lines.append("bench.py's HIP-event average for the dominant kernel in the same run: %.1f us" % (bu["roofline"]["avg_ms"] * 1e3))
 open(out + "/rocprofv3_timed_region.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
