@@ -376,3 +376,41 @@ def test_sparse_constraint_block_is_handed_over_from_nzval(case):
             want[:g, vm] = G.val
         assert np.array_equal(dense_of(got["A"], (rows, n)), want)
         assert np.array_equal(got["l"][rows - m:], d.val) and np.array_equal(got["u"][rows - m:], d.val)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_handoff_recorded_on_the_side_lane_equals_the_launches_behind_the_tape(use_graph):
+    """With a Gram objective and constraints built straight from Parameters the hand-off launches (one fused gather for A, one for q, one
+    bounds kernel) are side-lane entries of the model's tape (DeviceQP._in_tape); with side_lane=False they are launched behind the tape on
+    every update.  Both must hand over the same QP, update after update, with the launch tape and with hipGraph replay."""
+    n, r, m = 40, 64, 6
+
+    def build(side_lane):
+        model = P.Model(P.MockOptimizer(variable_offset=1), quadratic_mode="canonical", handoff="device", use_graph=use_graph, side_lane=side_lane)
+        x = [Variable(model) for _ in range(n)]
+        rng = np.random.default_rng(31)
+        fill = lambda a: a.__setitem__(Ellipsis, rng.random(a.shape) - 0.4)
+        A = P.Parameter(fill, np.zeros((r, n)), model)
+        b = P.Parameter(fill, np.zeros(r), model)
+        G = P.Parameter(fill, np.zeros((m, n)), model)
+        h = P.Parameter(fill, np.zeros(m), model)
+        lo = P.Parameter(fill, np.zeros(n), model)
+        residual = A * x - b
+        P.objective(model, P.Minimize, P.dot(residual, residual))
+        P.constraint(model, G * x, "<=", h)
+        P.constraint(model, x, ">=", lo)
+        model.initialize()
+        return model
+
+    a, b = build(True), build(False)
+    assert a.device_qp._in_tape and not b.device_qp._in_tape
+    for _ in range(3):
+        a.update(); b.update()
+        qa, qb = a.device_qp.fetch(), b.device_qp.fetch()
+        for key in ("q", "l", "u"):
+            assert np.array_equal(qa[key], qb[key])
+        for key in ("P", "A"):
+            for u, v in zip(qa[key], qb[key]):
+                assert np.array_equal(u, v)
+        assert qa["r"] == qb["r"]
+    a.close(); b.close()
