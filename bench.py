@@ -377,7 +377,7 @@ def cpu_baseline(wl):
     """The reference's literal CPU path restated in C (oracle/, single thread like the reference), timed on this box's host cores.
     BASELINE.md §2: affine nodes and the constraint MOI copy at full size; the literal quadratic expansion + MOI copy at
     n = r in {64, 128, 256, 512}, fitted as c*n^3 and extrapolated to n = 4096 (the full literal objective is 1.65 TB and cannot be
-    materialised); cross-check: 2 of the 4096 residual rows at full width, extrapolated x2048."""
+    materialised); cross-check: 8 of the 4096 residual rows at full width, extrapolated x512.  About 5 s of single-core work in all."""
     import numpy as np
     from oracle import oracle as O
     n, r, m = wl.n, wl.r, wl.m
@@ -387,7 +387,7 @@ def cpu_baseline(wl):
     d = O.fill_uniform(m, 4, 2.0)
     xvar = np.arange(1, n + 1, dtype=np.int64)
     w = O.LsqWorkspace(n, r, m)
-    rows = 2
+    rows = 8                                 # 8 x 4096^2 literal terms = 3.2 GB (+ the same again as MOI terms)
 
     def affine_part():
         w.eval_residual(A, b, xvar)
@@ -416,9 +416,12 @@ def cpu_baseline(wl):
         wk = O.LsqWorkspace(k, k, 1)
         wk.eval_residual(Ak, bk, xk)
         wk.eval_vecdot(-1); wk.objective.moi(xk)                 # first touch
-        t0 = time.perf_counter()
-        wk.eval_vecdot(-1); wk.objective.moi(xk)
-        times.append(time.perf_counter() - t0)
+        best = float("inf")
+        for _ in range(3):                                        # best of 3: the host is shared with the driver's own processes
+            t0 = time.perf_counter()
+            wk.eval_vecdot(-1); wk.objective.moi(xk)
+            best = min(best, time.perf_counter() - t0)
+        times.append(best)
         del wk
     n3 = np.array([float(k) ** 3 for k in sizes])
     c = float(np.dot(n3, times) / np.dot(n3, n3))                 # least squares through the origin
@@ -430,7 +433,7 @@ def cpu_baseline(wl):
                       "EXTRAPOLATED to n = 4096 (%.1f s) — the full literal objective is 1.65 TB and cannot be materialised"
                       % (t_aff, ", ".join("%.4f" % t for t in times), c, t_quad_fit),
             "seconds_per_reevaluation_extrapolated": total,
-            "cross_check_two_rows": {"seconds_per_reevaluation_extrapolated": cross_check, "re_evaluations_per_s": 1.0 / cross_check,
+            "cross_check_rows": {"seconds_per_reevaluation_extrapolated": cross_check, "re_evaluations_per_s": 1.0 / cross_check,
                                      "sample": "%d of %d residual rows at full width (%.3f s), x%d" % (rows, r, t_quad_rows, r // rows)}}
 
 
