@@ -35,9 +35,24 @@ def main():
     for _ in range(3):
         P.solve(model)
     k = 10
+    if "--staged" in sys.argv:
+        # overlapped uploads: the values of solve k+1 travel on the copy stream while solve k runs (Model.stage_parameters)
+        def step():
+            model.stage_parameters()
+            model.update(synchronize=False)
+            model.optimizer.optimize()
+    else:
+        def step():
+            P.solve(model)
+    for _ in range(3):
+        step()
+    model.device().synchronize()
     t0 = time.perf_counter()
     for _ in range(k):
-        P.solve(model)
+        step()
+    model.device().synchronize()
+    if "--staged" in sys.argv:
+        model.wait_staged()
     dt = (time.perf_counter() - t0) / k
     if device:
         qp = model.device_qp
