@@ -435,6 +435,10 @@ int pmt_plan_wait_staged(pmt_plan *plan);
 int pmt_plan_commit_staged(pmt_plan *plan, void *device_dst, const void *device_staging, size_t bytes);
 int pmt_plan_staging_consumed(pmt_plan *plan);
 int pmt_plan_staged_synchronize(pmt_plan *plan);
+/* Two staging SLOTS (0 / 1): the four calls above act on the current slot, each slot with its own staged / consumed events.  Alternating
+ * the slot — and the staging buffers — from one update to the next lets the copy of update k+1 start while the commits of update k are
+ * still reading theirs (with one slot it has to wait for them).  Optional: without this call everything uses slot 0. */
+int pmt_plan_stage_slot(pmt_plan *plan, int slot);
 
 /* recording: between begin_record and end_record every pmt_*_f64 call issued with stream ==
  * pmt_plan_recording_stream(plan) is appended to the plan's tape instead of being launched */

@@ -180,6 +180,8 @@ commit_staged!(plan::Plan, dst::DevPtr, staging::DevPtr, bytes) =
     check(ccall((:pmt_plan_commit_staged, lib), Cint, (Ptr{Cvoid}, DevPtr, DevPtr, Csize_t), plan.handle, dst, staging, bytes))
 staging_consumed!(plan::Plan) = check(ccall((:pmt_plan_staging_consumed, lib), Cint, (Ptr{Cvoid},), plan.handle))
 staged_synchronize(plan::Plan) = check(ccall((:pmt_plan_staged_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
+"staging slot (0 / 1) of the calls above; alternate it (and the staging buffers) per update so the next copy does not wait for this update's commits"
+stage_slot!(plan::Plan, slot::Integer) = check(ccall((:pmt_plan_stage_slot, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, slot))
 
 # ---- batched independent models across GPUs (BASELINE config 4): the library's own RCCL communicator
 "rank 0: a fresh 128-byte id; carry it to the other ranks with whatever launcher is at hand (MPI.jl, Distributed, a file)"

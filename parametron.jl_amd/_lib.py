@@ -124,6 +124,7 @@ SIGNATURES = {
     "pmt_plan_commit_staged": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_staging_consumed": (_ci, [_vp]),
     "pmt_plan_staged_synchronize": (_ci, [_vp]),
+    "pmt_plan_stage_slot": (_ci, [_vp, _ci]),
     "pmt_plan_begin_record": (_ci, [_vp]),
     "pmt_plan_end_record": (_ci, [_vp]),
     "pmt_plan_set_lane": (_ci, [_vp, _ci]),

@@ -40,9 +40,11 @@ struct pmt_plan {
     char recording_tag = 0;   // &recording_tag is the recording handle
     // staged (overlapped) uploads of host-updated Parameter values: a copy stream of its own and two events
     hipStream_t copy_stream = nullptr;
-    hipEvent_t staged = nullptr;     // recorded on the copy stream behind every staged upload
-    hipEvent_t consumed = nullptr;   // recorded on the plan stream behind every commit (the staging buffer may be overwritten after it)
-    bool consumed_recorded = false;
+    // two SLOTS (pmt_plan_stage_slot): the values of update k+1 travel into slot (k+1) % 2 while the commits of update k still read slot k % 2
+    hipEvent_t staged[2] = {nullptr, nullptr};     // recorded on the copy stream behind every staged upload of the slot
+    hipEvent_t consumed[2] = {nullptr, nullptr};   // recorded on the plan stream behind the slot's commits (its staging buffers may be overwritten after it)
+    bool consumed_recorded[2] = {false, false};
+    int slot = 0;
 };
 
 namespace pmt {
@@ -231,8 +233,10 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     (void)hipStreamSynchronize(plan->stream);
     pmt::release_side_stream(plan->stream);
     if (plan->copy_stream) { (void)hipStreamSynchronize(plan->copy_stream); (void)hipStreamDestroy(plan->copy_stream); }
-    if (plan->staged) (void)hipEventDestroy(plan->staged);
-    if (plan->consumed) (void)hipEventDestroy(plan->consumed);
+    for (int i = 0; i < 2; ++i) {
+        if (plan->staged[i]) (void)hipEventDestroy(plan->staged[i]);
+        if (plan->consumed[i]) (void)hipEventDestroy(plan->consumed[i]);
+    }
     if (plan->lane_fork) (void)hipEventDestroy(plan->lane_fork);
     if (plan->lane_join) (void)hipEventDestroy(plan->lane_join);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
@@ -339,16 +343,18 @@ static int ensure_copy_stream(pmt_plan *plan) {
     if (plan->copy_stream) return PMT_OK;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamCreateWithFlags(&plan->copy_stream, hipStreamNonBlocking));
-    PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->staged, hipEventDisableTiming));
-    PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->consumed, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->staged[i], hipEventDisableTiming));
+        PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->consumed[i], hipEventDisableTiming));
+    }
     return PMT_OK;
 }
 
 static int stage_prologue(pmt_plan *plan) {
     if (int rc = ensure_copy_stream(plan)) return rc;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
-    // the staging buffers may still be being read by the commits of the previous update
-    if (plan->consumed_recorded) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed, 0));
+    // the slot's staging buffers may still be being read by the commits of the update that used the slot last
+    if (plan->consumed_recorded[plan->slot]) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed[plan->slot], 0));
     return PMT_OK;
 }
 
@@ -358,7 +364,7 @@ extern "C" int pmt_plan_stage_upload(pmt_plan *plan, void *device_staging, const
     PMT_REQUIRE(device_staging && host_src, PMT_INVALID_ARGUMENT, "plan_stage_upload: null pointer");
     if (int rc = stage_prologue(plan)) return rc;
     PMT_HIP_CHECK(hipMemcpyAsync(device_staging, host_src, bytes, hipMemcpyHostToDevice, plan->copy_stream));
-    PMT_HIP_CHECK(hipEventRecord(plan->staged, plan->copy_stream));
+    PMT_HIP_CHECK(hipEventRecord(plan->staged[plan->slot], plan->copy_stream));
     return PMT_OK;
 }
 
@@ -369,7 +375,7 @@ extern "C" int pmt_plan_stage_upload_2d(pmt_plan *plan, void *device_staging, si
     PMT_REQUIRE(device_staging && host_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_stage_upload_2d: bad argument");
     if (int rc = stage_prologue(plan)) return rc;
     PMT_HIP_CHECK(hipMemcpy2DAsync(device_staging, dst_pitch, host_src, src_pitch, width_bytes, height, hipMemcpyHostToDevice, plan->copy_stream));
-    PMT_HIP_CHECK(hipEventRecord(plan->staged, plan->copy_stream));
+    PMT_HIP_CHECK(hipEventRecord(plan->staged[plan->slot], plan->copy_stream));
     return PMT_OK;
 }
 
@@ -379,7 +385,7 @@ extern "C" int pmt_plan_wait_staged(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_wait_staged: null plan");
     if (!plan->copy_stream) return PMT_OK;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
-    PMT_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->staged, 0));
+    PMT_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->staged[plan->slot], 0));
     return PMT_OK;
 }
 
@@ -396,8 +402,18 @@ extern "C" int pmt_plan_staging_consumed(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_staging_consumed: null plan");
     if (int rc = ensure_copy_stream(plan)) return rc;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
-    PMT_HIP_CHECK(hipEventRecord(plan->consumed, plan->stream));
-    plan->consumed_recorded = true;
+    PMT_HIP_CHECK(hipEventRecord(plan->consumed[plan->slot], plan->stream));
+    plan->consumed_recorded[plan->slot] = true;
+    return PMT_OK;
+}
+
+// Two staging slots: stage_upload / wait_staged / commit_staged / staging_consumed act on the CURRENT slot.  A host that alternates the slot
+// (and its staging buffers) from one update to the next lets the copy of update k+1 start while the commits of update k are still
+// reading their staging buffers; a host that never calls this uses slot 0 throughout (one staging buffer per Parameter).
+extern "C" int pmt_plan_stage_slot(pmt_plan *plan, int slot) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_stage_slot: null plan");
+    PMT_REQUIRE(slot == 0 || slot == 1, PMT_INVALID_ARGUMENT, "plan_stage_slot: slot must be 0 or 1");
+    plan->slot = slot;
     return PMT_OK;
 }
 

@@ -24,6 +24,9 @@ class DeviceContext:
         self._keep = []          # host arrays that must outlive asynchronous uploads
         self._keep_staged = []   # ... and staged uploads (copy stream)
         self._staging_dirty = False
+        self._stage_slot = 0            # current staging slot; _next_stage_slot alternates per stage_parameters(), _pending_slot is what update! consumes
+        self._next_stage_slot = 0
+        self._pending_slot = 0
 
     def close(self):
         if self.plan:
@@ -102,6 +105,12 @@ class DeviceContext:
 
     def staging_consumed(self):
         _lib.call("pmt_plan_staging_consumed", self.plan)
+
+    def set_stage_slot(self, slot):
+        """the staging slot (0 / 1) the stage / wait / commit / consumed calls act on; Model.stage_parameters() alternates it so that the
+        copy of update k+1 does not wait for the commits of update k"""
+        self._stage_slot = int(slot)
+        _lib.call("pmt_plan_stage_slot", self.plan, int(slot))
 
     def staged_synchronize(self):
         """host: the staged uploads issued so far have left the host buffers"""
@@ -228,31 +237,36 @@ class DMat(DV):
         if not (self.rows and self.cols):
             self._staged_kind = None
             return
+        slot = ctx._stage_slot                                     # one pair of staging buffers per slot (pmt_plan_stage_slot)
+        if not hasattr(self, "_stage_rm"):
+            self._stage_rm, self._staging_cm = {}, {}
+        self._staged_slot = slot
         if m.flags.c_contiguous and not m.flags.f_contiguous:
-            if getattr(self, "_stage", None) is None:
-                self._stage = ctx.alloc(8 * self.rows * self.cols)
-            ctx.stage_upload(self._stage, m)
+            if slot not in self._stage_rm:
+                self._stage_rm[slot] = ctx.alloc(8 * self.rows * self.cols)
+            ctx.stage_upload(self._stage_rm[slot], m)
             self._staged_kind = "rowmajor"
             return
-        if getattr(self, "_staging", None) is None:
-            self._staging = ctx.alloc(8 * self.lda * self.cols)
+        if slot not in self._staging_cm:
+            self._staging_cm[slot] = ctx.alloc(8 * self.lda * self.cols)
             if self.lda != self.rows:
-                ctx.zero(self._staging, 8 * self.lda * self.cols)
+                ctx.zero(self._staging_cm[slot], 8 * self.lda * self.cols)
                 ctx.synchronize()                                  # (setup: the padding rows are zero before the copy stream writes beside them)
         m = np.asfortranarray(m)
         ctx._keep_staged.append(m)
-        _lib.call("pmt_plan_stage_upload_2d", ctx.plan, C.c_void_p(self._staging), 8 * self.lda, m.ctypes.data_as(C.c_void_p), 8 * self.rows,
+        _lib.call("pmt_plan_stage_upload_2d", ctx.plan, C.c_void_p(self._staging_cm[slot]), 8 * self.lda, m.ctypes.data_as(C.c_void_p), 8 * self.rows,
                   8 * self.rows, self.cols)
         self._staged_kind = "colmajor"
 
     def commit(self, ctx):
         """plan stream: the staged value becomes the Parameter's value"""
         kind = getattr(self, "_staged_kind", None)
+        slot = getattr(self, "_staged_slot", 0)
         if kind == "rowmajor":
             ctx.wait_staged()
-            _lib.call("pmt_transpose_f64", C.c_void_p(self._stage), self.cols, self.cols, self.rows, C.c_void_p(self.buf), self.lda, ctx.stream)
+            _lib.call("pmt_transpose_f64", C.c_void_p(self._stage_rm[slot]), self.cols, self.cols, self.rows, C.c_void_p(self.buf), self.lda, ctx.stream)
         elif kind == "colmajor":
-            ctx.commit_staged(self.buf, self._staging, 8 * self.lda * self.cols)
+            ctx.commit_staged(self.buf, self._staging_cm[slot], 8 * self.lda * self.cols)
         self._staged_kind = None
 
     def fetch(self, ctx):

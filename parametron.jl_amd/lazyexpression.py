@@ -204,17 +204,20 @@ def _stage_value(ctx, dv, val):
         host, nbytes = np.asarray(val.data, dtype=np.float64), 8 * dv.nnz
     else:
         raise ArgumentError("cannot stage an upload into %s" % type(dv).__name__)
-    if getattr(dv, "_staging", None) is None:
-        dv._staging = ctx.alloc(max(nbytes, 8))
-    dv._staged_bytes = nbytes
-    ctx.stage_upload(dv._staging, host)
+    slot = ctx._stage_slot                              # one staging buffer per slot (pmt_plan_stage_slot)
+    if not hasattr(dv, "_staging_slots"):
+        dv._staging_slots = {}
+    if slot not in dv._staging_slots:
+        dv._staging_slots[slot] = ctx.alloc(max(nbytes, 8))
+    dv._staged_bytes, dv._staged_slot = nbytes, slot
+    ctx.stage_upload(dv._staging_slots[slot], host)
 
 
 def _commit_staged_value(ctx, dv):
     if isinstance(dv, DMat):
         dv.commit(ctx)
     elif getattr(dv, "_staged_bytes", 0):
-        ctx.commit_staged(dv.buf, dv._staging, dv._staged_bytes)
+        ctx.commit_staged(dv.buf, dv._staging_slots[dv._staged_slot], dv._staged_bytes)
 
 
 def const_device_value(ctx, x):

@@ -190,6 +190,11 @@ class Model:
         ctx = self.device()
         if len(ctx._keep_staged) > 64:           # the caller never waits: do not let the references to old host values pile up
             ctx.staged_synchronize()
+        # alternate the staging slot: these values go into the buffers the update BEFORE the previous one used, so the copy does not wait
+        # for the previous update's commits, only for those of the one before it
+        ctx._pending_slot = ctx._next_stage_slot
+        ctx._next_stage_slot ^= 1
+        ctx.set_stage_slot(ctx._pending_slot)
         for x in self._order:
             if not isinstance(x, Parameter) or getattr(x, "device_resident", False) or isinstance(x, DerivedParameter) or x._dev is None:
                 continue
@@ -344,6 +349,8 @@ class Model:
         ctx = self.device()
         from .lazyexpression import device_value_of
         ctx._staging_dirty = False
+        if ctx._stage_slot != ctx._pending_slot:
+            ctx.set_stage_slot(ctx._pending_slot)   # wait / commit / consumed act on the slot the pending values were staged into
         for x in self._order:
             if isinstance(x, Parameter):
                 device_value_of(x, ctx)
