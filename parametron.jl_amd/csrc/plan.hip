@@ -45,6 +45,9 @@ struct pmt_plan {
     hipEvent_t consumed[2] = {nullptr, nullptr};   // recorded on the plan stream behind the slot's commits (its staging buffers may be overwritten after it)
     bool consumed_recorded[2] = {false, false};
     int slot = 0;
+    // pmt_plan_alloc zero-fills on the plan's stream; a staged upload into a fresh buffer must not overtake that fill on the copy stream
+    hipEvent_t alloc_done = nullptr;
+    bool alloc_pending = false;
 };
 
 namespace pmt {
@@ -237,6 +240,7 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
         if (plan->staged[i]) (void)hipEventDestroy(plan->staged[i]);
         if (plan->consumed[i]) (void)hipEventDestroy(plan->consumed[i]);
     }
+    if (plan->alloc_done) (void)hipEventDestroy(plan->alloc_done);
     if (plan->lane_fork) (void)hipEventDestroy(plan->lane_fork);
     if (plan->lane_join) (void)hipEventDestroy(plan->lane_join);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
@@ -260,6 +264,9 @@ extern "C" int pmt_plan_alloc(pmt_plan *plan, size_t bytes, void **out_device_pt
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     PMT_HIP_CHECK(hipMemsetAsync(p, 0, sz, plan->stream));
+    if (!plan->alloc_done) PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->alloc_done, hipEventDisableTiming));
+    PMT_HIP_CHECK(hipEventRecord(plan->alloc_done, plan->stream));
+    plan->alloc_pending = true;
     plan->allocations.push_back(p);
     plan->bytes += sz;
     *out_device_ptr = p;
@@ -353,6 +360,11 @@ static int ensure_copy_stream(pmt_plan *plan) {
 static int stage_prologue(pmt_plan *plan) {
     if (int rc = ensure_copy_stream(plan)) return rc;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
+    // a staging buffer allocated just now is still being zero-filled on the plan's stream: the copy must come after that
+    if (plan->alloc_pending) {
+        PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->alloc_done, 0));
+        plan->alloc_pending = false;
+    }
     // the slot's staging buffers may still be being read by the commits of the update that used the slot last
     if (plan->consumed_recorded[plan->slot]) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed[plan->slot], 0));
     return PMT_OK;
