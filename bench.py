@@ -353,22 +353,33 @@ def config_c5(torch, P, _lib, steps):
 
 def host_api_c2(torch, P, steps):
     """Model.solve!() of config 2 through the host API, PCIe included where it occurs (never `value`):
-    device hand-off (nothing crosses PCIe) and the reference's boundary (252 MB of MOI terms fetched into page-locked host buffers)."""
+      handoff_device           CSC QP data left in HBM (nothing crosses PCIe)
+      handoff_host_csc         what a host OSQP's update takes (P.x 67.1 MB, A.x 16.8 MB, q, l, u = 84 MB) in page-locked host arrays,
+                               shipped WHILE the re-evaluation runs: recorded fetches + band-wise delivery of P out of the contraction
+      handoff_host_csc_serial  the same 84 MB fetched behind the re-evaluation
+      handoff_moi              the reference's boundary: 252 MB of MOI term arrays fetched into page-locked host buffers
+    Every solve! ends with the host holding the data (synchronised); Parameters are regenerated on the device before each one."""
     from parametron_jl_amd import workloads
     out = {}
-    for handoff in ("device", "moi"):
-        model = workloads.config2(handoff=handoff)
+    what = {"device": "CSC QP data left in HBM", "moi": "MOI term arrays fetched to the host (252 MB over PCIe)",
+            "host_csc": "CSC values of P and A, q, l, u (84 MB) delivered to page-locked host arrays while the contraction runs",
+            "host_csc_serial": "the same 84 MB fetched behind the re-evaluation"}
+    for name in ("device", "host_csc", "host_csc_serial", "moi"):
+        kw = {"handoff": "host_csc", "overlap_fetch": name == "host_csc"} if name.startswith("host_csc") else {"handoff": name}
+        model = workloads.config2(**kw)
         P.solve(model)
-        for _ in range(3):
+        for _ in range(5):
             P.solve(model)
-        k = max(3, min(steps, 10))
+        k = max(3, min(steps, 20))
         t0 = time.perf_counter()
         for _ in range(k):
             P.solve(model)
         dt = (time.perf_counter() - t0) / k
-        out["handoff_" + handoff] = {"ms_per_solve": dt * 1e3, "solves_per_s": 1.0 / dt,
-                                     "what": "Parameters regenerated on the device, " + ("CSC QP data left in HBM" if handoff == "device" else
-                                                                                        "MOI term arrays fetched to the host (252 MB over PCIe)")}
+        out["handoff_" + name] = {"ms_per_solve": dt * 1e3, "solves_per_s": 1.0 / dt, "what": "Parameters regenerated on the device, " + what[name]}
+        if name.startswith("host_csc"):
+            nb = model.device_qp.host.nbytes()
+            out["handoff_" + name]["bytes_to_host"] = nb
+            out["handoff_" + name]["pcie_floor_ms"] = nb / 54e9 * 1e3      # 54 GB/s: the page-locked D2H rate of this box (tools/deliver_probe.hip)
         model.close()
     return out
 

@@ -191,6 +191,21 @@ int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t co
                           double alpha, double *out_P_values, pmt_quadratic_term *out_quad,
                           pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
 
+/* The same node (values only, no term structs) with the values additionally DELIVERED TO THE HOST while the contraction runs — the
+ * reference's boundary is a host solver (MOI.set, src/moi_interop.jl:131-137; OSQP's update_P takes exactly this array).  host_P_values
+ * is page-locked host memory (pmt_host_alloc) of cols*(cols+1)/2 doubles.  The tiles are computed column band by column band; the kernel
+ * counts finished tiles per band group (`ngroups` groups of about equal bytes, 0 = default 8, at most 16) and a co-resident courier kernel
+ * on the calling stream's FETCH stream polls each count and stores that group's columns straight into the host array, so most of P has
+ * crossed PCIe before the last tile is done.  `stream` does not wait for the delivery: pmt_plan_fetch_synchronize (or
+ * pmt_fetch_synchronize for a plain stream) does — PMT_HIP_ERROR there if the courier timed out (no progress for 2 s); the next call on
+ * the same stream waits by itself until the previous delivery has read out_P_values. */
+int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
+                                  const int64_t *xvar, const double *b, int sign, const int64_t *varmap,
+                                  double alpha, double *out_P_values, double *host_P_values, int ngroups,
+                                  pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
+/* host: block until every copy on the fetch stream of `stream` (a HIP stream, not a recording handle) has landed */
+int pmt_fetch_synchronize(void *stream);
+
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
  * bilinearmul! src/functions.jl:840-858 (the Q' pairing quirk is reproduced).
  * The linear index k is that of the rows x cols matrix; ldq is the leading dimension of its device copy.  moi as above. */
@@ -415,6 +430,14 @@ int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const
 int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
                       size_t height);
 int pmt_plan_synchronize(pmt_plan *plan);
+/* Recorded fetch (while recording; lane-aware like every recorded call): at replay the D2H copy goes to the plan's FETCH stream, ordered
+ * behind everything recorded before it on its lane, and runs while the rest of the tape is still busy — results reach a HOST solver
+ * (MOI.set, src/moi_interop.jl:134,171) without waiting for the end of the re-evaluation.  host_dst should be page-locked.  The plan's
+ * stream does not wait for these copies; pmt_plan_fetch_synchronize blocks the host until all of them (and a delivery of
+ * pmt_quad_gram_csc_deliver_f64) have landed; the next pmt_plan_update waits on the device until they have read their buffers.
+ * A plan with recorded fetches cannot be instantiated as a hipGraph. */
+int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
+int pmt_plan_fetch_synchronize(pmt_plan *plan);
 
 /* Staged (overlapped) uploads of host-updated Parameter values — `Parameter(model, val=buf)` / `Parameter(f, val, model)`,
  * src/parameter.jl:57,88,101-102: the user (or f) rewrites a host buffer between solves and update!() reads it when the Parameter is

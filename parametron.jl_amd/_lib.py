@@ -61,6 +61,8 @@ SIGNATURES = {
     "pmt_quad_gram_workspace_bytes": (_sz, [_i64, _i64]),
     "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_csc_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pmt_quad_gram_csc_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
+    "pmt_fetch_synchronize": (_ci, [_vp]),
     "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_fill_uniform_matrix_f64": (_ci, [_vp, _i64, _i64, _i64, _u64, _f64, _vp]),
     "pmt_plan_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
@@ -118,6 +120,8 @@ SIGNATURES = {
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
+    "pmt_plan_record_fetch": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_fetch_synchronize": (_ci, [_vp]),
     "pmt_plan_stage_upload": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_stage_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "pmt_plan_wait_staged": (_ci, [_vp]),

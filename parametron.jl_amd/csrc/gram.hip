@@ -15,7 +15,7 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "common.h"
+#include "gram_common.h"
 
 namespace pmt {
 
@@ -23,11 +23,14 @@ int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
+int launch_courier(const double *src, double *dst_dev, unsigned long long *progress, unsigned *done, int *error, int ngroups,
+                   const unsigned long long *expect, const int64_t *off, hipStream_t s);
+int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
+void *host_device_pointer(void *host);
+struct SKDeliver;
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s);
-
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-typedef unsigned long long u64;
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, const SKDeliver *deliver,
+                   hipStream_t s);
 
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 
@@ -99,7 +102,21 @@ namespace pmt {
 // One non-blocking side stream + fork/join events PER CALLING STREAM (= per plan: a plan is one stream), created on first use on the
 // calling stream's device.  Two plans driven from two host threads therefore never share an event (different plans are
 // independent); calls on ONE stream must be serialised by the caller, as for any HIP stream.
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; };
+// `counters` (library-owned device memory, zeroed once here, put back to zero by the courier kernel): the progress counts of a host
+// delivery (MAXGROUPS x u64) and the courier's own completion count / error flag — calls on one stream are serialised, so one set per
+// calling stream is enough.
+// `fetch` is the calling stream's DEVICE-TO-HOST stream (created on first use, highest priority so that it has a hardware queue of its
+// own class): recorded fetches (pmt_plan_record_fetch) and the band-wise delivery of pmt_quad_gram_csc_deliver_f64 travel on it while
+// the kernels go on; `fetch_done` is recorded behind the last copy enqueued so far.
+struct SideStream {
+    hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1;
+    void *counters = nullptr;
+    hipStream_t fetch = nullptr; hipEvent_t fetch_done = nullptr; bool fetch_pending = false;
+};
+// layout of `counters`: [MAXGROUPS x u64 progress][u32 courier done][i32 courier error]
+constexpr size_t PROGRESS_OFFSET = 0;
+constexpr size_t DONE_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
+constexpr size_t COUNTER_BYTES = DONE_OFFSET + 2 * sizeof(unsigned);
 static std::mutex g_side_mu;
 static std::unordered_map<hipStream_t, SideStream> g_side;
 static SideStream *side_stream(hipStream_t s) {
@@ -126,7 +143,9 @@ static SideStream *side_stream(hipStream_t s) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     bool ok = hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
               hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess &&
+              hipMalloc(&ss.counters, COUNTER_BYTES) == hipSuccess &&
+              hipMemsetAsync(ss.counters, 0, COUNTER_BYTES, s) == hipSuccess;      // on the calling stream: ordered before its first kernel
     if (prev != dev) (void)hipSetDevice(prev);
     if (!ok) { (void)hipGetLastError(); g_side.erase(s); return nullptr; }
     ss.device = dev;
@@ -138,8 +157,20 @@ static SideStream *side_stream(hipStream_t s) {
 // a plan that goes away takes the side stream of its stream with it (pmt_plan_destroy): HIP multiplexes streams onto a handful of hardware
 // queues, and a leaked side stream can end up sharing the queue of a later plan's stream — its contraction then queues BEHIND its own side
 // kernels instead of running beside them (measured: config 3 1.27 -> 1.45 ms when run after another plan in the same process)
+// Plans that share one external stream share its side stream: it is reference-counted by plan (pmt_plan_create retains, pmt_plan_destroy
+// releases) and goes away with the LAST of them, not with the first.
+static std::unordered_map<hipStream_t, int> g_side_refs;
+void retain_side_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    ++g_side_refs[s];
+}
 void release_side_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lock(g_side_mu);
+    auto rc = g_side_refs.find(s);
+    if (rc != g_side_refs.end()) {
+        if (--rc->second > 0) return;
+        g_side_refs.erase(rc);
+    }
     auto it = g_side.find(s);
     if (it == g_side.end()) return;
     if (it->second.stream) {
@@ -148,7 +179,75 @@ void release_side_stream(hipStream_t s) {
     }
     if (it->second.fork) (void)hipEventDestroy(it->second.fork);
     if (it->second.join) (void)hipEventDestroy(it->second.join);
+    if (it->second.fetch) {
+        (void)hipStreamSynchronize(it->second.fetch);
+        (void)hipStreamDestroy(it->second.fetch);
+    }
+    if (it->second.fetch_done) (void)hipEventDestroy(it->second.fetch_done);
+    if (it->second.counters) (void)hipFree(it->second.counters);
     g_side.erase(it);
+}
+
+// ---- the calling stream's device-to-host stream -----------------------------------------------------------------------------------
+static int ensure_fetch_stream(SideStream *ss) {
+    if (ss->fetch) return PMT_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (prev != ss->device) PMT_HIP_CHECK(hipSetDevice(ss->device));
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    hipError_t e = hipStreamCreateWithPriority(&ss->fetch, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ss->fetch_done, hipEventDisableTiming);
+    if (prev != ss->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_HIP_ERROR, std::string("fetch stream: ") + hipGetErrorString(e)); }
+    return PMT_OK;
+}
+
+// D2H copy on the fetch stream of `s`, ordered behind everything enqueued on `after` (the plan's stream or its side stream) so far
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes) {
+    SideStream *ss = side_stream(s);
+    if (!ss) return fail(PMT_STATE_ERROR, "fetch_async: no auxiliary streams for this stream");
+    if (int rc = ensure_fetch_stream(ss)) return rc;
+    PMT_HIP_CHECK(hipEventRecord(order_event, after));
+    PMT_HIP_CHECK(hipStreamWaitEvent(ss->fetch, order_event, 0));
+    // a <= 16-VGPR copy kernel that is co-resident with the contraction (deliver.hip) when the destination is page-locked, 8-byte words
+    // and below 16 GiB; the runtime's copy otherwise
+    void *dst_dev = (bytes % 8 == 0 && bytes / 8 < (size_t)1 << 31) ? host_device_pointer(host_dst) : nullptr;
+    if (dst_dev) { if (int rc = launch_to_host(device_src, dst_dev, bytes, ss->fetch)) return rc; }
+    else PMT_HIP_CHECK(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ss->fetch));
+    PMT_HIP_CHECK(hipEventRecord(ss->fetch_done, ss->fetch));
+    ss->fetch_pending = true;
+    return PMT_OK;
+}
+
+// `s` waits until the copies enqueued on its fetch stream so far have read their device buffers (start of the next re-evaluation)
+int fetch_fence(hipStream_t s) {
+    std::unique_lock<std::mutex> lock(g_side_mu);
+    auto it = g_side.find(s);
+    if (it == g_side.end() || !it->second.fetch_pending) return PMT_OK;
+    SideStream *ss = &it->second;
+    lock.unlock();
+    PMT_HIP_CHECK(hipStreamWaitEvent(s, ss->fetch_done, 0));
+    ss->fetch_pending = false;
+    return PMT_OK;
+}
+
+// host: block until every copy enqueued on the fetch stream of `s` has landed
+int fetch_synchronize(hipStream_t s) {
+    std::unique_lock<std::mutex> lock(g_side_mu);
+    auto it = g_side.find(s);
+    if (it == g_side.end() || !it->second.fetch) return PMT_OK;
+    hipStream_t f = it->second.fetch;
+    void *counters = it->second.counters;
+    lock.unlock();
+    PMT_HIP_CHECK(hipStreamSynchronize(f));
+    int err = 0;
+    PMT_HIP_CHECK(hipMemcpy(&err, static_cast<char *>(counters) + DONE_OFFSET + sizeof(unsigned), sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        PMT_HIP_CHECK(hipMemset(counters, 0, COUNTER_BYTES));
+        return fail(PMT_HIP_ERROR, "host delivery: the courier saw no progress of the contraction for 2 s and gave up; the host arrays are incomplete");
+    }
+    return PMT_OK;
 }
 
 hipStream_t side_stream_of(hipStream_t s) {
@@ -166,23 +265,75 @@ extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
                                                                    blocked_dot_scratch_doubles());
 }
 
+// Host delivery of the CSC values (pmt_quad_gram_csc_deliver_f64): where the band groups end and what each of them ships.
+struct DeliverPlan {
+    double *host = nullptr;                 // page-locked destination, same layout as out_csc
+    double *host_dev = nullptr;             // ... and its device-visible address
+    int ngroups = 0;
+    short gend[MAXGROUPS];                  // band group i = tile columns [gend[i-1], gend[i])
+    unsigned long long expect[MAXGROUPS];   // accumulator units of the group's tiles = 32 x sum over its bands kb of (kb + 1)
+    int64_t off[MAXGROUPS + 1];             // CSC offsets (doubles) of the groups' first columns
+};
+
+// band groups of (nearly) equal bytes: group i ends at the first band whose columns bring the shipped fraction to (i + 1) / ngroups
+static DeliverPlan deliver_plan(int64_t cols, int ngroups, double *host) {
+    DeliverPlan d;
+    d.host = host;
+    const int nt = (int)cdiv(cols, GT);
+    const int64_t total = cols * (cols + 1) / 2;
+    ngroups = std::max(1, std::min(ngroups, std::min(nt, MAXGROUPS)));
+    int g = 0, b0 = 0;
+    d.off[0] = 0;
+    for (int kb = 0; kb < nt; ++kb) {
+        const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
+        const int64_t off = cend * (cend + 1) / 2;
+        const bool last_band = kb == nt - 1;
+        if (last_band || (off * ngroups >= total * (g + 1) && nt - 1 - kb >= ngroups - 1 - g)) {
+            d.gend[g] = (short)(kb + 1);
+            d.off[g + 1] = off;
+            unsigned long long tiles = 0;
+            for (int k = b0; k <= kb; ++k) tiles += (unsigned long long)(k + 1);
+            d.expect[g] = tiles * 32;           // Cfg<2>::NACC units per tile (gram_sk.hip: sk_signal_tile)
+            b0 = kb + 1;
+            ++g;
+            if (last_band) break;
+        }
+    }
+    d.ngroups = g;
+    return d;
+}
+
 // the whole node: contraction on the main stream, q = 2A'c and c'c on a side stream.  out_quad (term structs) and out_csc (solver
-// values, alpha-scaled) are independent optional outputs of the same contraction.
+// values, alpha-scaled) are independent optional outputs of the same contraction.  host_csc != null: out_csc is also DELIVERED to that
+// page-locked host buffer, band group by band group, on the stream's fetch stream while the contraction is still running.
 static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
                      int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
-                     double *out_const, void *workspace, void *stream) {
+                     double *out_const, void *workspace, double *host_csc, int ngroups, void *stream) {
     PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "quad_gram: negative dimension");
     PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "quad_gram: lda < rows");
     PMT_REQUIRE(sign >= -1 && sign <= 1, PMT_INVALID_ARGUMENT, "quad_gram: sign must be -1, 0 or +1");
     PMT_REQUIRE(out_const, PMT_INVALID_ARGUMENT, "quad_gram: null out_const");
     PMT_REQUIRE(sign == 0 || b || rows == 0, PMT_INVALID_ARGUMENT, "quad_gram: sign != 0 needs b");
     if (cols > 0) PMT_REQUIRE(xvar && (out_quad || out_csc) && out_lin && (A || rows == 0), PMT_INVALID_ARGUMENT, "quad_gram: null pointer");
-    PMT_REQUIRE(cols < (int64_t)GT * 46000, PMT_DIMENSION_MISMATCH, "quad_gram: too many columns");
+    PMT_REQUIRE(cols < (int64_t)GT * 32000, PMT_DIMENSION_MISMATCH, "quad_gram: too many columns");
     if (int rc = check_strictly_increasing(xvar, cols, stream)) return rc;
+    DeliverPlan dplan;
+    if (host_csc && cols > 0) {
+        dplan = deliver_plan(cols, ngroups > 0 ? ngroups : 8, host_csc);
+        dplan.host_dev = static_cast<double *>(host_device_pointer(host_csc));
+        PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
+    }
     return dispatch(stream, [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
         // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.
         SideStream *side = side_stream(s);
+        const bool deliver = dplan.host != nullptr;
+        if (deliver) {
+            PMT_REQUIRE(side && side->counters, PMT_STATE_ERROR, "quad_gram_csc_deliver: no auxiliary streams for this stream");
+            if (int rc = ensure_fetch_stream(side)) return rc;
+            // the previous delivery must have read out_csc before this contraction overwrites it
+            if (side->fetch_pending) { PMT_HIP_CHECK(hipStreamWaitEvent(s, side->fetch_done, 0)); side->fetch_pending = false; }
+        }
         hipStream_t s2 = s;
         if (side) {
             PMT_HIP_CHECK(hipEventRecord(side->fork, s));
@@ -207,7 +358,26 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
         }
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));
-        if (!rc && cols > 0) rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, s);
+        if (!rc && cols > 0) {
+            SKDeliver sd;
+            if (deliver) {
+                sd.progress = reinterpret_cast<unsigned long long *>(static_cast<char *>(side->counters) + PROGRESS_OFFSET);
+                sd.ngroups = dplan.ngroups;
+                for (int i = 0; i < MAXGROUPS; ++i) sd.gend[i] = i < dplan.ngroups ? dplan.gend[i] : 0;
+            }
+            // a delivery wants the column bands finished in ascending order: super-columns of two tile columns
+            rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver ? 2 : 0, deliver ? &sd : nullptr, s);
+            if (!rc && deliver) {
+                // fetch stream: ONE courier launch, queued now that the contraction's workgroups are on their way; it polls the band groups'
+                // counts and stores each finished group straight into the host array (deliver.hip)
+                char *cb = static_cast<char *>(side->counters);
+                rc = launch_courier(out_csc, dplan.host_dev, sd.progress, reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
+                                    reinterpret_cast<int *>(cb + DONE_OFFSET + sizeof(unsigned)), dplan.ngroups, dplan.expect, dplan.off, side->fetch);
+                if (rc) return rc;
+                PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
+                side->fetch_pending = true;
+            }
+        }
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
         return rc;
     });
@@ -217,12 +387,26 @@ extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int
                                  int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_linear_term *out_lin, double *out_const,
                                  void *workspace, void *stream) {
     if (cols > 0) PMT_REQUIRE(out_quad, PMT_INVALID_ARGUMENT, "quad_gram: null out_quad");
-    return gram_node(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, nullptr, 1.0, out_lin, out_const, workspace, stream);
+    return gram_node(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, nullptr, 1.0, out_lin, out_const, workspace, nullptr, 0, stream);
 }
 
 extern "C" int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
                                      const int64_t *varmap, double alpha, double *out_P_values, pmt_quadratic_term *out_quad,
                                      pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream) {
     if (cols > 0) PMT_REQUIRE(out_P_values, PMT_INVALID_ARGUMENT, "quad_gram_csc: null out_P_values");
-    return gram_node(A, lda, rows, cols, xvar, b, sign, 1, varmap, out_quad, out_P_values, alpha, out_lin, out_const, workspace, stream);
+    return gram_node(A, lda, rows, cols, xvar, b, sign, 1, varmap, out_quad, out_P_values, alpha, out_lin, out_const, workspace, nullptr, 0, stream);
+}
+
+extern "C" int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                                             const int64_t *varmap, double alpha, double *out_P_values, double *host_P_values, int ngroups,
+                                             pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream) {
+    if (cols > 0) PMT_REQUIRE(out_P_values && host_P_values, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: null P values pointer");
+    PMT_REQUIRE(ngroups >= 0 && ngroups <= MAXGROUPS, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: ngroups must be 0 (default) .. 16");
+    return gram_node(A, lda, rows, cols, xvar, b, sign, 1, varmap, nullptr, out_P_values, alpha, out_lin, out_const, workspace, host_P_values, ngroups,
+                     stream);
+}
+
+extern "C" int pmt_fetch_synchronize(void *stream) {
+    PMT_REQUIRE(!is_recording_handle(stream), PMT_INVALID_ARGUMENT, "fetch_synchronize: `stream` is a plan's recording handle; use pmt_plan_fetch_synchronize");
+    return fetch_synchronize(reinterpret_cast<hipStream_t>(stream));
 }

@@ -12,6 +12,7 @@ constexpr int ST = 128;            // output tile edge
 constexpr int SKC = 256;           // contraction depth per work unit
 constexpr int MAXG = 512;          // upper bound on persistent workgroups
 constexpr int SLOT = ST * ST;      // doubles per partial-tile slot
+constexpr int MAXGROUPS = 16;     // band groups of a host delivery
 
 struct SKArgs {
     const double *A; int64_t lda, rows, cols;
@@ -24,7 +25,19 @@ struct SKArgs {
     int64_t U;        // number of (tile, chunk) units of phase B = (T - tfull*G) * nchunk
     int vec_in;
     double *ws;
+    // Tile order: 0 = super-rows of 4 tile rows (sk_seq_unrank); w > 0 = super-columns of w tile columns (sk_colseq_unrank): the column
+    // bands of the output complete in ascending order, which is what a solver hand-off in CSC order wants to ship first.
+    int order_w;
+    // Host delivery (pmt_quad_gram_csc_deliver_f64): progress[i] counts the finished work of the tiles whose column band lies in band group i
+    // (bands [gend[i-1], gend[i])) in units of accumulators per thread — a whole tile NACC, a fix-up workgroup its share; the courier
+    // kernel (deliver.hip) polls the count and ships the group's columns.
+    unsigned long long *progress;
+    int ngroups;
+    short gend[MAXGROUPS];
 };
+
+// host delivery of the CSC values: the kernel counts finished tiles per band group (bands [gend[i-1], gend[i])) in progress[i]
+struct SKDeliver { unsigned long long *progress; int ngroups; short gend[MAXGROUPS]; };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
 template <int TN>
@@ -76,6 +89,36 @@ __device__ __forceinline__ void sk_seq_unrank(int idx, int nt, int &jb, int &kb)
     jb = kb = nt - 1;
 }
 
+// Column-band-major enumeration: super-columns of w tile columns, each traversed row by row (jb-major), so 32 consecutive tiles form a
+// (32/w) x w block and every column band kb is complete once the sequence has passed its super-column.
+__device__ __forceinline__ void sk_colseq_unrank(int idx, int nt, int w, int &jb, int &kb) {
+    int base = 0;
+    for (int c0 = 0; c0 < nt; c0 += w) {
+        const int h = min(w, nt - c0);                  // tile columns in this super-column
+        const int rect = c0 * h;                        // rows 0 .. c0-1 hold h tiles each; rows c0 .. c0+h-1 hold h, h-1, .., 1
+        const int count = rect + h * (h + 1) / 2;
+        if (idx < base + count) {
+            int p = idx - base;
+            if (p < rect) {
+                jb = p / h; kb = c0 + p % h;
+            } else {
+                p -= rect;
+                int r = 0;
+                while (p >= h - r) { p -= h - r; ++r; }
+                jb = c0 + r; kb = c0 + r + p;
+            }
+            return;
+        }
+        base += count;
+    }
+    jb = kb = nt - 1;
+}
+
+__device__ __forceinline__ void sk_tile_unrank(const SKArgs &g, int idx, int &jb, int &kb) {
+    if (g.order_w > 0) sk_colseq_unrank(idx, g.ntiles, g.order_w, jb, kb);
+    else sk_seq_unrank(idx, g.ntiles, jb, kb);
+}
+
 // sequence index of the t-th whole tile of workgroup bid (phase A)
 __device__ __forceinline__ int sk_phase_a_index(const SKArgs &g, int bid, int t) {
     if ((g.G & 7) == 0) return (t * 8 + (bid & 7)) * (g.G >> 3) + (bid >> 3);
@@ -96,13 +139,16 @@ __device__ __forceinline__ void sk_acc_pos(int tid, int r, int &row, int &col) {
 }
 
 // 2*acc -> QuadraticTerm at the canonical upper-triangular position
-__device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, int row, int col, double v) {
+__device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, int row, int col, double v, bool system_scope = false) {
     const int64_t n = g.cols;
     const int64_t j = (int64_t)jb * ST + row, k = (int64_t)kb * ST + col;
     if (k >= n || j >= n || j > k) return;
     double c = v;
     if (g.moi || j != k) c = 2 * c;          // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
-    if (g.out_csc) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
+    if (g.out_csc) {
+        if (system_scope) __hip_atomic_store(&g.out_csc[k * (k + 1) / 2 + j], g.alpha * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through (host delivery)
+        else g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
+    }
     if (!g.out_quad) return;
     const int64_t jv = g.xvar[j], kv = g.xvar[k];
     const int64_t pos = j * n - (j * (j - 1)) / 2 + (k - j);

@@ -24,12 +24,16 @@
 // acc[tm][tn][s] of lane l = C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
 #include "gram_common.h"
 
-// Codegen knobs (tools/tune_gram.sh).  The compiler's schedule of the stage loop — how many of a stage's 128 MFMAs it sinks below the
-// barrier, where it puts the operand reads — moves by +-5 % with source changes that do not touch the loop (even wrapping phase B
-// in a lambda), so the knob combination AND this exact source shape are the ones that measured best:
-//   PMT_SK_ORDER 1   MFMA issue order (tn, r, tm): consecutive MFMAs share the B operand   (0: (tn, tm, r))
-//   PMT_SK_LOADKS 1  the next stage's global loads are issued after the first k-step
-// gram_sk_kernel at n = r = 4096: 1.177 ms (58.4 TFLOP/s); the sweep is in profiles/r01d_side_stream.txt.
+// Codegen knobs.  The compiler's schedule of the stage loop moves by +-10 % with source changes that do not touch the loop.  Rounds 1-2
+// shipped the luckiest draw of a sweep (246 VGPRs, 1.177 ms at n = r = 4096) — an allocation that only came out that way while a second,
+// unrelated instantiation shared the translation unit (alone: 256 + 7 spilled).  Round 3 takes the lottery out of it in two steps
+// (profiles/r03_gram_codegen.txt): (1) the epilogue derives its lane-dependent offsets from a FRESH copy of threadIdx.x (sk_fresh_tid),
+// so nothing of it is live across the stage loop: the kernel's natural register need drops from ~263 to 183-231; (2) the register
+// budget is stated in the source (amdgpu_num_vgpr) and the scheduler works towards it.  Measured over budget x LOADKS x ORDER:
+//   budget 248/232: 1.38 ms;  budget 216 and below (183-187 VGPRs allocated): 1.185-1.20 ms;  spills: none in any of them
+//   PMT_SK_ORDER 0   MFMA issue order (tn, tm, r)   (1: (tn, r, tm), consecutive MFMAs share the B operand: 1.198 ms)
+//   PMT_SK_LOADKS 1  the next stage's global loads are issued after the first k-step   (0: 1.26, 2: 1.23, 3: 1.26 ms)
+// gram_sk_kernel at n = r = 4096: 1.186 ms with 183 VGPRs — two waves per SIMD leave 146 of its 512 registers to co-resident kernels.
 #ifndef PMT_GRAM_SK_STAGGER
 #define PMT_GRAM_SK_STAGGER 0
 #endif
@@ -37,7 +41,7 @@
 #define PMT_SK_LOADKS 1
 #endif
 #ifndef PMT_SK_ORDER
-#define PMT_SK_ORDER 1
+#define PMT_SK_ORDER 0
 #endif
 #ifndef PMT_SK_WPS
 #define PMT_SK_WPS 2          // __launch_bounds__ waves-per-SIMD hint of the shipped instantiation
@@ -53,9 +57,32 @@ namespace pmt {
 constexpr int EPITCH = 129;
 constexpr int EPI_DOUBLES = 64 * EPITCH + 192;
 
-template <int TN>
-__device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int tid) {
+// threadIdx.x through an opaque move: everything derived from the returned value is computed AFTER this point.  The epilogue needs a dozen
+// lane-dependent offsets; derived from the kernel's one `tid` they are hoisted above the stage loop and held (or spilled) across it.
+__device__ __forceinline__ int sk_fresh_tid() {
+    int t;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"((int)threadIdx.x));
+    return t;
+}
+
+// Host delivery: the tile's values are complete in memory before the count of its band group goes up — the delivery instantiation writes
+// them with system-scope write-through stores (sk_epilogue<.., SIGNAL>), so waiting for their acknowledgement is enough and this XCD's L2
+// is not flushed (a release fence at system scope writes back the WHOLE L2); the courier kernel polls the count (deliver.hip).
+// `units`: a whole tile counts NACC units, a fix-up workgroup the accumulators it handled.
+__device__ __forceinline__ void sk_signal_tile(const SKArgs &g, int kb, int tid, unsigned long long units) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        int grp = 0;
+        while (grp + 1 < g.ngroups && kb >= g.gend[grp]) ++grp;
+        __hip_atomic_fetch_add(&g.progress[grp], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int TN, bool SIGNAL = false>
+__device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int) {
     using C = Cfg<TN>;
+    const int tid = sk_fresh_tid();
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     const int64_t n = g.cols;
     const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
@@ -94,7 +121,11 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
             for (int col = wave; col < ST; col += C::NW) {
                 const int64_t k = k0 + col;
                 if (k >= n) break;
-                if (j <= k) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * tile[lane * EPITCH + col];
+                if (j <= k) {
+                    const double v = g.alpha * tile[lane * EPITCH + col];
+                    if (SIGNAL) __hip_atomic_store(&g.out_csc[k * (k + 1) / 2 + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through
+                    else g.out_csc[k * (k + 1) / 2 + j] = v;
+                }
             }
         }
         for (int row = wave; g.out_quad && row < 64; row += C::NW) {
@@ -382,8 +413,12 @@ int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, 
 }
 
 // ABL: ablation switch for profiling only; results are wrong for ABL != 0; selected with PMT_GRAM_SK_ABLATE.
-template <int TN, int BK, int WPS, int ABL>
-__global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
+// SIGNAL: the host-delivery instantiation (counts finished tiles per band group, sk_signal_tile); everything else is identical.
+// amdgpu_num_vgpr(108): on gfx90a+ the attribute counts in pairs of the unified file, i.e. a budget of 216 registers.  The budget is part
+// of the source (and checked again by tools/kernel_resources.py at build time), not a by-product of which other instantiations share the
+// translation unit; the scheduler settles at 183-187 registers under it (see the knobs at the top of this file).
+template <int TN, int BK, int WPS, int ABL, bool SIGNAL>
+__global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(108))) void gram_sk_kernel(SKArgs g) {
     using C = Cfg<TN>;
     constexpr int GP = BK + 1;
     __shared__ double lds[2][2][ST * GP];
@@ -403,7 +438,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
             const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
             const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
             int jb, kb;
-            sk_seq_unrank(tile, g.ntiles, jb, kb);
+            sk_tile_unrank(g, tile, jb, kb);
             const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
             const bool diag = (jb == kb);
             const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
@@ -413,7 +448,8 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
 
             if (c0 == 0 && c1 == g.nchunk) {
                 static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
-                sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+                sk_epilogue<TN, SIGNAL>(g, jb, kb, acc, &lds[0][0][0], tid);
+                if (SIGNAL) sk_signal_tile(g, kb, tid, C::NACC);
             } else {
                 // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
                 const int slot = 2 * bid + (u == u0 ? 0 : 1);
@@ -429,10 +465,11 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
-        sk_seq_unrank(sk_phase_a_index(g, bid, t), g.ntiles, jb, kb);
+        sk_tile_unrank(g, sk_phase_a_index(g, bid, t), jb, kb);
         double acc[C::NACC];
         sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
-        sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+        sk_epilogue<TN, SIGNAL>(g, jb, kb, acc, &lds[0][0][0], tid);
+        if (SIGNAL) sk_signal_tile(g, kb, tid, C::NACC);
     }
 
     if (!b_first) phase_b();
@@ -443,6 +480,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) void gram_sk_kernel(SKArgs g) {
 // over up to 256 partials) so that the sum is spread over NACC instead of NACC/4 workgroups per tile
 template <int TN, int APB>
 __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
+    const bool signal = g.progress != nullptr;                                  // host delivery: system-scope stores + a count per workgroup
     using C = Cfg<TN>;
     const int rtile = blockIdx.x;                                              // index among the remainder (split) tiles
     const int tile = g.tfull * g.G + rtile;
@@ -456,7 +494,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         return b;
     };
     const int blo = owner(ub), bhi = owner(ue);
-    if (blo == bhi) return;                                                   // one workgroup did the whole tile
+    if (blo == bhi) return;                                                   // one workgroup did the whole tile (and counted it)
     // blockIdx.y selects APB of the NACC accumulators of every thread, so a tile split many ways is summed by NACC/APB workgroups
     const int r0 = (int)blockIdx.y * APB;
     double acc[APB];
@@ -491,13 +529,14 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         for (int r = 0; r < APB; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
-    sk_seq_unrank(tile, g.ntiles, jb, kb);
+    sk_tile_unrank(g, tile, jb, kb);
 #pragma unroll
     for (int r = 0; r < APB; ++r) {
         int row, col;
         sk_acc_pos<TN>(tid, r0 + r, row, col);
-        sk_store_term(g, jb, kb, row, col, acc[r]);
+        sk_store_term(g, jb, kb, row, col, acc[r], signal);
     }
+    if (signal) sk_signal_tile(g, kb, tid, APB);
 }
 
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
@@ -515,19 +554,25 @@ static int env_int(const char *name, int dflt) {
 #endif
 
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, hipStream_t s) {
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, const SKDeliver *deliver,
+                   hipStream_t s) {
     SKArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
     g.ntiles = (int)cdiv(cols, ST);
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
     const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;
-    // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16;
-    //          2 = wg512 with BK 32
+    // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16
 #ifdef PMT_TUNING
+#ifdef PMT_TUNING_ABLATE
     static const int variant = env_int("PMT_GRAM_SK_VARIANT", 1);   // measured equal within noise (profiles/r01b_gram_variants.txt)
     static const int abl = env_int("PMT_GRAM_SK_ABLATE", 0);
+#else
+    constexpr int variant = 1;
+#endif
     static const int gdef = env_int("PMT_GRAM_SK_BLOCKS", 0);
+    static const int order_env = env_int("PMT_GRAM_SK_ORDER_W", -1);
+    if (order_env >= 0) order_w = order_env;
 #else
     constexpr int variant = 1, gdef = 0;
 #endif
@@ -538,34 +583,44 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.U = R * g.nchunk;
     g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
     g.ws = reinterpret_cast<double *>(workspace);
+    g.order_w = order_w;
+    g.progress = nullptr; g.ngroups = 0;
+    for (int i = 0; i < MAXGROUPS; ++i) g.gend[i] = 0;
+    if (deliver) {
+        PMT_REQUIRE(out_csc && deliver->progress && deliver->ngroups >= 1 && deliver->ngroups <= MAXGROUPS, PMT_INVALID_ARGUMENT,
+                    "quad_gram: bad delivery description");
+        g.progress = deliver->progress; g.ngroups = deliver->ngroups;
+        for (int i = 0; i < deliver->ngroups; ++i) g.gend[i] = deliver->gend[i];
+    }
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
-#ifdef PMT_TUNING
+#ifdef PMT_TUNING_ABLATE
+    // (ablation instantiations: profiling only, results are wrong for abl != 0; they are a separate switch because their mere presence in
+    // the translation unit moves the register allocation of the shipped kernel)
 #define SK_LAUNCH(TN, BK, WPS)                                                                                              \
     do {                                                                                                                    \
-        if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
-        else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
-        else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
-        else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
+        if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0, true>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
+        else if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1, false>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
+        else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2, false>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3, false>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
+        else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0, false>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
     } while (0)
     if (variant == 0) SK_LAUNCH(4, 16, 2);
-    else if (variant == 1) SK_LAUNCH(2, 16, PMT_SK_WPS);
-    else SK_LAUNCH(2, 32, 2);
-#else
-    // 32-row stages pay off for tall matrices (+1 % at r = 16384, -3 % at r = 4096: profiles/r01b_gram_variants.txt); same summation order,
-    // same bits.  (Keeping this second instantiation also keeps the register allocation of the first at 246 VGPRs: compiled alone it takes
-    // 256 + 7 spilled, and the two 16-VGPR kernels of the node's side stream are no longer co-resident with it — measured +9 % per step.)
-    if (rows >= 16384) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 32, 2, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0>), grid, dim3(Cfg<2>::NT), 0, s, g);
-#endif
-#ifdef PMT_TUNING
+    else SK_LAUNCH(2, 16, PMT_SK_WPS);
 #undef SK_LAUNCH
+#else
+    // Two instantiations that differ only in the per-tile progress count of a host delivery.  (The 32-row-stage instantiation used for
+    // tall matrices in rounds 1-2 spilled 49 VGPRs — +1 % at r = 16384 when it was introduced — and is gone: all shapes take 16-row stages.)
+    if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0, true>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0, false>), grid, dim3(Cfg<2>::NT), 0, s, g);
 #endif
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
     if (g.nchunk > 1 && R > 0) {
-        if (variant == 0) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<4, 4>), dim3((unsigned)R, Cfg<4>::NACC / 4), dim3(Cfg<4>::NT), 0, s, g);
-        else if (R * (Cfg<2>::NACC / 4) < 64) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        // The split tiles are summed by a second launch.  (Round 3 measured the alternative — the workgroup that arrives last at a split tile
+        // adds its partials inside the contraction: +55 us at n = r = 4096, one CU pulling 2 MB of partials, against 15 us of fix-up kernel
+        // plus ~25 us of in-stream gaps; profiles/r03_gram_fold_experiment.txt.)
+        if (R * (Cfg<2>::NACC / 4) < 64) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }

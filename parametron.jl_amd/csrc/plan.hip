@@ -48,6 +48,8 @@ struct pmt_plan {
     // pmt_plan_alloc zero-fills on the plan's stream; a staged upload into a fresh buffer must not overtake that fill on the copy stream
     hipEvent_t alloc_done = nullptr;
     bool alloc_pending = false;
+    // recorded fetches (pmt_plan_record_fetch): one ordering event per entry
+    std::vector<hipEvent_t> fetch_events;
 };
 
 namespace pmt {
@@ -204,6 +206,15 @@ extern "C" int pmt_device_count(void) {
     return n;
 }
 
+namespace pmt {
+hipStream_t side_stream_of(hipStream_t s);
+void retain_side_stream(hipStream_t s);
+void release_side_stream(hipStream_t s);
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes);
+int fetch_fence(hipStream_t s);
+int fetch_synchronize(hipStream_t s);
+}
+
 extern "C" int pmt_plan_create(int device, void *stream, pmt_plan **out) {
     PMT_REQUIRE(out, PMT_INVALID_ARGUMENT, "plan_create: null out");
     PMT_HIP_CHECK(hipSetDevice(device));
@@ -220,11 +231,11 @@ extern "C" int pmt_plan_create(int device, void *stream, pmt_plan **out) {
         std::lock_guard<std::mutex> lock(g_mu);
         g_recording[&p->recording_tag] = p;
     }
+    pmt::retain_side_stream(p->stream);
     *out = p;
     return PMT_OK;
 }
 
-namespace pmt { hipStream_t side_stream_of(hipStream_t s); void release_side_stream(hipStream_t s); }
 
 extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     if (!plan) return PMT_OK;
@@ -241,6 +252,7 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
         if (plan->consumed[i]) (void)hipEventDestroy(plan->consumed[i]);
     }
     if (plan->alloc_done) (void)hipEventDestroy(plan->alloc_done);
+    for (hipEvent_t e : plan->fetch_events) (void)hipEventDestroy(e);
     if (plan->lane_fork) (void)hipEventDestroy(plan->lane_fork);
     if (plan->lane_join) (void)hipEventDestroy(plan->lane_join);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
@@ -466,6 +478,9 @@ extern "C" int pmt_plan_end_record(pmt_plan *plan) {
 // outputs nothing else in the tape reads, so they fork at the top of the replay and join at its end; they are queued on the calling
 // stream's side stream, where a Gram node's small reductions go first — see pmt_plan_set_lane in the header.
 static int replay(pmt_plan *plan, hipStream_t s) {
+    // copies of the previous re-evaluation that are still on the fetch stream read buffers this one is about to overwrite
+    if (!plan->fetch_events.empty())
+        if (int rc = pmt::fetch_fence(s)) return rc;
     hipStream_t side = nullptr;
     bool any = false;
     for (char l : plan->lanes) any |= (l != 0);
@@ -493,6 +508,33 @@ static int replay(pmt_plan *plan, hipStream_t s) {
     return PMT_OK;
 }
 
+// ---- recorded fetches: results leave for the host while the tape is still running -----------------------------------------------------
+// The reference hands its MOI functions to a HOST solver (MOI.set, src/moi_interop.jl:134,171).  pmt_plan_fetch puts a D2H copy on the
+// plan's stream, i.e. behind the whole re-evaluation.  A RECORDED fetch is a tape entry: at replay an event is recorded on the stream the
+// entry's lane runs on (everything recorded before it on that lane has been enqueued), and the copy goes to the plan's FETCH stream behind
+// that event — the constraint block of config 2 (lane 1, finished early) crosses PCIe while the contraction is still busy.
+extern "C" int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_record_fetch: null plan");
+    PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan_record_fetch: the plan is not recording");
+    if (bytes == 0) return PMT_OK;
+    PMT_REQUIRE(host_dst && device_src, PMT_INVALID_ARGUMENT, "plan_record_fetch: null pointer");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    hipEvent_t ev = nullptr;
+    PMT_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    plan->fetch_events.push_back(ev);
+    hipStream_t main = plan->stream;
+    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes); });
+    plan->lanes.push_back(plan->record_lane);
+    return PMT_OK;
+}
+
+// host: block until every copy the plan's fetch stream has been given (recorded fetches, delivered CSC values) has landed
+extern "C" int pmt_plan_fetch_synchronize(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch_synchronize: null plan");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    return pmt::fetch_synchronize(plan->stream);
+}
+
 extern "C" int pmt_plan_set_lane(pmt_plan *plan, int lane) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_set_lane: null plan");
     PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan_set_lane: the plan is not recording");
@@ -516,6 +558,7 @@ extern "C" int pmt_plan_instantiate_graph(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_instantiate_graph: null plan");
     PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");
     if (plan->graph_exec) return PMT_OK;
+    PMT_REQUIRE(plan->fetch_events.empty(), PMT_STATE_ERROR, "plan_instantiate_graph: a tape with recorded fetches is replayed as launches (its copies leave the capture)");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
     int rc = replay(plan, plan->stream);

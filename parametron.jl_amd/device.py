@@ -82,6 +82,17 @@ class DeviceContext:
             return
         _lib.call("pmt_plan_fetch", self.plan, host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), int(nbytes))
 
+    def record_fetch(self, host, dptr, nbytes):
+        """while recording: a D2H copy as a tape entry of the current lane; at replay it leaves on the plan's FETCH stream as soon as the
+        entries recorded before it on that lane are done, while the rest of the tape is still busy (pmt_plan_record_fetch)"""
+        if nbytes == 0:
+            return
+        _lib.call("pmt_plan_record_fetch", self.plan, host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), int(nbytes))
+
+    def fetch_synchronize(self):
+        """host: every copy on the plan's fetch stream (recorded fetches, delivered CSC values) has landed"""
+        _lib.call("pmt_plan_fetch_synchronize", self.plan)
+
     def zero(self, dptr, nbytes):
         _lib.call("pmt_plan_zero", self.plan, C.c_void_p(dptr), int(nbytes))
 

@@ -53,8 +53,61 @@ class CSC:
         self.nnz = len(row_idx)
 
 
+class HostQP:
+    """What a HOST solver takes per solve (OSQP: update(Px=, Ax=, q=, l=, u=)) — numpy arrays over page-locked memory that the
+    re-evaluation refills in place; the structure arrays (Pi, Pp, Ai, Ap) are computed once.  `wait()` blocks until the arrays of the
+    current re-evaluation have landed (Model.update(synchronize=True) has already done so)."""
+
+    def __init__(self, qp):
+        self._qp = qp
+        ctx = qp.ctx
+        obj_dev = qp.model.objective.dev or {}
+        self.Px = obj_dev["P_host"] if "P_host" in obj_dev else ctx.pinned_array(max(qp.P.nnz, 1), np.float64)
+        self.P_delivered_by_contraction = "P_host" in obj_dev
+        self.Px = self.Px[:qp.P.nnz]
+        self.Pi, self.Pp = qp.P.row_idx, qp.P.col_ptr
+        self.q = ctx.pinned_array(max(qp.nvars, 1), np.float64)[:qp.nvars]
+        self.Ax = ctx.pinned_array(max(qp.A.nnz, 1), np.float64)[:qp.A.nnz]
+        self.Ai, self.Ap = qp.A.row_idx, qp.A.col_ptr
+        self.l = ctx.pinned_array(max(qp.nrows, 1), np.float64)[:qp.nrows]
+        self.u = ctx.pinned_array(max(qp.nrows, 1), np.float64)[:qp.nrows]
+        self._r = ctx.pinned_array(1, np.float64)
+        self._r[0] = qp._obj_const[1]
+
+    @property
+    def r(self):
+        return self._qp.sign * float(self._r[0])
+
+    def transfers(self):
+        """(host array, device pointer) pairs of one re-evaluation; P is absent when the contraction delivers it itself"""
+        qp = self._qp
+        t = [(self.Ax, qp.A.values_ptr), (self.q, qp.q_ptr), (self.l, qp.l_ptr), (self.u, qp.u_ptr)]
+        if qp._obj_const[0]:
+            t.append((self._r, qp._obj_const[0]))
+        if not self.P_delivered_by_contraction:
+            t.append((self.Px, qp.P.values_ptr))
+        return [(a, ptr) for a, ptr in t if a.nbytes]
+
+    def nbytes(self):
+        return self.Px.nbytes + self.q.nbytes + self.Ax.nbytes + self.l.nbytes + self.u.nbytes + 8
+
+    def wait(self):
+        self._qp.ctx.fetch_synchronize()
+        self._qp.ctx.synchronize()
+
+    def as_dict(self):
+        return {"P": (self.Px, self.Pi, self.Pp), "q": self.q, "r": self.r, "A": (self.Ax, self.Ai, self.Ap), "l": self.l, "u": self.u}
+
+
 class DeviceQP:
-    def __init__(self, model, infty=DEFAULT_INFTY, in_tape=False):
+    def __init__(self, model, infty=DEFAULT_INFTY, in_tape=False, host=None):
+        """in_tape: False (the hand-off kernels are launched behind the tape by refresh()), "side" (recorded as side-lane entries) or
+        "main" (recorded at the end of the tape).  host: None, "overlap" (the solver's arrays leave for page-locked host memory as
+        RECORDED fetches, each as soon as its producer is done) or "serial" (fetched behind the whole re-evaluation)."""
+        if in_tape is True:
+            in_tape = "side"
+        if host not in (None, "overlap", "serial"):
+            raise ArgumentError("DeviceQP: host must be None, 'overlap' or 'serial'")
         if not model.initialized:
             raise ErrorException("DeviceQP needs an initialized model (initialize!(model) / solve!(model) first)")
         self.model, self.infty = model, float(infty)
@@ -156,12 +209,21 @@ class DeviceQP:
                 ctx.upload(self.l_ptr + 8 * r0, lo); ctx.upload(self.u_ptr + 8 * r0, hi)
         ctx.synchronize()
         self._in_tape = False
-        if in_tape and self._launches:
+        self.host = HostQP(self) if host else None
+        self._host_mode = host
+        if host == "overlap" and not in_tape:
+            in_tape = "main"                        # the fetches are tape entries, so their producers have to be too
+        if in_tape and (self._launches or host == "overlap") and model._records:
+            # NOTE (side lane): the q gather reads the objective's affine part, which the Gram node writes on the calling stream's side
+            # stream; lane-1 entries are replayed on that same side stream (plan.hip `replay`, gram.hip `side_stream`), i.e. behind it.
             ctx.begin_record()
             try:
-                ctx.set_lane(1)
+                ctx.set_lane(1 if in_tape == "side" else 0)
                 for name, args in self._launches:
                     ctx.call(name, *args)
+                if host == "overlap":
+                    for arr, ptr in self.host.transfers():
+                        ctx.record_fetch(arr, ptr, arr.nbytes)
                 ctx.set_lane(0)
             finally:
                 ctx.end_record()
@@ -169,6 +231,8 @@ class DeviceQP:
             model._run_tape(fetch=False)
         else:
             self.refresh()
+        if self.host is not None:
+            self.host.wait()
 
     # ---- structure
     def _build_matrix(self, blocks, nrows, ncols, upper, alpha):
@@ -238,10 +302,12 @@ class DeviceQP:
     # ---- per re-evaluation
     def refresh(self):
         """Rebuild P.x, q, A.x, l, u from the model's current device MOI buffers (call after update!(model) / solve!(model))."""
-        if self._in_tape:
-            return                                  # part of the model's tape (side lane): rebuilt by update!(model) itself
-        for name, args in self._launches:
-            self.ctx.call(name, *args)
+        if not self._in_tape:                       # otherwise part of the model's tape: rebuilt by update!(model) itself
+            for name, args in self._launches:
+                self.ctx.call(name, *args)
+        if self.host is not None and not (self._in_tape and self._host_mode == "overlap"):
+            for arr, ptr in self.host.transfers():  # behind everything on the plan's stream (serial mode)
+                self.ctx.fetch(arr, ptr, arr.nbytes)
 
     # ---- host views (tests, host solvers)
     def _f64(self, ptr, n):

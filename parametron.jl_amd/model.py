@@ -86,6 +86,9 @@ class MockOptimizer(AbstractOptimizer):
     def set_device_qp(self, qp):
         self.device_qp = qp
 
+    def set_host_qp(self, qp):
+        self.host_qp = qp
+
     def set_objective_function(self, f):
         self.objective = f
         self.set_calls += 1
@@ -121,12 +124,18 @@ class _Backend:
 
 
 class Model:
-    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False, handoff="moi", side_lane=True):       # src/model.jl:10-22
+    def __init__(self, optimizer, quadratic_mode="auto", device=0, use_graph=False, handoff="moi", side_lane=True, overlap_fetch=True):       # src/model.jl:10-22
         if quadratic_mode not in ("auto", "literal", "canonical"):
             raise ArgumentError("quadratic_mode must be 'auto', 'literal' or 'canonical'")
-        if handoff not in ("moi", "device"):
-            raise ArgumentError("handoff must be 'moi' (host MOI functions, the reference's boundary) or 'device' (CSC data in HBM)")
+        if handoff not in ("moi", "device", "host_csc"):
+            raise ArgumentError("handoff must be 'moi' (host MOI functions, the reference's boundary), 'device' (CSC data in HBM) or "
+                                "'host_csc' (CSC values / q / bounds in page-locked host arrays: what a host OSQP's update takes)")
         self.handoff = handoff
+        # host_csc: the arrays leave for the host while the re-evaluation is still running (recorded fetches, band-wise delivery of P);
+        # False fetches them behind it (the A/B in bench.py)
+        self._overlap_fetch = bool(overlap_fetch) and handoff == "host_csc"
+        if handoff == "host_csc" and use_graph:
+            raise ArgumentError("handoff='host_csc' replays the tape as launches (its copies leave a graph capture); use_graph must be False")
         self.device_qp = None
         self.params = []
         self.optimizer = optimizer
@@ -255,7 +264,7 @@ class Model:
         backend = _Backend(self.nvars, self.sense, self.objective, list(self.constraints))
         records = [r for r in [self.objective] + list(self.constraints) if not r.isconstant]
         self._records = records
-        early = self.handoff == "device"
+        early = self.handoff in ("device", "host_csc")
         if early:
             # device hand-off: the optimizer never sees host MOI functions, so the index map is fixed BEFORE the plan is recorded and
             # the plan can be specialised on it (P's CSC values straight from the contraction when the variable order is preserved)
@@ -294,7 +303,7 @@ class Model:
                 # one small kernel on the lane does not pay (config 2: the co-resident pack slows the contraction by what it saves); several
                 # do (config 3: -0.15 ms), and so does the device hand-off, whose launches join them on the lane
                 eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane) else []
-                use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and self.handoff == "device")
+                use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and self.handoff != "moi")
                 for r, e in zip(records, emitters):
                     side = use_lane and any(r is x for x in eligible)
                     if side:
@@ -312,7 +321,7 @@ class Model:
             indexmap = self.optimizer.copy_to(backend)
             self._mapindices(indexmap)
         self.initialized = True
-        if self.handoff == "device":
+        if self.handoff != "moi":
             from .handoff import DeviceQP
             # When every constraint's MOI copy sits on the side lane and the objective is the Gram node (whose affine part is written on
             # the same side stream), the hand-off launches read side-stream outputs only: they are appended to the tape as side-lane
@@ -321,7 +330,8 @@ class Model:
             in_tape = bool(records) and (obj.isconstant or "P_values" in (obj.dev or {})) and \
                 all(c.isconstant or any(c is r for r in getattr(self, "_lane_records", [])) for c in self.constraints) and \
                 any(not c.isconstant for c in self.constraints)
-            self.device_qp = DeviceQP(self, in_tape=in_tape)
+            host = None if self.handoff == "device" else ("overlap" if self._overlap_fetch else "serial")
+            self.device_qp = DeviceQP(self, in_tape="side" if in_tape else False, host=host)
         if records and self._use_graph:
             self.device().instantiate_graph()
 
@@ -380,8 +390,13 @@ class Model:
                 self._run_tape(fetch=False)
             self.device_qp.refresh()
             if synchronize:                                            # synchronize=False: the caller overlaps the next stage_parameters()
-                self.device().synchronize()                            # with this re-evaluation and synchronises later
-            if hasattr(self.optimizer, "set_device_qp"):
+                if self.device_qp.host is not None:                    # with this re-evaluation and synchronises later
+                    self.device_qp.host.wait()                         # host_csc: the solver's arrays have landed
+                else:
+                    self.device().synchronize()
+            if self.device_qp.host is not None and hasattr(self.optimizer, "set_host_qp"):
+                self.optimizer.set_host_qp(self.device_qp.host)        # OSQP: update(Px=, Ax=, q=, l=, u=) from these arrays
+            elif hasattr(self.optimizer, "set_device_qp"):
                 self.optimizer.set_device_qp(self.device_qp)
             return
         if self._records:

@@ -6,6 +6,8 @@ Julia host can pass `pointer(moi_f.terms)` as the destination of pmt_plan_fetch.
 itself runs on the device (the pack kernels write MOI terms, through `varmap`, into device twins of these buffers);
 constant records are converted once on the host at setup, as in the reference (`isconstant`, :123,132,153,169).
 """
+import ctypes as C
+
 import numpy as np
 
 from ._lib import LT, QT, VAT, ArgumentError, DimensionMismatch
@@ -195,10 +197,20 @@ class _Record:
                 self.mode = "canonical-csc"
                 vec = gram.vec.buf if gram.vec is not None else None
                 alpha = -1.0 if self.model.sense == "Maximize" else 1.0
+                host_P = None
+                if getattr(self.model, "handoff", "") == "host_csc" and getattr(self.model, "_overlap_fetch", False):
+                    # host solver hand-off: the contraction finishes P column band by column band and every finished group of bands leaves
+                    # for this page-locked array while the rest is still being computed (pmt_quad_gram_csc_deliver_f64)
+                    host_P = ctx.pinned_array(max(n * (n + 1) // 2, 1), np.float64)
+                    self.dev["P_host"] = host_P
 
                 def emit(c):
-                    c.call("pmt_quad_gram_csc_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec),
-                           gram.sign if vec else 0, P(varmap_buf), alpha, P(dp), None, P(dl), P(dc), P(ws))
+                    if host_P is not None:
+                        c.call("pmt_quad_gram_csc_deliver_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec),
+                               gram.sign if vec else 0, P(varmap_buf), alpha, P(dp), host_P.ctypes.data_as(C.c_void_p), 0, P(dl), P(dc), P(ws))
+                    else:
+                        c.call("pmt_quad_gram_csc_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec),
+                               gram.sign if vec else 0, P(varmap_buf), alpha, P(dp), None, P(dl), P(dc), P(ws))
                 return emit
             if use_gram:
                 n = gram.mat.cols

@@ -1,0 +1,158 @@
+"""-m gpu: hand-off to a HOST solver (the reference's boundary: MOI.set into a host optimizer,
+src/moi_interop.jl:131-137,168-175, src/model.jl:151-159).  `handoff="host_csc"` delivers what a host OSQP's update takes — P's CSC
+values, q, A's CSC values, l, u — into page-locked host arrays while the re-evaluation is still running: recorded fetches
+(pmt_plan_record_fetch) for q / A / l / u, band-wise delivery out of the contraction (pmt_quad_gram_csc_deliver_f64) for P.
+What lands on the host must equal the device hand-off bit for bit, solve after solve, while every Parameter changes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import parametron_jl_amd as P  # noqa: E402
+from parametron_jl_amd import _lib  # noqa: E402
+from gpu_util import DEV, empty_f64, lib, ptr, stream  # noqa: E402
+
+
+def lsq_model(n, r, m, **kw):
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", **kw)
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model)
+    b = P.DeviceUniformParameter((r,), 2, model)
+    Cm = P.DeviceUniformParameter((m, n), 3, model)
+    d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    residual = A * x - b
+    P.objective(model, P.Minimize, P.dot(residual, residual))
+    P.constraint(model, Cm * x == d)
+    return model
+
+
+def assert_host_equals_device(model):
+    host = model.device_qp.host.as_dict()
+    dev = model.device_qp.fetch()
+    for k in ("P", "A"):
+        assert np.array_equal(host[k][0], dev[k][0]), k + " values differ between the host delivery and the device hand-off"
+        assert np.array_equal(host[k][1], dev[k][1]) and np.array_equal(host[k][2], dev[k][2])
+    for k in ("q", "l", "u"):
+        assert np.array_equal(host[k], dev[k]), k
+    assert host["r"] == dev["r"]
+    return host
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (300, 520, 7), (1024, 2048, 64)])
+def test_host_arrays_equal_device_handoff_solve_after_solve(n, r, m, overlap):
+    model = lsq_model(n, r, m, handoff="host_csc", overlap_fetch=overlap)
+    prev = None
+    for _ in range(4):
+        P.solve(model)                                    # every DeviceUniformParameter is regenerated with a new seed
+        host = assert_host_equals_device(model)
+        px = host["P"][0].copy()
+        assert prev is None or not np.array_equal(px, prev), "the Parameters did not change between solves"
+        prev = px
+    assert model.optimizer.host_qp is model.device_qp.host
+    assert model.device_qp.host.P_delivered_by_contraction == overlap
+    model.close()
+
+
+def test_host_csc_equals_moi_boundary():
+    """the same model through the reference's boundary (host MOI functions) and through host_csc: P = upper triangle of the MOI
+    quadratic terms, q, A and the bounds from the MOI constraint function"""
+    n, r, m = 160, 144, 6
+    ref = lsq_model(n, r, m, handoff="moi")
+    new = lsq_model(n, r, m, handoff="host_csc")
+    for _ in range(2):
+        P.solve(ref); P.solve(new)
+    f = ref.objective.f
+    host = new.device_qp.host.as_dict()
+    # canonical MOI terms are the row-major upper triangle (j <= k); CSC of the upper triangle stores column k's rows 0..k
+    Q = np.zeros((n, n))
+    Q[f.quadratic_terms["row"] - 1, f.quadratic_terms["col"] - 1] = f.quadratic_terms["coeff"]
+    px = np.concatenate([Q[:k + 1, k] for k in range(n)])
+    np.testing.assert_allclose(host["P"][0], px, rtol=1e-13, atol=0)      # (tile order differs: split tiles may add their partials in other groups)
+    q = np.zeros(n); q[f.affine_terms["var"] - 1] = f.affine_terms["coeff"]
+    assert np.array_equal(host["q"], q)
+    assert host["r"] == f.constant
+    cf = list(ref.constraints)[0].f
+    Ad = np.zeros((m, n)); Ad[cf.terms["out"] - 1, cf.terms["var"] - 1] = cf.terms["coeff"]
+    ax, ai, ap = host["A"]
+    import scipy.sparse as sp
+    assert np.array_equal(sp.csc_matrix((ax, ai, ap), shape=(m, n)).toarray(), Ad)
+    assert np.array_equal(host["l"], 0.0 - cf.constants) and np.array_equal(host["u"], 0.0 - cf.constants)
+    ref.close(); new.close()
+
+
+@pytest.mark.parametrize("rows,cols,ngroups", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 5)])
+def test_deliver_entry_point_matches_plain_csc(rows, cols, ngroups):
+    """C ABI: pmt_quad_gram_csc_deliver_f64 — the host array equals the device array of the same call bit for bit, both equal
+    pmt_quad_gram_csc_f64's values (1e-13: the tile order differs), and q / constant are identical"""
+    L = lib()
+    s = stream()
+    A = torch.empty(rows * cols, dtype=torch.float64, device=DEV)
+    b = torch.empty(rows, dtype=torch.float64, device=DEV)
+    _lib.call("pmt_fill_uniform_f64", ptr(A), rows * cols, 11, 1.0, s)
+    _lib.call("pmt_fill_uniform_f64", ptr(b), rows, 12, 1.0, s)
+    xvar = torch.arange(1, cols + 1, dtype=torch.int64, device=DEV)
+    nq = cols * (cols + 1) // 2
+    ws = torch.empty(max(1, L.pmt_quad_gram_workspace_bytes(rows, cols) // 8), dtype=torch.float64, device=DEV)
+    outs = []
+    for deliver in (False, True):
+        Pv, lin, const = empty_f64(nq), torch.empty(2 * cols, dtype=torch.int64, device=DEV), empty_f64(1)
+        if deliver:
+            hp = C.c_void_p()
+            _lib.call("pmt_host_alloc", 8 * nq, C.byref(hp))
+            host = np.frombuffer((C.c_char * (8 * nq)).from_address(hp.value), dtype=np.float64)
+            for rep in range(3):                          # repeated calls: the counters come back to zero by themselves
+                host[:] = np.nan
+                _lib.call("pmt_quad_gram_csc_deliver_f64", ptr(A), rows, rows, cols, ptr(xvar), ptr(b), -1, None, 1.0, ptr(Pv), hp, ngroups,
+                          ptr(lin), ptr(const), ptr(ws), s)
+                _lib.call("pmt_fetch_synchronize", s)
+                torch.cuda.synchronize()
+                assert np.array_equal(host, Pv.cpu().numpy()), "delivered values differ from the device buffer (repeat %d)" % rep
+            outs.append((host.copy(), lin.cpu().numpy(), const.cpu().numpy()))
+            _lib.call("pmt_host_free", hp)
+        else:
+            _lib.call("pmt_quad_gram_csc_f64", ptr(A), rows, rows, cols, ptr(xvar), ptr(b), -1, None, 1.0, ptr(Pv), None, ptr(lin), ptr(const), ptr(ws), s)
+            torch.cuda.synchronize()
+            outs.append((Pv.cpu().numpy(), lin.cpu().numpy(), const.cpu().numpy()))
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-13, atol=0)
+    assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2])
+    # spot check against a CPU sum
+    Ah = A.cpu().numpy().reshape(cols, rows).T
+    for (j, k) in [(0, 0), (0, cols - 1), (cols // 2, cols - 1), (cols - 1, cols - 1), (min(127, cols - 1), min(128, cols - 1))]:
+        if j <= k:
+            ref = 2.0 * float(np.dot(Ah[:, j], Ah[:, k]))
+            assert abs(outs[1][0][k * (k + 1) // 2 + j] - ref) <= 1e-12 * abs(ref)
+
+
+def test_recorded_fetch_runs_beside_the_tape_and_is_fenced():
+    """pmt_plan_record_fetch: the copy lands with the values of ITS re-evaluation although the next update is issued before the host waits"""
+    model = lsq_model(256, 256, 8, handoff="host_csc")
+    P.solve(model)
+    snap = model.device_qp.host.as_dict()["P"][0].copy()
+    model.update(synchronize=False)                       # second re-evaluation in flight ...
+    model.update(synchronize=False)                       # ... third one queued behind it: must wait until the second delivery has read P
+    model.device_qp.host.wait()
+    assert_host_equals_device(model)
+    assert not np.array_equal(model.device_qp.host.as_dict()["P"][0], snap)
+    model.close()
+
+
+def test_graph_replay_is_refused_for_recorded_fetches():
+    with pytest.raises(P.ArgumentError):
+        lsq_model(64, 64, 2, handoff="host_csc", use_graph=True)
+
+
+def test_full_size_config2_host_delivery():
+    """BASELINE config 2 (n = r = 4096, m = 512): 84 MB of solver arrays delivered per solve; host == device, bit for bit"""
+    from parametron_jl_amd import workloads
+    model = workloads.config2(handoff="host_csc")
+    for _ in range(3):
+        P.solve(model)
+        host = assert_host_equals_device(model)
+    n = 4096
+    assert host["P"][0].shape == (n * (n + 1) // 2,) and host["A"][0].shape == (512 * n,)
+    assert np.all(np.isfinite(host["P"][0])) and np.all(host["P"][0] > 0)
+    model.close()

@@ -11,7 +11,9 @@ import parametron_jl_amd as P  # noqa: E402
 def main():
     n, r, m = 4096, 4096, 512
     device = "--device-handoff" in sys.argv
-    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", use_graph="--graph" in sys.argv, handoff="device" if device else "moi")
+    host_csc = "--host-csc" in sys.argv                    # [--serial]: fetch behind the re-evaluation instead of beside it
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", use_graph="--graph" in sys.argv,
+                    handoff="host_csc" if host_csc else ("device" if device else "moi"), overlap_fetch="--serial" not in sys.argv)
     x = [P.Variable(model) for _ in range(n)]
     if "--host-params" in sys.argv:
         # host-updated Parameters in the reference's `val=` form (buffers overwritten externally between solves, src/parameter.jl:88):
@@ -54,6 +56,11 @@ def main():
     if "--staged" in sys.argv:
         model.wait_staged()
     dt = (time.perf_counter() - t0) / k
+    if host_csc:
+        h = model.device_qp.host
+        print("host_csc hand-off (%s): steady solve! %.3f ms = %.1f /s; %.1f MB to the host per solve (PCIe floor at 54 GB/s: %.2f ms); P delivered by the contraction: %s"
+              % ("serial" if "--serial" in sys.argv else "overlapped", dt * 1e3, 1 / dt, h.nbytes() / 1e6, h.nbytes() / 54e9 * 1e3, h.P_delivered_by_contraction))
+        return
     if device:
         qp = model.device_qp
         t0 = time.perf_counter(); got = qp.fetch(); t_fetch = time.perf_counter() - t0
