@@ -6,7 +6,10 @@
 // copy-engine / command-processor operation, both take wave slots and registers the persistent contraction (2 x 248 of a SIMD's 512 VGPRs)
 // does not leave, so "wait for a band group, then copy it" from the runtime slowed the contraction from 1.24 to 1.66 ms and starved the
 // node's side kernels.  A store from a kernel into page-locked host memory runs at the same 54 GB/s as the runtime's copy.  Hence two
-// kernels of at most 16 VGPRs and no LDS, i.e. CO-RESIDENT with the contraction (like the node's own small reductions):
+// kernels of at most 16 VGPRs and no LDS, i.e. CO-RESIDENT with the contraction (like the node's own small reductions).  They are the
+// FALLBACK: the preferred path hands the copies to the copy engine, gated by signals the kernels set (hsadma.hip) — a courier that shares
+// CUs with the contraction costs it dearly too (its stores to the host queue up in the CU's memory pipeline in front of the
+// contraction's panel loads: 1.19 -> 1.95 ms).  They run when the process's HSA runtime cannot be reached:
 //   courier_kernel   one launch per delivery: for every band group, ONE lane per workgroup polls the group's progress count (s_sleep
 //                    between polls), then the workgroup's slice of the group is copied straight into the host array;
 //   to_host_kernel   a plain device -> host copy (recorded fetches: q, A's values, bounds).
@@ -20,11 +23,10 @@ namespace pmt {
 struct CourierArgs {
     const double *src;                    // out_csc (device)
     double *dst;                          // device address of the page-locked host array
-    unsigned long long *progress;         // per band group: finished tiles (counted by gram_sk_kernel<..., SIGNAL>)
-    unsigned *done;                       // workgroups that have finished; the last one zeroes the counts for the next launch
+    long long *ready;                     // per band group: 1 = in the making, 0 = complete (set by gram_sk_kernel<..., SIGNAL> / the fix-up pass)
+    unsigned *done;                       // workgroups that have finished; the last one re-arms the flags for the next launch
     int *error;                           // set to 1 on timeout
     int ngroups;
-    unsigned long long expect[MAXGROUPS];
     long long off[MAXGROUPS + 1];
 };
 
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void courier_kernel(CourierArgs a) {
         if (tid == 0) {
             int abort = 0;
             const long long t0 = wall_clock64();
-            while (__hip_atomic_load(&a.progress[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.expect[g]) {
+            while (__hip_atomic_load(&a.ready[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
                 __builtin_amdgcn_s_sleep(32);
                 if (wall_clock64() - t0 > COURIER_TIMEOUT_TICKS) { abort = 1; break; }
             }
@@ -67,11 +69,11 @@ __global__ __launch_bounds__(256) void courier_kernel(CourierArgs a) {
         if (o < nb) *reinterpret_cast<double *>(db + o) = __hip_atomic_load(reinterpret_cast<const double *>(sb + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();                                        // s_abort is rewritten by the next group's poll
     }
-    // the last workgroup to finish puts the counts back to zero (all polls are over): ready for the next launch
+    // the last workgroup to finish re-arms the flags (all polls are over): ready for the next launch
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == gridDim.x - 1) {
-            for (int g = 0; g < a.ngroups; ++g) __hip_atomic_store(&a.progress[g], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int g = 0; g < a.ngroups; ++g) __hip_atomic_store(&a.ready[g], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -101,13 +103,11 @@ void *host_device_pointer(void *host) {
     return d;
 }
 
-int launch_courier(const double *src, double *dst_dev, unsigned long long *progress, unsigned *done, int *error, int ngroups,
-                   const unsigned long long *expect, const int64_t *off, hipStream_t s) {
+int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s) {
     for (int g = 0; g < ngroups; ++g)
         PMT_REQUIRE((off[g + 1] - off[g]) * 8 < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH, "host delivery: a band group of 2 GiB or more (use more groups)");
     CourierArgs a;
-    a.src = src; a.dst = dst_dev; a.progress = progress; a.done = done; a.error = error; a.ngroups = ngroups;
-    for (int g = 0; g < MAXGROUPS; ++g) a.expect[g] = g < ngroups ? expect[g] : 0;
+    a.src = src; a.dst = dst_dev; a.ready = ready; a.done = done; a.error = error; a.ngroups = ngroups;
     for (int g = 0; g <= MAXGROUPS; ++g) a.off[g] = g <= ngroups ? off[g] : 0;
     // 64 workgroups: page-locked stores saturate PCIe from 64 workgroups on (tools/deliver_probe.hip: 53.6 GB/s), and at most one courier
     // wave sits beside the contraction's two on a quarter of the SIMDs

@@ -15,6 +15,11 @@
 #include <mutex>
 #include <unordered_map>
 
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "dma.h"
 #include "gram_common.h"
 
 namespace pmt {
@@ -23,8 +28,7 @@ int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
-int launch_courier(const double *src, double *dst_dev, unsigned long long *progress, unsigned *done, int *error, int ngroups,
-                   const unsigned long long *expect, const int64_t *off, hipStream_t s);
+int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s);
 int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
 void *host_device_pointer(void *host);
 struct SKDeliver;
@@ -33,6 +37,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
                    hipStream_t s);
 
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
+constexpr int DELIVER_ORDER_W = 2; // a delivery computes the tiles in super-columns of two tile columns: the column bands finish in ascending order
 
 // out_lin[j] = (2 * sum_i c_i * A[i,j], vm[xvar[j]]),  c_i = 0.0 (+|-) b[i]; one wave per column (coalesced along i)
 __global__ __launch_bounds__(256) void gram_linear_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
@@ -109,16 +114,22 @@ namespace pmt {
 // own class): recorded fetches (pmt_plan_record_fetch) and the band-wise delivery of pmt_quad_gram_csc_deliver_f64 travel on it while
 // the kernels go on; `fetch_done` is recorded behind the last copy enqueued so far.
 struct SideStream {
-    hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1;
+    hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; int device = -1;
     void *counters = nullptr;
     hipStream_t fetch = nullptr; hipEvent_t fetch_done = nullptr; bool fetch_pending = false;
+    std::vector<std::pair<dma::Engine *, dma::Signal>> dma_pending;     // completion signals of copy-engine transfers in flight
+    std::vector<std::shared_ptr<void>> keepalive;                        // ... and the owners of their signals (an immediate call's go with the call)
+    bool in_replay = false;                                              // a plan's tape is being replayed: P's transfers are submitted at its end
+    std::vector<std::function<int()>> deferred;
 };
-// layout of `counters`: [MAXGROUPS x u64 progress][u32 courier done][i32 courier error]
+// layout of `counters`: [MAXGROUPS x u64 progress][MAXGROUPS x i64 courier flags (armed = 1)][u32 courier done][i32 courier error]
 constexpr size_t PROGRESS_OFFSET = 0;
-constexpr size_t DONE_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
+constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
+constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
 constexpr size_t COUNTER_BYTES = DONE_OFFSET + 2 * sizeof(unsigned);
 static std::mutex g_side_mu;
 static std::unordered_map<hipStream_t, SideStream> g_side;
+static int wait_dma_pending(SideStream *ss);
 static SideStream *side_stream(hipStream_t s) {
 #ifdef PMT_TUNING
     static const bool enabled = [] { const char *e = getenv("PMT_GRAM_SIDE_STREAM"); return !(e && e[0] == '0'); }();
@@ -144,8 +155,13 @@ static SideStream *side_stream(hipStream_t s) {
     bool ok = hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, prio_least) == hipSuccess &&
               hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&ss.counters, COUNTER_BYTES) == hipSuccess &&
               hipMemsetAsync(ss.counters, 0, COUNTER_BYTES, s) == hipSuccess;      // on the calling stream: ordered before its first kernel
+    if (ok) {
+        static const long long armed[MAXGROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+        ok = hipMemcpyAsync(static_cast<char *>(ss.counters) + FLAGS_OFFSET, armed, sizeof armed, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
     if (prev != dev) (void)hipSetDevice(prev);
     if (!ok) { (void)hipGetLastError(); g_side.erase(s); return nullptr; }
     ss.device = dev;
@@ -179,11 +195,13 @@ void release_side_stream(hipStream_t s) {
     }
     if (it->second.fork) (void)hipEventDestroy(it->second.fork);
     if (it->second.join) (void)hipEventDestroy(it->second.join);
+    if (it->second.join2) (void)hipEventDestroy(it->second.join2);
     if (it->second.fetch) {
         (void)hipStreamSynchronize(it->second.fetch);
         (void)hipStreamDestroy(it->second.fetch);
     }
     if (it->second.fetch_done) (void)hipEventDestroy(it->second.fetch_done);
+    (void)wait_dma_pending(&it->second);
     if (it->second.counters) (void)hipFree(it->second.counters);
     g_side.erase(it);
 }
@@ -203,10 +221,40 @@ static int ensure_fetch_stream(SideStream *ss) {
     return PMT_OK;
 }
 
-// D2H copy on the fetch stream of `s`, ordered behind everything enqueued on `after` (the plan's stream or its side stream) so far
-int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes) {
+FetchState::~FetchState() {
+    if (eng && created) { dma::signal_destroy(eng, dep); dma::signal_destroy(eng, done); }
+}
+
+// D2H copy ordered behind everything enqueued on `after` (the plan's stream or its side stream) so far.  Preferred: the copy engine, started
+// by a signal that a one-thread kernel on `after` sets (hsadma.hip) — nothing of it runs on a CU.  Otherwise a kernel copy / the runtime's
+// copy on the fetch stream of `s`.
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st) {
     SideStream *ss = side_stream(s);
     if (!ss) return fail(PMT_STATE_ERROR, "fetch_async: no auxiliary streams for this stream");
+    // A fetch behind the plan's OWN stream inside a replay (its producer finishes with the objective's kernels, e.g. the constant, whose
+    // serial chain is itself queued at the end of the replay) is issued at the end of the replay, behind that chain's join and behind the
+    // band groups of a delivery (the copy engine's queue is first in, first out).
+    if (ss->in_replay && after == s) {
+        ss->deferred.push_back([=]() -> int { return fetch_async(s, after, order_event, host_dst, device_src, bytes, st); });
+        return PMT_OK;
+    }
+    if (st && !st->created && !st->tried) {
+        st->tried = true;
+        st->eng = dma::get(ss->device);
+        if (st->eng) {
+            if (dma::signal_create(st->eng, 1, &st->dep) == PMT_OK && dma::signal_create(st->eng, 0, &st->done) == PMT_OK) st->created = true;
+            else st->eng = nullptr;
+        }
+    }
+    if (st && st->created) {
+        if (st->pending) { if (int rc = dma::wait(st->eng, st->done, 10.0)) return rc; st->pending = false; }
+        dma::signal_set(st->eng, st->dep, 1);
+        dma::signal_set(st->eng, st->done, 1);
+        if (int rc = dma::launch_signal_store(st->dep, after)) return rc;
+        st->pending = true;
+        ss->dma_pending.emplace_back(st->eng, st->done);
+        return dma::copy_to_host(st->eng, host_dst, device_src, bytes, &st->dep, st->done);
+    }
     if (int rc = ensure_fetch_stream(ss)) return rc;
     PMT_HIP_CHECK(hipEventRecord(order_event, after));
     PMT_HIP_CHECK(hipStreamWaitEvent(ss->fetch, order_event, 0));
@@ -220,26 +268,86 @@ int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *
     return PMT_OK;
 }
 
+#ifdef PMT_TUNING
+static double g_replay_t0 = 0;
+static double host_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+// debugging aid (PMT_DMA_DEBUG=2): poll every pending completion signal and the calling stream, print when each changes
+static void trace_dma_pending(SideStream *ss, hipStream_t s) {
+    std::vector<long> last(ss->dma_pending.size(), -100);
+    bool stream_done = false;
+    const double t0 = host_us();
+    for (;;) {
+        bool all = true;
+        for (size_t i = 0; i < ss->dma_pending.size(); ++i) {
+            const long v = (long)*ss->dma_pending[i].second.value;
+            if (v != last[i]) { fprintf(stderr, "[trace +%.0f us] transfer set %zu: %ld left\n", host_us() - g_replay_t0, i, v); last[i] = v; }
+            if (v > 0) all = false;
+        }
+        if (!stream_done && hipStreamQuery(s) == hipSuccess) { stream_done = true; fprintf(stderr, "[trace +%.0f us] the plan's stream is idle\n", host_us() - g_replay_t0); }
+        if ((all && stream_done) || host_us() - t0 > 1e6) break;
+    }
+}
+#endif
+
+static int wait_dma_pending(SideStream *ss) {
+    int rc = PMT_OK;
+    for (auto &p : ss->dma_pending) { const int r = dma::wait(p.first, p.second, 10.0); if (r && !rc) rc = r; }
+    ss->dma_pending.clear();
+    ss->keepalive.clear();
+    return rc;
+}
+
 // `s` waits until the copies enqueued on its fetch stream so far have read their device buffers (start of the next re-evaluation)
 int fetch_fence(hipStream_t s) {
     std::unique_lock<std::mutex> lock(g_side_mu);
     auto it = g_side.find(s);
-    if (it == g_side.end() || !it->second.fetch_pending) return PMT_OK;
+    if (it == g_side.end()) return PMT_OK;
     SideStream *ss = &it->second;
     lock.unlock();
+    // copy-engine transfers are not stream work: the HOST waits for them (a no-op when the caller has synchronised, as solve! does)
+    if (int rc = wait_dma_pending(ss)) return rc;
+    if (!ss->fetch_pending) return PMT_OK;
     PMT_HIP_CHECK(hipStreamWaitEvent(s, ss->fetch_done, 0));
     ss->fetch_pending = false;
     return PMT_OK;
+}
+
+// a plan's replay brackets its tape with these: transfers that should queue up behind the tape's own are submitted by replay_end
+void replay_begin(hipStream_t s) {
+#ifdef PMT_TUNING
+    g_replay_t0 = host_us();
+#endif
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    auto it = g_side.find(s);
+    if (it != g_side.end()) it->second.in_replay = true;
+}
+int replay_end(hipStream_t s) {
+    std::unique_lock<std::mutex> lock(g_side_mu);
+    auto it = g_side.find(s);
+    if (it == g_side.end()) return PMT_OK;
+    SideStream *ss = &it->second;
+    lock.unlock();
+    ss->in_replay = false;
+    int rc = PMT_OK;
+    for (auto &f : ss->deferred) { const int r = f(); if (r && !rc) rc = r; }
+    ss->deferred.clear();
+    return rc;
 }
 
 // host: block until every copy enqueued on the fetch stream of `s` has landed
 int fetch_synchronize(hipStream_t s) {
     std::unique_lock<std::mutex> lock(g_side_mu);
     auto it = g_side.find(s);
-    if (it == g_side.end() || !it->second.fetch) return PMT_OK;
-    hipStream_t f = it->second.fetch;
-    void *counters = it->second.counters;
+    if (it == g_side.end()) return PMT_OK;
+    SideStream *ss = &it->second;
+    hipStream_t f = ss->fetch;
+    void *counters = ss->counters;
     lock.unlock();
+#ifdef PMT_TUNING
+    { const char *e = getenv("PMT_DMA_DEBUG"); if (e && e[0] == '2') trace_dma_pending(ss, s); }
+#endif
+    if (int rc = wait_dma_pending(ss)) return rc;
+    if (!f) return PMT_OK;
     PMT_HIP_CHECK(hipStreamSynchronize(f));
     int err = 0;
     PMT_HIP_CHECK(hipMemcpy(&err, static_cast<char *>(counters) + DONE_OFFSET + sizeof(unsigned), sizeof(int), hipMemcpyDeviceToHost));
@@ -265,6 +373,20 @@ extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
                                                                    blocked_dot_scratch_doubles());
 }
 
+// the signals of one recorded delivery: a dependency signal per band group (the contraction stores 0 into its value when the group is in
+// memory) and one completion signal that counts the groups' transfers down
+struct DeliverSignals {
+    dma::Engine *eng = nullptr;
+    dma::Signal dep[MAXGROUPS], done;
+    int n = 0;
+    bool tried = false, pending = false;
+    ~DeliverSignals() {
+        if (!eng) return;
+        for (int i = 0; i < n; ++i) dma::signal_destroy(eng, dep[i]);
+        dma::signal_destroy(eng, done);
+    }
+};
+
 // Host delivery of the CSC values (pmt_quad_gram_csc_deliver_f64): where the band groups end and what each of them ships.
 struct DeliverPlan {
     double *host = nullptr;                 // page-locked destination, same layout as out_csc
@@ -275,28 +397,65 @@ struct DeliverPlan {
     int64_t off[MAXGROUPS + 1];             // CSC offsets (doubles) of the groups' first columns
 };
 
-// band groups of (nearly) equal bytes: group i ends at the first band whose columns bring the shipped fraction to (i + 1) / ngroups
-static DeliverPlan deliver_plan(int64_t cols, int ngroups, double *host) {
+// Band groups: a column band is complete when the LAST tile of its super-column has been written, and with the persistent grid all tiles of
+// one "round" (G consecutive tiles of the sequence) finish together.  Group boundaries therefore sit on the boundaries between rounds —
+// a group that straddled one would wait for the later round with all of its bytes — and each round's bands are cut into groups of about
+// equal bytes, so that the copy engine has something to ship as soon as a round ends and keeps shipping while the next one computes.
+static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int ngroups, int order_w, double *host) {
     DeliverPlan d;
     d.host = host;
     const int nt = (int)cdiv(cols, GT);
-    const int64_t total = cols * (cols + 1) / 2;
+    const int64_t T = (int64_t)nt * (nt + 1) / 2;
+    const int64_t nchunk = std::max<int64_t>(1, cdiv(rows, 256));
+    const int64_t G = std::min<int64_t>(T * nchunk, 256);                  // as launch_gram_sk (gram_sk.hip)
+    const int64_t tfull = T / G;
     ngroups = std::max(1, std::min(ngroups, std::min(nt, MAXGROUPS)));
-    int g = 0, b0 = 0;
-    d.off[0] = 0;
+    // round in which band kb completes (tfull = the split tiles at the end of the launch)
+    std::vector<int64_t> round((size_t)nt), endoff((size_t)nt);
+    int64_t seq_end = 0;
+    for (int c0 = 0; c0 < nt; c0 += order_w) {
+        const int h = std::min(order_w, nt - c0);
+        seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;             // tiles up to the end of this super-column (sk_colseq_unrank)
+        const int64_t r = seq_end <= tfull * G ? (seq_end - 1) / G : tfull;
+        for (int kb = c0; kb < c0 + h; ++kb) round[(size_t)kb] = r;
+    }
     for (int kb = 0; kb < nt; ++kb) {
         const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
-        const int64_t off = cend * (cend + 1) / 2;
-        const bool last_band = kb == nt - 1;
-        if (last_band || (off * ngroups >= total * (g + 1) && nt - 1 - kb >= ngroups - 1 - g)) {
-            d.gend[g] = (short)(kb + 1);
-            d.off[g + 1] = off;
-            unsigned long long tiles = 0;
-            for (int k = b0; k <= kb; ++k) tiles += (unsigned long long)(k + 1);
-            d.expect[g] = tiles * 32;           // Cfg<2>::NACC units per tile (gram_sk.hip: sk_signal_tile)
-            b0 = kb + 1;
-            ++g;
-            if (last_band) break;
+        endoff[(size_t)kb] = cend * (cend + 1) / 2;
+    }
+    // segments of equal round; groups per segment proportional to its bytes (at least one each)
+    struct Seg { int b0, b1; int64_t bytes; int groups; };
+    std::vector<Seg> segs;
+    for (int kb = 0; kb < nt; ++kb) {
+        if (segs.empty() || round[(size_t)kb] != round[(size_t)segs.back().b0]) segs.push_back({kb, kb + 1, 0, 1});
+        else segs.back().b1 = kb + 1;
+    }
+    while ((int)segs.size() > ngroups) { segs[segs.size() - 2].b1 = segs.back().b1; segs.pop_back(); }
+    const int64_t total = endoff[(size_t)nt - 1];
+    int spare = ngroups - (int)segs.size();
+    for (auto &sg : segs) sg.bytes = endoff[(size_t)sg.b1 - 1] - (sg.b0 ? endoff[(size_t)sg.b0 - 1] : 0);
+    for (auto &sg : segs) {
+        const int want = (int)std::min<int64_t>(sg.b1 - sg.b0 - 1, std::min<int64_t>(spare, sg.bytes * ngroups / std::max<int64_t>(1, total)));
+        sg.groups += std::max(0, want);
+        spare -= std::max(0, want);
+    }
+    int g = 0;
+    d.off[0] = 0;
+    for (const auto &sg : segs) {
+        const int64_t base = sg.b0 ? endoff[(size_t)sg.b0 - 1] : 0;
+        int b0 = sg.b0, k = 0;
+        for (int kb = sg.b0; kb < sg.b1; ++kb) {
+            const bool last = kb == sg.b1 - 1;
+            const int left_groups = sg.groups - 1 - k, left_bands = sg.b1 - 1 - kb;
+            if (last || ((endoff[(size_t)kb] - base) * sg.groups >= sg.bytes * (k + 1) && left_bands >= left_groups && left_groups > 0)) {
+                d.gend[g] = (short)(kb + 1);
+                d.off[g + 1] = endoff[(size_t)kb];
+                unsigned long long tiles = 0;
+                for (int q = b0; q <= kb; ++q) tiles += (unsigned long long)(q + 1);
+                d.expect[g] = tiles * 32;           // Cfg<2>::NACC units per tile (gram_sk.hip: sk_signal_tile)
+                b0 = kb + 1;
+                ++g; ++k;
+            }
         }
     }
     d.ngroups = g;
@@ -318,8 +477,9 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     PMT_REQUIRE(cols < (int64_t)GT * 32000, PMT_DIMENSION_MISMATCH, "quad_gram: too many columns");
     if (int rc = check_strictly_increasing(xvar, cols, stream)) return rc;
     DeliverPlan dplan;
+    std::shared_ptr<DeliverSignals> sig = std::make_shared<DeliverSignals>();      // lives as long as the recorded call
     if (host_csc && cols > 0) {
-        dplan = deliver_plan(cols, ngroups > 0 ? ngroups : 8, host_csc);
+        dplan = deliver_plan(rows, cols, ngroups > 0 ? ngroups : 8, DELIVER_ORDER_W, host_csc);
         dplan.host_dev = static_cast<double *>(host_device_pointer(host_csc));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
     }
@@ -330,9 +490,25 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         const bool deliver = dplan.host != nullptr;
         if (deliver) {
             PMT_REQUIRE(side && side->counters, PMT_STATE_ERROR, "quad_gram_csc_deliver: no auxiliary streams for this stream");
-            if (int rc = ensure_fetch_stream(side)) return rc;
-            // the previous delivery must have read out_csc before this contraction overwrites it
-            if (side->fetch_pending) { PMT_HIP_CHECK(hipStreamWaitEvent(s, side->fetch_done, 0)); side->fetch_pending = false; }
+            // Preferred: one copy-engine transfer per band group, each started by the signal the contraction sets (hsadma.hip)
+            if (!sig->tried) {
+                sig->tried = true;
+                dma::Engine *eng = dma::get(side->device);
+                if (eng) {
+                    bool ok = dma::signal_create(eng, 0, &sig->done) == PMT_OK;
+                    for (int i = 0; ok && i < dplan.ngroups; ++i) { ok = dma::signal_create(eng, 1, &sig->dep[i]) == PMT_OK; if (ok) sig->n = i + 1; }
+                    if (ok) sig->eng = eng;
+                }
+            }
+            if (sig->eng) {
+                // the previous delivery must have read out_csc before this contraction overwrites it, and its signals are re-armed
+                if (sig->pending) { if (int rc = dma::wait(sig->eng, sig->done, 10.0)) return rc; sig->pending = false; }
+                for (int i = 0; i < dplan.ngroups; ++i) dma::signal_set(sig->eng, sig->dep[i], 1);
+                dma::signal_set(sig->eng, sig->done, dplan.ngroups);
+            } else {
+                if (int rc = ensure_fetch_stream(side)) return rc;
+                if (side->fetch_pending) { PMT_HIP_CHECK(hipStreamWaitEvent(s, side->fetch_done, 0)); side->fetch_pending = false; }
+            }
         }
         hipStream_t s2 = s;
         if (side) {
@@ -352,33 +528,68 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             PMT_LAUNCH(gram_linear_kernel, dim3((unsigned)cdiv(cols, 4)), dim3(256), 0, s2, A, lda, rows, cols, xvar, b, sign, moi, varmap, out_lin);
             rc = check_launch("gram_linear_kernel");
         }
-        if (!rc) {
-            double *chains = scratch ? scratch + (size_t)linear_splits(rows, cols) * (size_t)cols : nullptr;
-            if (b && sign && rows > 0) rc = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2);
-            else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
-        }
-        if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));
+        // c'c: a serial chain of `rows` additions on ONE wave (bit for bit the reference's left-to-right sum) — ~50 us alone, ~0.3 ms beside
+        // the contraction.  Inside a plan's replay it is queued at the END of the replay, i.e. behind the tape's side-lane entries on the
+        // side stream (the MOI copies of the constraints, the hand-off gathers and their fetches), which used to wait for it.
+        double *chains = scratch ? scratch + (size_t)linear_splits(rows, cols) * (size_t)cols : nullptr;
+        auto const_part = [=]() -> int {
+            int rc2 = PMT_OK;
+            if (b && sign && rows > 0) rc2 = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2);
+            else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc2 = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
+            if (side) {
+                PMT_HIP_CHECK(hipEventRecord(side->join2, side->stream));
+                PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join2, 0));
+            }
+            return rc2;
+        };
+        const bool defer_const = side && side->in_replay;
+        if (!rc && defer_const) side->deferred.push_back(const_part);
+        if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
             SKDeliver sd;
             if (deliver) {
-                sd.progress = reinterpret_cast<unsigned long long *>(static_cast<char *>(side->counters) + PROGRESS_OFFSET);
+                char *cb = static_cast<char *>(side->counters);
+                sd.progress = reinterpret_cast<unsigned long long *>(cb + PROGRESS_OFFSET);
                 sd.ngroups = dplan.ngroups;
-                for (int i = 0; i < MAXGROUPS; ++i) sd.gend[i] = i < dplan.ngroups ? dplan.gend[i] : 0;
+                for (int i = 0; i < MAXGROUPS; ++i) {
+                    sd.gend[i] = i < dplan.ngroups ? dplan.gend[i] : 0;
+                    sd.expect[i] = i < dplan.ngroups ? dplan.expect[i] : 0;
+                    sd.ready[i] = i >= dplan.ngroups ? nullptr : (sig->eng ? reinterpret_cast<long long *>(sig->dep[i].value)
+                                                                            : reinterpret_cast<long long *>(cb + FLAGS_OFFSET) + i);
+                }
             }
             // a delivery wants the column bands finished in ascending order: super-columns of two tile columns
-            rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver ? 2 : 0, deliver ? &sd : nullptr, s);
+            rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver ? DELIVER_ORDER_W : 0, deliver ? &sd : nullptr, s);
             if (!rc && deliver) {
-                // fetch stream: ONE courier launch, queued now that the contraction's workgroups are on their way; it polls the band groups'
-                // counts and stores each finished group straight into the host array (deliver.hip)
-                char *cb = static_cast<char *>(side->counters);
-                rc = launch_courier(out_csc, dplan.host_dev, sd.progress, reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
-                                    reinterpret_cast<int *>(cb + DONE_OFFSET + sizeof(unsigned)), dplan.ngroups, dplan.expect, dplan.off, side->fetch);
-                if (rc) return rc;
-                PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
-                side->fetch_pending = true;
+                if (sig->eng) {
+                    // The engine works through its queue in submission order.  Inside a plan's replay the groups' transfers are therefore
+                    // submitted at the END of the replay, behind the recorded fetches of the tape (q, A's values, bounds: ready within the
+                    // first tenth of the contraction) — submitted here they would hold those back until the last band group has left.
+                    auto submit = [=]() -> int {
+                        for (int i = 0; i < dplan.ngroups; ++i)
+                            if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.off[i], out_csc + dplan.off[i],
+                                                            sizeof(double) * (size_t)(dplan.off[i + 1] - dplan.off[i]), &sig->dep[i], sig->done)) return rc2;
+                        return PMT_OK;
+                    };
+                    sig->pending = true;
+                    side->dma_pending.emplace_back(sig->eng, sig->done);
+                    side->keepalive.push_back(sig);
+                    if (side->in_replay) side->deferred.push_back(submit);
+                    else if (int rc2 = submit()) return rc2;
+                } else {
+                    // fallback, fetch stream: ONE courier launch, queued now that the contraction's workgroups are on their way; it polls the
+                    // band groups' flags and stores each finished group straight into the host array (deliver.hip)
+                    char *cb = static_cast<char *>(side->counters);
+                    rc = launch_courier(out_csc, dplan.host_dev, reinterpret_cast<long long *>(cb + FLAGS_OFFSET), reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
+                                        reinterpret_cast<int *>(cb + DONE_OFFSET + sizeof(unsigned)), dplan.ngroups, dplan.off, side->fetch);
+                    if (rc) return rc;
+                    PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
+                    side->fetch_pending = true;
+                }
             }
         }
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
+        if (!rc && !defer_const) rc = const_part();          // (behind the contraction's launch: its workgroups are placed first)
         return rc;
     });
 }

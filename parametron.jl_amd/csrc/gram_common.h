@@ -29,15 +29,18 @@ struct SKArgs {
     // bands of the output complete in ascending order, which is what a solver hand-off in CSC order wants to ship first.
     int order_w;
     // Host delivery (pmt_quad_gram_csc_deliver_f64): progress[i] counts the finished work of the tiles whose column band lies in band group i
-    // (bands [gend[i-1], gend[i])) in units of accumulators per thread — a whole tile NACC, a fix-up workgroup its share; the courier
-    // kernel (deliver.hip) polls the count and ships the group's columns.
+    // (bands [gend[i-1], gend[i])) in units of accumulators per thread — a whole tile NACC, a fix-up workgroup its share; the workgroup
+    // that completes a group (count == expect[i]) puts the count back to 0 and stores 0 into *ready[i].
     unsigned long long *progress;
     int ngroups;
     short gend[MAXGROUPS];
+    unsigned long long expect[MAXGROUPS];   // units of a complete group
+    long long *ready[MAXGROUPS];            // the word that is set to 0 when the group is complete: the value of the HSA signal the copy
+                                            // engine's transfer of this group depends on (hsadma.hip), or a flag the courier kernel polls
 };
 
 // host delivery of the CSC values: the kernel counts finished tiles per band group (bands [gend[i-1], gend[i])) in progress[i]
-struct SKDeliver { unsigned long long *progress; int ngroups; short gend[MAXGROUPS]; };
+struct SKDeliver { unsigned long long *progress; int ngroups; short gend[MAXGROUPS]; unsigned long long expect[MAXGROUPS]; long long *ready[MAXGROUPS]; };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
 template <int TN>

@@ -67,7 +67,8 @@ __device__ __forceinline__ int sk_fresh_tid() {
 
 // Host delivery: the tile's values are complete in memory before the count of its band group goes up — the delivery instantiation writes
 // them with system-scope write-through stores (sk_epilogue<.., SIGNAL>), so waiting for their acknowledgement is enough and this XCD's L2
-// is not flushed (a release fence at system scope writes back the WHOLE L2); the courier kernel polls the count (deliver.hip).
+// is not flushed (a release fence at system scope writes back the WHOLE L2).  The workgroup that completes a group stores 0 into the
+// group's `ready` word: the dependency signal of the copy engine's transfer of that group (hsadma.hip), or the courier's flag.
 // `units`: a whole tile counts NACC units, a fix-up workgroup the accumulators it handled.
 __device__ __forceinline__ void sk_signal_tile(const SKArgs &g, int kb, int tid, unsigned long long units) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -75,7 +76,11 @@ __device__ __forceinline__ void sk_signal_tile(const SKArgs &g, int kb, int tid,
     if (tid == 0) {
         int grp = 0;
         while (grp + 1 < g.ngroups && kb >= g.gend[grp]) ++grp;
-        __hip_atomic_fetch_add(&g.progress[grp], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long old = __hip_atomic_fetch_add(&g.progress[grp], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + units == g.expect[grp]) {          // every other contributor's stores were acknowledged before its own count
+            __hip_atomic_store(&g.progress[grp], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.ready[grp], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -585,12 +590,12 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.ws = reinterpret_cast<double *>(workspace);
     g.order_w = order_w;
     g.progress = nullptr; g.ngroups = 0;
-    for (int i = 0; i < MAXGROUPS; ++i) g.gend[i] = 0;
+    for (int i = 0; i < MAXGROUPS; ++i) { g.gend[i] = 0; g.expect[i] = 0; g.ready[i] = nullptr; }
     if (deliver) {
         PMT_REQUIRE(out_csc && deliver->progress && deliver->ngroups >= 1 && deliver->ngroups <= MAXGROUPS, PMT_INVALID_ARGUMENT,
                     "quad_gram: bad delivery description");
         g.progress = deliver->progress; g.ngroups = deliver->ngroups;
-        for (int i = 0; i < deliver->ngroups; ++i) g.gend[i] = deliver->gend[i];
+        for (int i = 0; i < deliver->ngroups; ++i) { g.gend[i] = deliver->gend[i]; g.expect[i] = deliver->expect[i]; g.ready[i] = deliver->ready[i]; }
     }
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);

@@ -1,0 +1,194 @@
+// Copy-engine (SDMA) delivery of results to the host, gated by signals the KERNELS set.
+//
+// Why not hipMemcpyAsync: measured on this stack (profiles/r03_host_delivery.txt) the HIP runtime bundled with PyTorch-ROCm 7.0 performs a
+// device -> page-locked-host hipMemcpyAsync with a blit KERNEL (__amd_rocclr_copyBuffer), /opt/rocm 7.2's with the copy engine; and a
+// stream-level "wait until this memory word changes" (hipStreamWaitValue64) is a spinning kernel in both.  Kernels that copy or spin sit on
+// the CUs of the persistent contraction and slowed it by 40-60 %.  The HSA runtime underneath both offers what the hardware has:
+// hsa_amd_memory_async_copy runs on an SDMA engine and starts when its DEPENDENCY SIGNALS read 0 — and a signal's value is an ordinary
+// 64-bit word in memory that a kernel can write.  So the contraction's epilogue stores 0 into the signal of a band group when the group's
+// last tile is in memory, and the engine ships that group while the matrix cores go on; no CU is involved in waiting or copying.
+//
+// The HSA runtime is the one the HIP runtime of this process has already loaded (found with dl_iterate_phdr, opened RTLD_NOLOAD): no second
+// runtime, no new dependency at link time.  If it cannot be found, or the device cannot be matched to an HSA agent, dma::get() returns null
+// and the callers fall back to kernel copies (deliver.hip).
+#include <dlfcn.h>
+#include <link.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <hsa/amd_hsa_signal.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include "common.h"
+#include "dma.h"
+
+namespace pmt {
+namespace dma {
+
+struct Api {
+    decltype(&hsa_init) init = nullptr;
+    decltype(&hsa_iterate_agents) iterate_agents = nullptr;
+    decltype(&hsa_agent_get_info) agent_get_info = nullptr;
+    decltype(&hsa_signal_create) signal_create = nullptr;
+    decltype(&hsa_signal_destroy) signal_destroy = nullptr;
+    decltype(&hsa_signal_store_relaxed) signal_store_relaxed = nullptr;
+    decltype(&hsa_signal_load_relaxed) signal_load_relaxed = nullptr;
+    decltype(&hsa_signal_wait_scacquire) signal_wait_scacquire = nullptr;
+    decltype(&hsa_amd_memory_async_copy) memory_async_copy = nullptr;
+};
+
+struct Engine {
+    Api api;
+    hsa_agent_t gpu{}, cpu{};
+};
+
+static std::mutex g_mu;
+static bool g_tried = false;
+static void *g_lib = nullptr;
+static Api g_api;
+static std::vector<Engine *> g_engines;        // per HIP device (null: no match)
+
+static int find_hsa(struct dl_phdr_info *info, size_t, void *data) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "libhsa-runtime64")) {
+        *static_cast<std::string *>(data) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+
+static bool load_api() {
+    if (g_tried) return g_lib != nullptr;
+    g_tried = true;
+#ifdef PMT_TUNING
+    if (const char *e = getenv("PMT_DMA")) if (e[0] == '0') return false;
+#endif
+    std::string path;
+    dl_iterate_phdr(find_hsa, &path);
+    if (path.empty()) return false;
+    void *lib = dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (!lib) return false;
+#define PMT_HSA_SYM(field, name)                                              \
+    g_api.field = reinterpret_cast<decltype(g_api.field)>(dlsym(lib, name)); \
+    if (!g_api.field) { dlclose(lib); return false; }
+    PMT_HSA_SYM(init, "hsa_init")
+    PMT_HSA_SYM(iterate_agents, "hsa_iterate_agents")
+    PMT_HSA_SYM(agent_get_info, "hsa_agent_get_info")
+    PMT_HSA_SYM(signal_create, "hsa_signal_create")
+    PMT_HSA_SYM(signal_destroy, "hsa_signal_destroy")
+    PMT_HSA_SYM(signal_store_relaxed, "hsa_signal_store_relaxed")
+    PMT_HSA_SYM(signal_load_relaxed, "hsa_signal_load_relaxed")
+    PMT_HSA_SYM(signal_wait_scacquire, "hsa_signal_wait_scacquire")
+    PMT_HSA_SYM(memory_async_copy, "hsa_amd_memory_async_copy")
+#undef PMT_HSA_SYM
+    if (g_api.init() != HSA_STATUS_SUCCESS) { dlclose(lib); return false; }     // reference-counted: HIP initialised it long ago
+    g_lib = lib;
+    return true;
+}
+
+struct AgentList { std::vector<hsa_agent_t> gpus, cpus; const Api *api; };
+static hsa_status_t collect_agent(hsa_agent_t a, void *data) {
+    AgentList *l = static_cast<AgentList *>(data);
+    hsa_device_type_t t;
+    if (l->api->agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_GPU) l->gpus.push_back(a);
+    else if (t == HSA_DEVICE_TYPE_CPU) l->cpus.push_back(a);
+    return HSA_STATUS_SUCCESS;
+}
+
+Engine *get(int device) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!load_api()) return nullptr;
+    if (device < 0) return nullptr;
+    if ((size_t)device < g_engines.size() && g_engines[(size_t)device]) return g_engines[(size_t)device];
+    AgentList l;
+    l.api = &g_api;
+    if (g_api.iterate_agents(collect_agent, &l) != HSA_STATUS_SUCCESS || l.gpus.empty() || l.cpus.empty()) return nullptr;
+    // the HSA agent of HIP device `device`: same PCI bus / device (HIP_VISIBLE_DEVICES renumbers HIP devices only)
+    int bus = -1, dev = -1;
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
+        hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    hsa_agent_t gpu{};
+    bool found = false;
+    for (hsa_agent_t a : l.gpus) {
+        uint32_t bdf = 0;
+        if (g_api.agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) continue;
+        if ((int)((bdf >> 8) & 0xff) == bus && (int)((bdf >> 3) & 0x1f) == dev) { gpu = a; found = true; break; }
+    }
+    if (!found) return nullptr;
+    Engine *e = new Engine();
+    e->api = g_api; e->gpu = gpu; e->cpu = l.cpus[0];
+    if (g_engines.size() <= (size_t)device) g_engines.resize((size_t)device + 1, nullptr);
+    g_engines[(size_t)device] = e;
+    return e;
+}
+
+int signal_create(Engine *e, int64_t initial, Signal *out) {
+    hsa_signal_t s{};
+    if (e->api.signal_create(initial, 0, nullptr, &s) != HSA_STATUS_SUCCESS) return fail(PMT_HIP_ERROR, "hsa_signal_create failed");
+    out->handle = s.handle;
+    // a signal is an amd_signal_t in system memory every agent can reach; its value is the word the copy engine polls and a kernel may write
+    out->value = const_cast<int64_t *>(&reinterpret_cast<amd_signal_t *>(s.handle)->value);
+    return PMT_OK;
+}
+
+void signal_destroy(Engine *e, Signal s) {
+    if (s.handle) (void)e->api.signal_destroy(hsa_signal_t{s.handle});
+}
+
+void signal_set(Engine *e, Signal s, int64_t v) { e->api.signal_store_relaxed(hsa_signal_t{s.handle}, v); }
+
+#ifdef PMT_TUNING
+static bool dbg() { static const bool on = getenv("PMT_DMA_DEBUG") != nullptr; return on; }
+static double dnow() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#endif
+
+int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes, const Signal *dep, Signal completion) {
+    hsa_signal_t d{};
+    if (dep) d.handle = dep->handle;
+#ifdef PMT_TUNING
+    if (dbg()) fprintf(stderr, "[dma %.0f] submit %zu bytes dep=%ld done=%ld (done handle %lx)\n", dnow(), bytes, dep ? (long)*dep->value : -99L, (long)*completion.value, (unsigned long)completion.handle);
+#endif
+    hsa_status_t st = e->api.memory_async_copy(host_dst, e->cpu, device_src, e->gpu, bytes, dep ? 1 : 0, dep ? &d : nullptr, hsa_signal_t{completion.handle});
+    if (st != HSA_STATUS_SUCCESS) return fail(PMT_HIP_ERROR, "hsa_amd_memory_async_copy failed (status " + std::to_string((int)st) + ")");
+    return PMT_OK;
+}
+
+// host: until the completion signal has counted down to 0 (every copy that decrements it is done); a negative value is the runtime's error
+// report; `timeout_s` bounds the wait (a dependency that is never signalled must not hang the host for good)
+int wait(Engine *e, Signal completion, double timeout_s) {
+    const uint64_t slice = 2000000000ull;                                       // the timeout argument is in HSA system-clock ticks: wait in slices
+    const double t0 = (double)clock() / CLOCKS_PER_SEC;
+    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+#ifdef PMT_TUNING
+    if (dbg()) fprintf(stderr, "[dma %.0f] wait on %lx: value %ld\n", dnow(), (unsigned long)completion.handle, (long)*completion.value);
+#endif
+    for (;;) {
+        const hsa_signal_value_t v = e->api.signal_wait_scacquire(hsa_signal_t{completion.handle}, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED);
+        if (v < 0) return fail(PMT_HIP_ERROR, "host delivery: the copy engine reported an error");
+#ifdef PMT_TUNING
+        if (dbg()) fprintf(stderr, "[dma %.0f] wait on %lx returned %ld\n", dnow(), (unsigned long)completion.handle, (long)v);
+#endif
+        if (v == 0) return PMT_OK;
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        if ((double)(ts.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts.tv_nsec - ts0.tv_nsec) > timeout_s)
+            return fail(PMT_HIP_ERROR, "host delivery: timed out waiting for the copy engine (a producer never signalled its data)");
+    }
+    (void)t0;
+}
+
+// one thread: the producers enqueued before this launch on `s` are done -> the copy that depends on `value` may start
+__global__ void signal_store_kernel(int64_t *value) {
+    __hip_atomic_store(value, (int64_t)0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_signal_store(Signal s, hipStream_t stream) {
+    PMT_LAUNCH(signal_store_kernel, dim3(1), dim3(1), 0, stream, s.value);
+    return check_launch("signal_store_kernel");
+}
+
+}  // namespace dma
+}  // namespace pmt

@@ -14,7 +14,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include <memory>
+
 #include "common.h"
+#include "dma.h"
 
 namespace pmt {
 
@@ -210,8 +213,10 @@ namespace pmt {
 hipStream_t side_stream_of(hipStream_t s);
 void retain_side_stream(hipStream_t s);
 void release_side_stream(hipStream_t s);
-int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes);
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st);
 int fetch_fence(hipStream_t s);
+void replay_begin(hipStream_t s);
+int replay_end(hipStream_t s);
 int fetch_synchronize(hipStream_t s);
 }
 
@@ -474,13 +479,17 @@ extern "C" int pmt_plan_end_record(pmt_plan *plan) {
 }
 
 
-// Side-lane entries (pmt_plan_set_lane) only read buffers that were complete BEFORE the replay started (Parameter values) and write
-// outputs nothing else in the tape reads, so they fork at the top of the replay and join at its end; they are queued on the calling
-// stream's side stream, where a Gram node's small reductions go first — see pmt_plan_set_lane in the header.
+// Side-lane entries (pmt_plan_set_lane) only read buffers that were complete BEFORE the replay started (Parameter values) — or the AFFINE
+// part of a Gram node recorded before them (the hand-off's q gather): they are queued on the calling stream's side stream, BEHIND that
+// node's affine reduction — and write outputs nothing else in the tape reads, so they fork at the top of the replay and join at its end.
+// (One side stream, not two: a second low-priority stream per plan cost config 3 its overlapped uploads, 1.27 -> 1.76 ms per step —
+// the runtime maps streams onto a handful of hardware queues, and the plan's copy stream ended up sharing one.  profiles/r03_host_delivery.txt)
 static int replay(pmt_plan *plan, hipStream_t s) {
     // copies of the previous re-evaluation that are still on the fetch stream read buffers this one is about to overwrite
     if (!plan->fetch_events.empty())
         if (int rc = pmt::fetch_fence(s)) return rc;
+    pmt::replay_begin(s);
+    struct End { hipStream_t s; int rc = PMT_OK; bool done = false; int finish() { if (!done) { done = true; rc = pmt::replay_end(s); } return rc; } ~End() { finish(); } } end{s};
     hipStream_t side = nullptr;
     bool any = false;
     for (char l : plan->lanes) any |= (l != 0);
@@ -505,7 +514,7 @@ static int replay(pmt_plan *plan, hipStream_t s) {
         PMT_HIP_CHECK(hipEventRecord(plan->lane_join, side));
         PMT_HIP_CHECK(hipStreamWaitEvent(s, plan->lane_join, 0));
     }
-    return PMT_OK;
+    return end.finish();
 }
 
 // ---- recorded fetches: results leave for the host while the tape is still running -----------------------------------------------------
@@ -523,7 +532,8 @@ extern "C" int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void 
     PMT_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     plan->fetch_events.push_back(ev);
     hipStream_t main = plan->stream;
-    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes); });
+    std::shared_ptr<pmt::FetchState> st = std::make_shared<pmt::FetchState>();     // the transfer's signals; goes with the tape entry
+    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes, st.get()); });
     plan->lanes.push_back(plan->record_lane);
     return PMT_OK;
 }

@@ -66,11 +66,11 @@ class HostQP:
         self.P_delivered_by_contraction = "P_host" in obj_dev
         self.Px = self.Px[:qp.P.nnz]
         self.Pi, self.Pp = qp.P.row_idx, qp.P.col_ptr
-        self.q = ctx.pinned_array(max(qp.nvars, 1), np.float64)[:qp.nvars]
+        self._small = ctx.pinned_array(max(qp._small_len, 1), np.float64)        # q | l | u, one transfer
+        n, m = qp.nvars, qp.nrows
+        self.q, self.l, self.u = self._small[:n], self._small[n:n + m], self._small[n + m:n + 2 * m]
         self.Ax = ctx.pinned_array(max(qp.A.nnz, 1), np.float64)[:qp.A.nnz]
         self.Ai, self.Ap = qp.A.row_idx, qp.A.col_ptr
-        self.l = ctx.pinned_array(max(qp.nrows, 1), np.float64)[:qp.nrows]
-        self.u = ctx.pinned_array(max(qp.nrows, 1), np.float64)[:qp.nrows]
         self._r = ctx.pinned_array(1, np.float64)
         self._r[0] = qp._obj_const[1]
 
@@ -78,14 +78,18 @@ class HostQP:
     def r(self):
         return self._qp.sign * float(self._r[0])
 
-    def transfers(self):
-        """(host array, device pointer) pairs of one re-evaluation; P is absent when the contraction delivers it itself"""
+    def transfers(self, late=None):
+        """(host array, device pointer) pairs of one re-evaluation; P is absent when the contraction delivers it itself.
+        late=False: what the hand-off launches produce (A's values, q | l | u); late=True: what only the objective's own kernels finish —
+        its constant (the node's serial c'c chain) and P when it is not delivered band by band; None: all."""
         qp = self._qp
-        t = [(self.Ax, qp.A.values_ptr), (self.q, qp.q_ptr), (self.l, qp.l_ptr), (self.u, qp.u_ptr)]
+        early = [(self.Ax, qp.A.values_ptr), (self._small[:qp._small_len], qp._small_ptr)]
+        tail = []
         if qp._obj_const[0]:
-            t.append((self._r, qp._obj_const[0]))
+            tail.append((self._r, qp._obj_const[0]))
         if not self.P_delivered_by_contraction:
-            t.append((self.Px, qp.P.values_ptr))
+            tail.append((self.Px, qp.P.values_ptr))
+        t = early + tail if late is None else (tail if late else early)
         return [(a, ptr) for a, ptr in t if a.nbytes]
 
     def nbytes(self):
@@ -150,7 +154,11 @@ class DeviceQP:
             else:
                 lblocks.append(_Block(at["var"].copy(), None, obj.dev["terms"], 16))
         self.P = direct_P if direct_P is not None else self._build_matrix(qblocks, n, n, upper=True, alpha=self.sign)
-        self.q_ptr = ctx.alloc(8 * max(n, 1))
+        # q, l and u share ONE device block (q | l | u): a host delivery ships them as a single transfer
+        mrows = sum(c.nrows for c in model.constraints)
+        self._small_ptr = ctx.alloc(8 * max(n + 2 * mrows, 1))
+        self._small_len = n + 2 * mrows
+        self.q_ptr = self._small_ptr
         ctx.upload(self.q_ptr, np.zeros(max(n, 1)))
         for b in lblocks:
             self._add_vector_block(b, n, self.q_ptr, self.sign)
@@ -191,7 +199,7 @@ class DeviceQP:
             row0 += c.nrows
         self.nrows = m = row0
         self.A = self._build_matrix(ablocks, m, n, upper=False, alpha=1.0)
-        self.l_ptr, self.u_ptr = ctx.alloc(8 * max(m, 1)), ctx.alloc(8 * max(m, 1))
+        self.l_ptr, self.u_ptr = self._small_ptr + 8 * n, self._small_ptr + 8 * (n + m)
         if m and any(dev_consts is not None for (_, _, _, _, dev_consts, _) in bounds):
             # all rows in one launch: row i reads its constant through an address (constant functions get a device copy of theirs)
             cptr, kinds, values_ = np.zeros(m, dtype=np.uint64), np.zeros(m, dtype=np.int32), np.zeros(m)
@@ -222,9 +230,12 @@ class DeviceQP:
                 for name, args in self._launches:
                     ctx.call(name, *args)
                 if host == "overlap":
-                    for arr, ptr in self.host.transfers():
+                    for arr, ptr in self.host.transfers(late=False):
                         ctx.record_fetch(arr, ptr, arr.nbytes)
                 ctx.set_lane(0)
+                if host == "overlap":                       # behind the objective's own kernels on the plan's stream
+                    for arr, ptr in self.host.transfers(late=True):
+                        ctx.record_fetch(arr, ptr, arr.nbytes)
             finally:
                 ctx.end_record()
             self._in_tape = True

@@ -111,13 +111,14 @@ int main() {
     double *hm = nullptr, *hd = nullptr;
     CK(hipHostMalloc(&hm, 64u << 20, hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void **)&hd, hm, 0));
-    for (int blocks : {64, 256, 1024}) {
+    for (int cfg = 0; cfg < 7; ++cfg) {
+        const int blocks = (const int[]){64, 256, 1024, 8, 8, 16, 4}[cfg], threads = (const int[]){256, 256, 256, 1024, 256, 1024, 1024}[cfg];
         for (int rep = 0; rep < 2; ++rep) {
             double t0 = now();
-            hipLaunchKernelGGL(store_kernel, dim3(blocks), dim3(256), 0, s, hd, (size_t)(64u << 20) / 8);
+            hipLaunchKernelGGL(store_kernel, dim3(blocks), dim3(threads), 0, s, hd, (size_t)(64u << 20) / 8);
             CK(hipStreamSynchronize(s));
             double t1 = now();
-            printf("zero-copy store 64 MB, %d workgroups: %.3f ms (%.1f GB/s) host sees %.1f %.1f\n", blocks, (t1 - t0) * 1e3, (64u << 20) / (t1 - t0) / 1e9, hm[0], hm[1]);
+            printf("zero-copy store 64 MB, %d workgroups x %d threads: %.3f ms (%.1f GB/s) host sees %.1f %.1f\n", blocks, threads, (t1 - t0) * 1e3, (64u << 20) / (t1 - t0) / 1e9, hm[0], hm[1]);
         }
     }
     return 0;

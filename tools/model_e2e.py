@@ -57,7 +57,12 @@ def main():
         model.wait_staged()
     dt = (time.perf_counter() - t0) / k
     if host_csc:
+        import numpy as np
         h = model.device_qp.host
+        dev = model.device_qp.fetch()
+        hd = h.as_dict()
+        same = {k: bool(np.array_equal(hd[k][0] if k in ("P", "A") else hd[k], dev[k][0] if k in ("P", "A") else dev[k])) for k in ("P", "A", "q", "l", "u")}
+        print("host arrays equal the device hand-off after the timed loop:", same, "r", hd["r"] == dev["r"])
         print("host_csc hand-off (%s): steady solve! %.3f ms = %.1f /s; %.1f MB to the host per solve (PCIe floor at 54 GB/s: %.2f ms); P delivered by the contraction: %s"
               % ("serial" if "--serial" in sys.argv else "overlapped", dt * 1e3, 1 / dt, h.nbytes() / 1e6, h.nbytes() / 54e9 * 1e3, h.P_delivered_by_contraction))
         return
