@@ -12,10 +12,14 @@ in HBM when the timed region starts, outputs left in HBM (the PCIe-inclusive rat
 it under "host_api", never as `value`).
 
 python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
-N > 1 runs N independent QP instances (one per GPU, no data-path collective): weak scaling.
---workload batch runs BASELINE config 4 alone (8192 x n=128 QPs sharded by instance + RCCL all-gather of the slabs).
-Prints ONE JSON line on rank 0.  At N = 1 the line also carries, under "configs", the other BASELINE configurations
-(C3, C4 on one GPU, C5) measured in the same process with their dominant kernel's roofline.
+The headline (`value`) is config 2 on every GPU: N > 1 runs N independent QP instances (one per GPU, no data-path collective —
+a single QP's rebuild does not shard): weak scaling.  The SAME line carries `configs.C4_sharded`: BASELINE config 4 (8192 independent
+n = 128 QPs) sharded by instance over the N ranks with the exchange of the coefficient slabs behind the C ABI (RCCL send/recv per
+peer) — compute only, computation + one monolithic all-gather, and the overlapped step, with `ranks_seen`, the bytes every rank puts
+on the wire and the per-link-bound cost of them: north_star's multi-GPU configuration under the driver's own command.  At N = 1 it
+runs the same code path with the single-rank communicator.
+--workload batch runs config 4 alone.  Prints ONE JSON line on rank 0.  At N = 1 the line also carries, under "configs", the other
+BASELINE configurations (C3, C4 on one GPU, C5) measured in the same process with their dominant kernel's roofline.
 """
 import argparse
 import ctypes as C
@@ -315,7 +319,39 @@ def config_c4(torch, _lib, steps):
 
 
 def config_c5(torch, P, _lib, steps):
+    """C5 at two boundaries.  `ms_per_step` is DEVICE-RESIDENT like the headline: nzval and d are regenerated on the device (the fills are
+    part of the step), the MOI triplets stay in HBM.  Beside it the host-updated form (`val=` Parameters: 27 MB cross PCIe per update),
+    serial and staged — BOTH reported: the copy is 0.5 ms against 0.04 ms of kernels, so there is nothing for a staged copy to hide behind
+    and the two differ by the cost of their host calls only."""
     from parametron_jl_amd import workloads
+    out = {}
+    model, Cs = workloads.config5(device_resident=True, handoff="device")
+    P.solve(model)
+    ctx = model.device()
+    out["workload"] = "C5: sparse C (5 %%, %d non-zeros, fixed pattern), n=16384, m=4096; device-resident: nzval and d regenerated on the device each step" % Cs.nnz
+
+    def resident():
+        model.update(synchronize=False)
+    for _ in range(20):
+        resident()
+    ctx.synchronize()
+    t = timed_loop(torch, resident, steps)
+    out["ms_per_step"] = t / steps * 1e3
+    out["re_evaluations_per_s"] = steps / t
+    out["boundary"] = "device-resident (Parameter values made in HBM, MOI buffers left in HBM), as the headline"
+    _lib.call("pmt_profile_enable", 1)
+    for _ in range(20):
+        resident()
+    ctx.synchronize()
+    kern = profile_report(_lib)
+    _lib.call("pmt_profile_enable", 0)
+    out["kernels"] = kern
+    name = next((k for k in kern if k.startswith("sparse_")), None)
+    if name:
+        # per non-zero: coefficient read (8) + static index streams read (4 + 4) + VectorAffineTerm written (24); + row pointers
+        out["roofline"] = hbm_roofline(name, kern[name]["avg_ms"], 40.0 * Cs.nnz, "pmt::sparse_")
+    model.close()
+
     model, Cs = workloads.config5(pinned=True, handoff="device")
     P.solve(model)
     ctx = model.device()
@@ -326,27 +362,15 @@ def config_c5(torch, P, _lib, steps):
     def staged():
         model.stage_parameters()
         model.update(synchronize=False)
-    out = {"workload": "C5: sparse C (5 %%, %d non-zeros, fixed pattern), n=16384, m=4096; nzval and d host-updated val= Parameters (27 MB per update)" % Cs.nnz}
+    hu = {"what": "nzval and d host-updated val= Parameters: 27 MB over PCIe per update (0.5 ms at 54 GB/s) in front of 0.04 ms of kernels"}
     for name, fn in (("serial_upload", serial), ("staged_upload", staged)):
         for _ in range(10):
             fn()
         ctx.synchronize()
         t = timed_loop(torch, fn, steps)
         model.wait_staged()
-        out[name] = {"ms_per_step": t / steps * 1e3, "re_evaluations_per_s": steps / t}
-    _lib.call("pmt_profile_enable", 1)
-    for _ in range(10):
-        staged()
-    ctx.synchronize()
-    kern = profile_report(_lib)
-    _lib.call("pmt_profile_enable", 0)
-    best = min(("staged_upload", "serial_upload"), key=lambda k: out[k]["ms_per_step"])   # the 27 MB copy is the step either way
-    out["ms_per_step"], out["upload_mode"] = out[best]["ms_per_step"], best
-    out["kernels"] = kern
-    name = next((k for k in kern if k.startswith("sparse_")), None)
-    if name:
-        # per non-zero: coefficient read (8) + static variable index read (8) + VectorAffineTerm written (24); + row pointers
-        out["roofline"] = hbm_roofline(name, kern[name]["avg_ms"], 40.0 * Cs.nnz, "pmt::sparse_")
+        hu[name] = {"ms_per_step": t / steps * 1e3, "re_evaluations_per_s": steps / t}
+    out["host_updated"] = hu
     model.close()
     return out
 
@@ -598,6 +622,7 @@ def main():
         for _ in range(5):
             wl.step_with_refresh()
         t = timed_loop(torch, wl.step_with_refresh, args.steps)
+        out["config"]["value_with_param_refresh"] = args.steps / t       # the reference's update! runs the Parameter callbacks too (src/model.jl:132-133)
         out["value_with_param_refresh"] = {"value": args.steps / t, "ms_per_step": t / args.steps * 1e3,
                                            "what": "every step regenerates A, b, C, d on the device (151 MB, pmt_fill_uniform_*) before the re-evaluation"}
         if args.steps < 200:
@@ -613,6 +638,19 @@ def main():
             out["host_api"] = guarded(host_api_c2, torch, P, 10)
         out["cpu_baseline"] = None if args.no_cpu_baseline else guarded(cpu_baseline, wl)
         out["cpu_canonical_blas"] = None if args.no_cpu_baseline else guarded(cpu_canonical_blas, wl)
+    else:
+        wl.close()
+    if not args.no_configs:
+        # every rank: BASELINE config 4 sharded by instance over the N ranks (N = 1: the same code path, single-rank communicator)
+        from parametron_jl_amd import batch
+        ksteps = max(20, min(args.steps, 100))
+        try:
+            sharded = batch.measure(torch, dist, rank, world, ksteps, args.warmup)
+        except Exception as e:                  # (a failing side section must not take the headline with it; every rank fails alike)
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out.setdefault("configs", {})["C4_sharded"] = sharded
+            out["ranks_seen"] = sharded.get("ranks_seen") if isinstance(sharded, dict) else None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

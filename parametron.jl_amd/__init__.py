@@ -7,7 +7,7 @@ solve!, src/Parametron.jl:3-36) over the C ABI of libparametron_hip.so (include/
 from . import _lib  # noqa: F401
 from ._lib import ArgumentError, DimensionMismatch, ErrorException  # noqa: F401
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, canonicalize  # noqa: F401
-from .parameter import DerivedParameter, DeviceUniformParameter, Parameter  # noqa: F401
+from .parameter import DerivedParameter, DeviceUniformParameter, DeviceUniformSparseParameter, Parameter  # noqa: F401
 from .lazyexpression import (LazyExpression, Relation, adjoint, bilinear, dot, expression, getindex, getproperty, lazy, prune_zero, transpose,  # noqa: F401
                              vcat, vect, wrap)
 from .hostops import Transpose  # noqa: F401

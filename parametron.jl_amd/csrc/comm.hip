@@ -106,22 +106,29 @@ extern "C" int pmt_comm_unique_id(void *out_id_128_bytes) {
     return PMT_OK;
 }
 
+extern "C" int pmt_comm_destroy(void *comm);
+
 extern "C" int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_128_bytes, int device, void **out_comm) {
     PMT_REQUIRE(out_comm && nranks >= 1 && rank >= 0 && rank < nranks, PMT_INVALID_ARGUMENT, "comm_init_rank: bad argument");
+    PMT_REQUIRE(nranks == 1 || unique_id_128_bytes, PMT_INVALID_ARGUMENT, "comm_init_rank: null unique id");
+    Rccl *R = nullptr;
+    if (nranks > 1) {                        // a single rank needs no communicator (and no RCCL); checked BEFORE anything is allocated
+        R = rccl();
+        if (!R->handle || !R->why.empty()) return fail(PMT_STATE_ERROR, "RCCL is not available: " + R->why);
+    }
     Comm *c = new Comm();
     c->rank = rank; c->nranks = nranks; c->device = device;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->computed, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gathered, hipEventDisableTiming);
-    if (e != hipSuccess) { delete c; return fail(PMT_HIP_ERROR, std::string("comm_init_rank: ") + hipGetErrorString(e)); }
-    if (nranks > 1) {                        // a single rank needs no communicator (and no RCCL)
-        PMT_REQUIRE(unique_id_128_bytes, PMT_INVALID_ARGUMENT, "comm_init_rank: null unique id");
-        PMT_RCCL_READY();
+    // every failure from here on leaves through pmt_comm_destroy: the stream and the events go with the communicator
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)pmt_comm_destroy(c); return fail(PMT_HIP_ERROR, std::string("comm_init_rank: ") + hipGetErrorString(e)); }
+    if (nranks > 1) {
         UniqueId id;
         memcpy(&id, unique_id_128_bytes, sizeof id);
         int rc = R->comm_init_rank(&c->nccl, nranks, id, rank);
-        if (rc != 0) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+        if (rc != 0) { c->nccl = nullptr; (void)pmt_comm_destroy(c); return rccl_fail("ncclCommInitRank", rc); }
     }
     *out_comm = c;
     return PMT_OK;

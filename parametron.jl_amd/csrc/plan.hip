@@ -9,6 +9,7 @@
 // host-side term bookkeeping (the reference's @allocated == 0 contract) — or, once
 // pmt_plan_instantiate_graph() has captured them, launches one hipGraph.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -122,12 +123,14 @@ int dispatch(void *stream, Launch launch) {
 namespace pmt {
 
 struct ProfRecord { const char *name; hipEvent_t e0, e1; };
-static bool g_prof_on = false;
+// The switch is an atomic (read by every launch of every thread); the filter, the record list and the event pool are only touched under
+// g_mu — two plans on two host threads may launch with profiling on (tests/test_gpu_hardening.py).
+static std::atomic<bool> g_prof_on{false};
 static std::string g_prof_filter;               // non-empty: only kernels whose name contains it are bracketed
 static std::vector<ProfRecord> g_prof_records;
 static std::vector<hipEvent_t> g_prof_pool;
 
-static hipEvent_t prof_event() {
+static hipEvent_t prof_event() {                // caller holds g_mu
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -135,12 +138,15 @@ static hipEvent_t prof_event() {
 }
 
 ProfScope::ProfScope(const char *name, hipStream_t s) : name_(name), s_(s) {
-    if (!g_prof_on) return;
-    if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str())) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return; }
     if (st != hipStreamCaptureStatusNone) return;          // never time inside a graph capture
-    e0_ = prof_event(); e1_ = prof_event();
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str())) return;
+        e0_ = prof_event(); e1_ = prof_event();
+    }
     if (e0_ && e1_) (void)hipEventRecord(e0_, s);
 }
 ProfScope::~ProfScope() {
@@ -164,7 +170,7 @@ extern "C" int pmt_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
     for (auto &r : g_prof_records) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
     g_prof_records.clear();
-    g_prof_on = on != 0;
+    g_prof_on.store(on != 0);
     return PMT_OK;
 }
 

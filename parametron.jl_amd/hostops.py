@@ -195,7 +195,17 @@ def apply(f, *args):
             return vecdot(a.parent, b)
         if isinstance(a, _RowTimesMatrix):
             return bilinearmul(a.Q, a.x, b)
+        # a 0-dimensional array is a scalar (Julia: a Number); scalar * numeric array of ANY rank is the elementwise scaling — `2 * A`
+        # is valid Julia, the generic rule src/lazyexpression.jl:198 calls `*` out of place
+        if isinstance(a, np.ndarray) and a.ndim == 0:
+            a = a.item()
+        if isinstance(b, np.ndarray) and b.ndim == 0:
+            b = b.item()
         na, nb = _is_numeric(a), _is_numeric(b)
+        if _isnum(a) and nb and isinstance(b, np.ndarray) and b.ndim >= 2:
+            return float(a) * _num_array(b)
+        if _isnum(b) and na and isinstance(a, np.ndarray) and a.ndim >= 2:
+            return _num_array(a) * float(b)
         if na and nb:
             # plain numbers on both sides: Julia's `*` is the MATRIX product (never numpy's elementwise broadcast) —
             # Matrix*Matrix, Matrix*Vector; Vector*Vector has no method (the generic rule src/lazyexpression.jl:198 would throw)

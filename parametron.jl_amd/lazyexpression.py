@@ -131,13 +131,17 @@ def device_value_of(x, ctx=None):
             return x._dev
         val = Parameter.__call__(x)                 # evalarg(::Parameter) (src/lazyexpression.jl:51)
         if x._dev is None:
-            if getattr(x, "device_resident", False):
+            if getattr(x, "pattern", None) is not None:                   # DeviceUniformSparseParameter: fixed pattern, values made on the device
+                x._dev = DSpMat(ctx, x.pattern)
+            elif getattr(x, "device_resident", False):
                 x._dev = DVec(ctx, x.shape[0]) if len(x.shape) == 1 else DMat(ctx, *x.shape)
             else:
                 x._dev = _alloc_like(ctx, val)
         if x._dev_version != x.version:
             if getattr(x, "device_resident", False):
-                if isinstance(x._dev, DMat):
+                if isinstance(x._dev, DSpMat):
+                    ctx.call("pmt_fill_uniform_f64", P(x._dev.buf), int(x._dev.nnz), C.c_uint64(x.current_seed()), x.scale)
+                elif isinstance(x._dev, DMat):
                     ctx.call("pmt_fill_uniform_matrix_f64", P(x._dev.buf), x._dev.rows, x._dev.cols, x._dev.lda,
                              C.c_uint64(x.current_seed()), x.scale)
                 else:
@@ -779,7 +783,10 @@ def _rule_canonicalize(model, ctx, x):
         try:
             ctx.synchronize()
             ctx.call_now("pmt_canonical_order_device", P(terms_ptr), nterms, nbytes, P(dperm), P(dseg), C.byref(nseg))
-        except ArgumentError:
+        except ArgumentError as e:
+            if "2^32" not in str(e):                                    # only the too-large-index case has a host fallback; anything else
+                raise                                                   # (null pointer, bad term size) is an error, not a slow path
+            # the host-computed perm / seg reuse the two buffers allocated above (same sizes), nothing is left behind
             t = fetch_terms(ctx, terms_ptr, nterms, dtype); ctx.synchronize()
             if dtype is LT:
                 perm, seg, (ov,) = _canonical_order("aff", t["var"])
@@ -787,7 +794,8 @@ def _rule_canonicalize(model, ctx, x):
             else:
                 perm, seg, (orow, ocol) = _canonical_order("quad", t["row"], t["col"])
                 init = np.zeros(len(orow), dtype=QT); init["row"] = orow; init["col"] = ocol
-            return ctx.upload_new(perm), ctx.upload_new(seg), len(init), lambda out_ptr: ctx.upload(out_ptr, init)
+            ctx.upload(dperm, np.ascontiguousarray(perm, dtype=np.int64)); ctx.upload(dseg, np.ascontiguousarray(seg, dtype=np.int64))
+            return dperm, dseg, len(init), lambda out_ptr: ctx.upload(out_ptr, init)
         n = int(nseg.value)
         return dperm, dseg, n, lambda out_ptr: ctx.call_now("pmt_canonical_init_terms", P(terms_ptr), nbytes, P(dperm), P(dseg), n, P(out_ptr))
 
@@ -821,6 +829,8 @@ SCALAR_FUNC_KINDS = {"aff", "quad", "var", "lt", "qt"}
 
 def _arg_kind(a):
     if isinstance(a, Parameter):
+        if getattr(a, "pattern", None) is not None:
+            return "spmat"
         if getattr(a, "device_resident", False):
             return "vec" if len(a.shape) == 1 else "mat"
         return kind_of(a())                           # evaluates the Parameter once, like evalarg at :187

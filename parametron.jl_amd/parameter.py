@@ -152,3 +152,33 @@ class DeviceUniformParameter(Parameter):
                 self.val = host
             self._host_stale = False
         return self.val
+
+
+class DeviceUniformSparseParameter(DeviceUniformParameter):
+    """A sparse Parameter (scipy.sparse.csc_matrix ↔ Julia SparseMatrixCSC) with a FIXED pattern whose non-zero values are regenerated
+    ON THE DEVICE at every update: nzval[t] = offset + scale * U[0,1)(seed + 1000*epoch, t) — BASELINE config 5 with the values resident
+    in HBM, like DeviceUniformParameter for dense values.  Calling it returns a host copy with the current values."""
+
+    def __init__(self, pattern, seed, model, scale=1.0, advance=True):
+        import scipy.sparse as sp
+        pattern = sp.csc_matrix(pattern)
+        self.pattern = sp.csc_matrix((np.zeros(pattern.nnz), pattern.indices.copy(), pattern.indptr.copy()), shape=pattern.shape)
+        self.shape = tuple(int(s) for s in pattern.shape)
+        self.seed, self.scale, self.advance = int(seed), float(scale), advance
+        self.epoch = -1
+        Parameter.__init__(self, lambda v: v, self.pattern, model)
+        self.device_resident = True
+
+    def __call__(self):
+        Parameter.__call__(self)
+        from .lazyexpression import device_value_of
+        dv = device_value_of(self)
+        if getattr(self, "_host_stale", True):
+            ctx = self.model.device()
+            host = np.empty(max(dv.nnz, 1), dtype=np.float64)
+            ctx.fetch(host, dv.buf, 8 * dv.nnz)
+            ctx.synchronize()
+            self.pattern.data[:] = host[:dv.nnz]
+            self.val = self.pattern
+            self._host_stale = False
+        return self.val

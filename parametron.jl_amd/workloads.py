@@ -13,7 +13,7 @@ import numpy as np
 from .model import Minimize, MockOptimizer, Model, constraint, objective
 from .functions import Variable
 from .lazyexpression import dot
-from .parameter import DeviceUniformParameter, Parameter
+from .parameter import DeviceUniformParameter, DeviceUniformSparseParameter, Parameter
 
 
 def lsq_objective(model, n, r):
@@ -63,7 +63,9 @@ def config3(pinned=True, seed=5, **kw):
     return model, bufs
 
 
-def config5(seed=3, pinned=False, **kw):
+def config5(seed=3, pinned=False, device_resident=False, **kw):
+    """device_resident=True: nzval and d are regenerated on the device at every update (the boundary config 2 is benchmarked at);
+    otherwise they are `val=` Parameters the host rewrites (27 MB cross PCIe per update)."""
     import scipy.sparse as sp
     m, n = 4096, 16384
     rng = np.random.default_rng(seed)
@@ -71,6 +73,13 @@ def config5(seed=3, pinned=False, **kw):
     indptr = np.arange(0, (n + 1) * k, k, dtype=np.int64)
     indices = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for _ in range(n)]).astype(np.int64)
     model = Model(MockOptimizer(), **kw)
+    if device_resident:
+        Cs = sp.csc_matrix((np.ones(indices.size), indices, indptr), shape=(m, n), copy=False)
+        x = [Variable(model) for _ in range(n)]
+        Cp = DeviceUniformSparseParameter(Cs, 3, model)
+        d = DeviceUniformParameter((m,), 4, model, scale=2.0)
+        constraint(model, Cp * x == d)
+        return model, Cs
     data = model.parameter_array(indices.size) if pinned else np.empty(indices.size)      # page-locked nzval: uploads at PCIe speed
     data[:] = rng.random(indices.size) + 0.1
     Cs = sp.csc_matrix((data, indices, indptr), shape=(m, n), copy=False)

@@ -127,3 +127,34 @@ def test_xcd_aware_slab_kernels_equal_the_flat_scatter(m, n, density, nslab):
         dense = np.zeros((m, n))
         dense[t["out"] - 8, n - model_var] = t["coeff"]                     # row_offset 7, 1-based rows
         assert np.array_equal(dense, csc.toarray())
+
+
+def test_device_resident_sparse_parameter_matches_the_host_updated_one():
+    """DeviceUniformSparseParameter: nzval regenerated on the device (config 5 at the headline's boundary) — the MOI triplets equal those
+    of a host-updated sparse Parameter holding the same values, and they change from solve to solve"""
+    import scipy.sparse as sp
+    import parametron_jl_amd as P
+    from oracle import oracle as O
+    m, n, k = 96, 200, 7
+    rng = np.random.default_rng(2)
+    indptr = np.arange(0, (n + 1) * k, k, dtype=np.int64)
+    indices = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for _ in range(n)]).astype(np.int64)
+    pattern = sp.csc_matrix((np.ones(indices.size), indices, indptr), shape=(m, n))
+    model = P.Model(P.MockOptimizer())
+    x = [P.Variable(model) for _ in range(n)]
+    Cp = P.DeviceUniformSparseParameter(pattern, 3, model)
+    d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    P.constraint(model, Cp * x == d)
+    prev = None
+    for epoch in range(3):
+        P.solve(model)
+        f = list(model.constraints)[0].f
+        vals = O.fill_uniform(indices.size, Cp.current_seed())                 # the same counter-based stream on the CPU
+        dense = sp.csc_matrix((vals, indices, indptr), shape=(m, n)).toarray()
+        got = np.zeros((m, n)); got[f.terms["out"] - 1, f.terms["var"] - 1] = f.terms["coeff"]
+        assert np.array_equal(got, dense)
+        assert np.array_equal(f.constants, 0.0 - O.fill_uniform(m, d.current_seed(), 2.0))
+        assert np.array_equal(Cp().toarray(), dense)                            # host copy on demand
+        assert prev is None or not np.array_equal(prev, dense)
+        prev = dense
+    model.close()

@@ -283,3 +283,26 @@ def test_number_array_products_are_matrix_products():
     row = hostops.apply("*", hostops.Transpose(b), A)
     assert isinstance(row, hostops.Transpose) and np.array_equal(row.parent, A.T @ b)
     assert hostops.apply("*", row, b) == float(b @ A @ b)
+
+
+def test_scalar_times_number_array_of_any_rank_is_a_scaling():
+    """`2 * A` is valid Julia (the generic rule src/lazyexpression.jl:198 calls `*` out of place); a 0-dimensional array is a
+    scalar.  Only vector * vector has no method."""
+    from parametron_jl_amd import hostops
+    A = np.arange(6.0).reshape(2, 3)
+    assert np.array_equal(hostops.apply("*", 2.0, A), 2.0 * A)
+    assert np.array_equal(hostops.apply("*", A, 2.0), 2.0 * A)
+    assert np.array_equal(hostops.apply("*", np.array(2.0), np.ones(3)), 2.0 * np.ones(3))
+    assert np.array_equal(hostops.apply("*", np.ones(3), np.array(0.5)), 0.5 * np.ones(3))
+    assert np.array_equal(hostops.apply("*", np.array(3.0), A), 3.0 * A)
+    with pytest.raises(P.ArgumentError):
+        hostops.apply("*", np.ones(3), np.ones(3))
+
+
+def test_derived_parameter_scalar_times_matrix_parameter():
+    """a Parameter-only expression scalar Parameter * matrix Parameter is a DerivedParameter that is recomputed out of place"""
+    model = P.mock_model()
+    s = P.Parameter(model, val=2.0)
+    M = P.Parameter(model, val=np.eye(2))
+    prod = P.lazy("*", s, M)
+    assert np.array_equal(prod(), 2.0 * np.eye(2))
