@@ -176,12 +176,61 @@ stage_upload!(plan::Plan, staging::DevPtr, src::Array) =
 stage_upload_matrix!(plan::Plan, staging::DevPtr, ldd, A::Matrix{Float64}) =
     check(ccall((:pmt_plan_stage_upload_2d, lib), Cint, (Ptr{Cvoid}, DevPtr, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
                 plan.handle, staging, 8 * ldd, A, 8 * size(A, 1), 8 * size(A, 1), size(A, 2)))
+"the same from a FLAT page-locked vector holding the rows x cols value column-major (the staging copy of a Parameter value)"
+stage_upload_pitched!(plan::Plan, staging::DevPtr, ldd, src::Vector{Float64}, rows, cols) =
+    check(ccall((:pmt_plan_stage_upload_2d, lib), Cint, (Ptr{Cvoid}, DevPtr, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t),
+                plan.handle, staging, 8 * ldd, src, 8 * rows, 8 * rows, cols))
 commit_staged!(plan::Plan, dst::DevPtr, staging::DevPtr, bytes) =
     check(ccall((:pmt_plan_commit_staged, lib), Cint, (Ptr{Cvoid}, DevPtr, DevPtr, Csize_t), plan.handle, dst, staging, bytes))
 staging_consumed!(plan::Plan) = check(ccall((:pmt_plan_staging_consumed, lib), Cint, (Ptr{Cvoid},), plan.handle))
 staged_synchronize(plan::Plan) = check(ccall((:pmt_plan_staged_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
 "staging slot (0 / 1) of the calls above; alternate it (and the staging buffers) per update so the next copy does not wait for this update's commits"
 stage_slot!(plan::Plan, slot::Integer) = check(ccall((:pmt_plan_stage_slot, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, slot))
+
+"plan stream: wait for the staged uploads of the current slot (then commit / consume them)"
+wait_staged!(plan::Plan) = check(ccall((:pmt_plan_wait_staged, lib), Cint, (Ptr{Cvoid},), plan.handle))
+
+# ---- page-locked host memory: the staging buffers of host-updated Parameters and the arrays a HOST solver is handed
+"a Vector{Float64} over page-locked memory (pmt_host_alloc); free with host_free — NOT garbage collected, the device copies into it asynchronously"
+function host_alloc(n::Integer)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmt_host_alloc, lib), Cint, (Csize_t, Ref{Ptr{Cvoid}}), 8 * max(n, 1), ref))
+    unsafe_wrap(Array, Ptr{Float64}(ref[]), n; own = false)
+end
+host_free(v::Vector{Float64}) = check(ccall((:pmt_host_free, lib), Cint, (Ptr{Cvoid},), pointer(v)))
+
+# ---- delivery to a HOST solver while the re-evaluation runs (include/parametron_hip.h: pmt_plan_record_fetch, pmt_quad_gram_csc_deliver_f64)
+"while recording: `dst` (page-locked) receives `bytes` from `src` on the plan's fetch path as soon as what was recorded before it on its lane is done"
+record_fetch!(plan::Plan, dst::Array, src::DevPtr, bytes::Integer = sizeof(dst)) =
+    check(ccall((:pmt_plan_record_fetch, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Csize_t), plan.handle, dst, src, bytes))
+"host: every recorded fetch / delivered band group of the last update has landed"
+fetch_synchronize(plan::Plan) = check(ccall((:pmt_plan_fetch_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
+"pitched device -> host copy on the plan's stream: the columns of a padded device matrix into a dense host column range (setup / serial path)"
+fetch_matrix!(plan::Plan, dst::Ptr{Float64}, dst_pitch_bytes, src::DevPtr, lds, rows, cols) =
+    check(ccall((:pmt_plan_fetch_2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, DevPtr, Csize_t, Csize_t, Csize_t),
+                plan.handle, dst, dst_pitch_bytes, src, 8 * lds, 8 * rows, cols))
+"the Gram node with P's CSC values DELIVERED band group by band group into the page-locked `host_P` while the contraction runs"
+quad_gram_csc_deliver!(out_P_values, host_P::Vector{Float64}, out_lin, out_const, A, lda, rows, cols, xvar, b, sign, varmap, alpha, workspace, stream; ngroups::Integer = 0) =
+    check(ccall((:pmt_quad_gram_csc_deliver_f64, lib), Cint,
+                (DevPtr, Int64, Int64, Int64, DevPtr, DevPtr, Cint, DevPtr, Cdouble, DevPtr, Ptr{Cvoid}, Cint, DevPtr, DevPtr, DevPtr, Ptr{Cvoid}),
+                A, lda, rows, cols, xvar, b, sign, varmap, alpha, out_P_values, host_P, ngroups, out_lin, out_const, workspace, stream))
+
+# ---- further builders used by ParametronHIPBackend.jl
+"x (+|-) v for x::Vector{Variable} (bounds): one term per row; native and/or MOI output may be C_NULL — src/functions.jl:421,751-764"
+vars_addsub!(out_lt::DevPtr, out_vat::DevPtr, out_consts::DevPtr, xvar::DevPtr, n, v::DevPtr, sign, varmap::DevPtr, row_offset, stream) =
+    check(ccall((:pmt_vars_addsub_f64, lib), Cint, (DevPtr, Int64, DevPtr, Cint, DevPtr, Int64, DevPtr, DevPtr, DevPtr, Ptr{Cvoid}),
+                xvar, n, v, sign, varmap, row_offset, out_lt, out_vat, out_consts, stream))
+"dest[i] = s * y[i] for a device scalar s: scale!(dest, x::Number, y::Vector{AffineFunction}) — src/functions.jl:895-915"
+affvec_scale!(out_terms::DevPtr, out_consts::DevPtr, rows, nterms, y_terms::DevPtr, y_consts::DevPtr, s_dev::DevPtr, stream) =
+    check(ccall((:pmt_affvec_scale_f64, lib), Cint, (Int64, Int64, DevPtr, DevPtr, DevPtr, Cdouble, DevPtr, DevPtr, Ptr{Cvoid}),
+                rows, nterms, y_terms, y_consts, s_dev, 0.0, out_terms, out_consts, stream))
+"update!(::MOI.VectorAffineFunction, fs, varmap) of a materialised Vector{AffineFunction} with uniform rows — src/moi_interop.jl:64-81"
+pack_vector_affine!(out_terms::DevPtr, terms::DevPtr, rows, row_len, varmap::DevPtr, row_offset, stream) =
+    check(ccall((:pmt_pack_vector_affine_f64, lib), Cint, (DevPtr, DevPtr, Int64, Int64, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
+                terms, C_NULL, rows, row_len, varmap, row_offset, out_terms, stream))
+"device-to-device copy on the stream (vcat! pieces of constants)"
+copy_bytes!(dst::DevPtr, src::DevPtr, bytes, stream) =
+    check(ccall((:pmt_copy_bytes, lib), Cint, (DevPtr, DevPtr, Csize_t, Ptr{Cvoid}), dst, src, bytes, stream))
 
 # ---- batched independent models across GPUs (BASELINE config 4): the library's own RCCL communicator
 "rank 0: a fresh 128-byte id; carry it to the other ranks with whatever launcher is at hand (MPI.jl, Distributed, a file)"

@@ -14,8 +14,23 @@
 #     vecsubtract!/vecadd!(dest, <that>, b::Parameter)  -> DenseAffine(A, x, b, -1|+1), kept implicit
 #     vecdot!(dest, r, r) / matvecmul!(dest::QuadraticFunction, r', r)   -> least-squares objective of a DenseAffine
 #     copyto!/convert wrappers                          -> looked through
+#     vecsubtract!/vecadd!(dest, x::Vector{Variable}, l::Parameter)     -> bounds rows `x - l` (test/model.jl:162-163)
+#     scale!(dest, s::Parameter{<:Number}, <DenseAffine>)               -> the affine block times a scalar Parameter (:284-290)
+#     vcat!(dest, <DenseAffine | bounds>...)                            -> one MOI function, the pieces stacked (:276-278)
+#     bilinearmul!(dest, Q, x', y)                                      -> transpose(x) * Q * y objectives (:219-226)
 # Anything else makes `HIPModel` keep the reference's own CPU `update!` for that record (it says so once): the device path is an
 # accelerator for the shapes it knows, never a silent approximation.
+#
+# Zero allocation in steady state, as the reference promises (`@allocated solve!(model) == 0`, README.md:8,138, test/model.jl:116-124):
+# update! below touches preallocated buffers only — Parameter values are copied into PAGE-LOCKED staging arrays (pmt_host_alloc) and
+# travel on the plan's copy stream (two slots, pmt_plan_stage_upload[_2d]) while the previous re-evaluation is still running; the scalar
+# the objective's constant is fetched into lives in the record.  tests/test_cabi_exports.py scans `refresh!` / `update!` / `solve!` for
+# allocating constructors.
+#
+# `HIPModel(model; handoff = :host_csc, solver_update = f)`: instead of 252 MB of MOI terms (config 2) the HOST solver is handed what its
+# own update takes — P's and A's CSC values, q, l, u (84 MB) in page-locked arrays that are filled WHILE the contraction runs (recorded
+# fetches + pmt_quad_gram_csc_deliver_f64): `f(Px, Ax, q, l, u)` is e.g. `(a...) -> OSQP.update!(osqp; Px = a[1], Ax = a[2], q = a[3],
+# l = a[4], u = a[5])`.  5.9 -> 1.96 ms per solve! through the Python host of this repository (DESIGN.md §8).
 #
 # NOT EXECUTED in this repository's CI (no julia in the build image; tests/test_gpu_julia.py runs julia/example1_parity.jl when a julia
 # binary is present on the GPU box).  tests/test_cabi_exports.py checks every ccall of julia/*.jl against include/parametron_hip.h —
@@ -42,8 +57,10 @@ mutable struct DeviceParameter
     param::Parameter
     buf::DevPtr
     rows::Int
-    cols::Int            # 0 for vectors
+    cols::Int            # 0 for vectors, -1 for scalars
     ld::Int              # leading dimension of the device copy (rows rounded up to 16, + 64 when a multiple of 512: DESIGN.md §2)
+    host::Vector{Float64}             # page-locked staging copy of the value (dense, column-major): the asynchronous upload reads it
+    staging::NTuple{2, DevPtr}        # one device staging buffer per slot (pmt_plan_stage_slot)
 end
 
 padded_rows(r) = r >= 64 ? 16 * cld(r, 16) : r
@@ -54,23 +71,39 @@ function DeviceParameter(plan::H.Plan, p::Parameter)
     if val isa AbstractMatrix
         r, c = size(val)
         ld = padded_ld(r)
-        buf = H.alloc(plan, 8 * ld * max(c, 1))            # zero filled: the padding rows stay zero
-        return DeviceParameter(p, buf, r, c, ld)
+        bytes = 8 * ld * max(c, 1)
+        return DeviceParameter(p, H.alloc(plan, bytes), r, c, ld, H.host_alloc(r * c), (H.alloc(plan, bytes), H.alloc(plan, bytes)))     # zero filled: the padding rows stay zero
     elseif val isa AbstractVector
         r = length(val)
-        return DeviceParameter(p, H.alloc(plan, 8 * max(padded_rows(r), 1)), r, 0, padded_rows(r))
+        bytes = 8 * max(padded_rows(r), 1)
+        return DeviceParameter(p, H.alloc(plan, bytes), r, 0, padded_rows(r), H.host_alloc(r), (H.alloc(plan, bytes), H.alloc(plan, bytes)))
+    elseif val isa Number
+        return DeviceParameter(p, H.alloc(plan, 8), 1, -1, 1, H.host_alloc(1), (H.alloc(plan, 8), H.alloc(plan, 8)))
     end
     throw(ArgumentError("Parameters of type $(typeof(val)) are not supported on the device"))
 end
 
-"evaluate the Parameter (runs its update function if dirty, src/parameter.jl:93-99) and upload the value"
-function refresh!(plan::H.Plan, d::DeviceParameter)
+"""evaluate the Parameter (runs its update function if dirty, src/parameter.jl:93-99), copy the value into its page-locked staging array
+(`copyto!`: no allocation, whatever array type the user's callback fills) and start the upload on the plan's COPY stream into staging slot
+`slot`; `commit!` consumes it on the plan's stream"""
+function refresh!(plan::H.Plan, d::DeviceParameter, slot::Int)
     val = d.param()
     if d.cols > 0
-        H.upload_matrix!(plan, d.buf, d.ld, Matrix{Float64}(val))
+        copyto!(d.host, val)
+        H.stage_upload_pitched!(plan, d.staging[slot + 1], d.ld, d.host, d.rows, d.cols)
+    elseif d.cols == 0
+        copyto!(d.host, val)
+        H.stage_upload!(plan, d.staging[slot + 1], d.host)
     else
-        H.upload!(plan, d.buf, Vector{Float64}(val))
+        d.host[1] = val
+        H.stage_upload!(plan, d.staging[slot + 1], d.host)
     end
+    nothing
+end
+
+function commit!(plan::H.Plan, d::DeviceParameter, slot::Int)
+    H.commit_staged!(plan, d.buf, d.staging[slot + 1], d.cols > 0 ? 8 * d.ld * d.cols : 8 * max(d.ld, 1))
+    nothing
 end
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -127,6 +160,58 @@ function analyse_affine(arg)::DenseAffine
     throw(Unsupported("builder $(e.f)"))
 end
 
+"x (+|-) l for x::Vector{Variable} and a vector Parameter l: one term (1.0, x[i]) per row (src/lazyexpression.jl:249-258 -> vecsubtract!, src/functions.jl:421)"
+struct VarBounds
+    x::Vector{Variable}
+    l::Parameter
+    sign::Int
+end
+
+"s * (A*x (+|-) b) for a scalar Parameter s: scale!(dest, s, y) (src/lazyexpression.jl:284-290, src/functions.jl:895-915)"
+struct ScaledAffine
+    s::Parameter
+    inner::DenseAffine
+end
+
+"one piece of a constraint function: what `analyse_piece` understands"
+const Piece = Union{DenseAffine, VarBounds, ScaledAffine}
+
+function analyse_piece(arg)::Piece
+    e = unwrap(arg)
+    e isa LazyExpression || throw(Unsupported("affine operand $(typeof(e))"))
+    if (e.f === Functions.vecsubtract! || e.f === Functions.vecadd!) && length(e.args) == 3 && e.args[2] isa Vector{Variable} && e.args[3] isa Parameter
+        return VarBounds(e.args[2], e.args[3], e.f === Functions.vecsubtract! ? -1 : 1)
+    elseif e.f === Functions.scale! && length(e.args) == 3 && e.args[2] isa Parameter && e.args[2]() isa Number
+        return ScaledAffine(e.args[2], analyse_affine(e.args[3]))
+    end
+    analyse_affine(e)
+end
+
+"the pieces of a constraint expression: vcat!(dest, pieces...) (src/lazyexpression.jl:276-278, src/functions.jl:969-994) or a single piece"
+function analyse_pieces(arg)::Vector{Piece}
+    e = unwrap(arg)
+    if e isa LazyExpression && e.f === Functions.vcat! && length(e.args) >= 2
+        return Piece[analyse_piece(a) for a in e.args[2:end]]
+    end
+    Piece[analyse_piece(e)]
+end
+
+"transpose(x) * Q * y (src/lazyexpression.jl:219-226): bilinearmul!(dest, Q, x', y) with Q a matrix Parameter"
+struct Bilinear
+    Q::Parameter
+    x::Vector{Variable}
+    y::Vector{Variable}
+end
+
+function analyse_bilinear(expr)::Bilinear
+    e = unwrap(expr)
+    (e isa LazyExpression && e.f === Functions.bilinearmul! && length(e.args) == 4 && e.args[2] isa Parameter) || throw(Unsupported("not a bilinear objective"))
+    xt, y = e.args[3], e.args[4]
+    x = xt isa Union{Transpose, Adjoint} ? parent(xt) : throw(Unsupported("bilinearmul! without a transposed left vector"))
+    (x isa Vector{Variable} && y isa Vector{Variable}) || throw(Unsupported("bilinearmul! of non-Variable vectors"))
+    Bilinear(e.args[2], x, y)
+end
+
 "residual ⋅ residual (vecdot!, src/lazyexpression.jl:228-232) or residual' * residual (matvecmul! into a QuadraticFunction, src/functions.jl:824-829)"
 function analyse_lsq(expr)::DenseAffine
     e = unwrap(expr)
@@ -147,13 +232,15 @@ end
 # ---------------------------------------------------------------------------------------------------------------------------
 # device records (↔ Objective / Constraint, src/moi_interop.jl:113-175)
 
-struct HIPObjective
+mutable struct HIPObjective
     objective              # the reference's Objective (its .f is the host MOI function the optimizer is given)
-    quad::DevPtr           # MOI.ScalarQuadraticTerm[] on the device
+    quad::DevPtr           # MOI.ScalarQuadraticTerm[] on the device (C_NULL in the host_csc hand-off: P's CSC values instead)
     lin::DevPtr            # MOI.ScalarAffineTerm[]
     constant::DevPtr       # Float64[1]
     nquad::Int
     nlin::Int
+    cbuf::Vector{Float64}  # where the constant is fetched to: preallocated (update! allocates nothing)
+    P_values::DevPtr       # host_csc: alpha * P in CSC order, upper triangle
 end
 
 struct HIPConstraint
@@ -162,7 +249,21 @@ struct HIPConstraint
     constants::DevPtr      # Float64[rows]
     nterms::Int
     rows::Int
+    dense::Union{Nothing, Tuple{DevPtr, Int, Int, Int}}     # (C buffer, lda, rows, cols) when the function is ONE unscaled dense block
 end
+
+"what a host solver's update takes, in page-locked arrays the device fills (handoff = :host_csc)"
+mutable struct HostQP
+    Px::Vector{Float64}    # P, upper triangle, CSC values (structure: column k holds rows 1..k of the variables in index order)
+    Ax::Vector{Float64}    # A, CSC values, the constraint blocks stacked in the reference's update order
+    small::Vector{Float64} # q | l | u, one transfer
+    n::Int
+    m::Int
+    small_dev::DevPtr
+end
+q_of(h::HostQP) = view(h.small, 1:h.n)
+l_of(h::HostQP) = view(h.small, h.n + 1:h.n + h.m)
+u_of(h::HostQP) = view(h.small, h.n + h.m + 1:h.n + 2 * h.m)
 
 mutable struct HIPModel
     model::Model
@@ -173,6 +274,10 @@ mutable struct HIPModel
     constraints::Vector{HIPConstraint}
     cpu_records::Vector{Any}          # records that stay on the reference's own update! (unsupported shapes, constant expressions)
     literal_limit::Int                # literal (uncombined) objective up to this many quadratic terms, canonical beyond (DESIGN.md §3)
+    slot::Int                         # staging slot of the next update (alternates: the copy of update k+1 does not wait for update k's commits)
+    handoff::Symbol                   # :moi (the reference's boundary) or :host_csc
+    host::Union{Nothing, HostQP}
+    solver_update::Any                # f(Px, Ax, q, l, u), called by update! in the host_csc hand-off
 end
 
 function device_param!(hm::HIPModel, p::Parameter)
@@ -201,11 +306,34 @@ function operand!(hm::HIPModel, da::DenseAffine, rec)
     t, ld, rows, cols
 end
 
+identity_map(hm::HIPModel, x::Vector{Variable}) = all(i -> hm.model.model_var_to_optimizer[x[i].index].value == i, eachindex(x)) && length(x) == length(hm.model.model_var_to_optimizer)
+
 function record_objective!(hm::HIPModel, objective, rec)
+    sense_sign = hm.model.backend.sense == MOI.MAX_SENSE ? -1.0 : 1.0          # a host QP solver minimises (DESIGN.md §8)
+    bil = try analyse_bilinear(objective.expr) catch err; err isa Unsupported ? nothing : rethrow() end
+    if bil !== nothing
+        # transpose(x) * Q * y: quad[k] = (Q[k], x[(k-1) ÷ n + 1], y[(k-1) mod n + 1]) in column-major order of Q (src/functions.jl:840-858)
+        hm.handoff === :host_csc && throw(Unsupported("bilinear objective in the host_csc hand-off"))
+        d = device_param!(hm, bil.Q)
+        xv = upload_indices(hm.plan, Int64[v.index for v in bil.x]); yv = upload_indices(hm.plan, Int64[v.index for v in bil.y])
+        nq = d.rows * d.cols
+        quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16), H.alloc(hm.plan, 8)
+        H.bilinear!(quad, d.buf, d.ld, d.rows, d.cols, xv, yv, 1, hm.varmap, rec)
+        return HIPObjective(objective, quad, lin, constant, nq, 0, zeros(1), DevPtr(C_NULL))
+    end
     da = analyse_lsq(objective.expr)
     A, lda, r, n = operand!(hm, da, rec)
     xvar = upload_indices(hm.plan, Int64[v.index for v in da.x])
     b = da.b === nothing ? DevPtr(C_NULL) : device_param!(hm, da.b).buf
+    if hm.handoff === :host_csc
+        identity_map(hm, da.x) || throw(Unsupported("host_csc hand-off needs the optimizer to keep the variable order"))
+        nq = div(n * (n + 1), 2)
+        Pv, lin, constant = H.alloc(hm.plan, 8 * nq), H.alloc(hm.plan, 16 * n), H.alloc(hm.plan, 8)
+        ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(r, n))
+        hm.host.Px = H.host_alloc(nq)
+        H.quad_gram_csc_deliver!(Pv, hm.host.Px, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, hm.varmap, sense_sign, ws, rec)
+        return HIPObjective(objective, DevPtr(C_NULL), lin, constant, 0, n, zeros(1), Pv)
+    end
     if r * n * n <= hm.literal_limit
         # literal: the reference's term order and coefficients bit for bit (src/functions.jl:702-709 over :548-576, moi_interop.jl:45-62)
         nq, nl = r * n * n, 2 * r * n
@@ -213,29 +341,67 @@ function record_objective!(hm::HIPModel, objective, rec)
         quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * nl), H.alloc(hm.plan, 8)
         H.affine_assemble!(res, resc, A, lda, r, n, xvar, b, da.sign, rec)
         H.quad_expand!(quad, lin, constant, r, res, n, resc, res, n, resc, 1, hm.varmap, rec)
-        return HIPObjective(objective, quad, lin, constant, nq, nl)
+        return HIPObjective(objective, quad, lin, constant, nq, nl, zeros(1), DevPtr(C_NULL))
     end
     issorted([v.index for v in da.x], lt = <=) || throw(Unsupported("canonical objective needs strictly increasing variables"))
     nq = div(n * (n + 1), 2)
     quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * n), H.alloc(hm.plan, 8)
     ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(r, n))
     H.quad_gram!(quad, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, 1, hm.varmap, ws, rec)
-    HIPObjective(objective, quad, lin, constant, nq, n)
+    HIPObjective(objective, quad, lin, constant, nq, n, zeros(1), DevPtr(C_NULL))
+end
+
+piece_rows(hm::HIPModel, p::DenseAffine) = (d = device_param!(hm, p.A); p.transposed ? d.cols : d.rows)
+piece_rows(hm::HIPModel, p::VarBounds) = length(p.x)
+piece_rows(hm::HIPModel, p::ScaledAffine) = piece_rows(hm, p.inner)
+piece_terms(hm::HIPModel, p::DenseAffine) = (d = device_param!(hm, p.A); d.rows * d.cols)
+piece_terms(hm::HIPModel, p::VarBounds) = length(p.x)
+piece_terms(hm::HIPModel, p::ScaledAffine) = piece_terms(hm, p.inner)
+
+"one piece of a constraint function -> MOI.VectorAffineTerms at term offset `t0`, rows from `row0` (vcat!: the pieces are stacked)"
+function record_piece!(hm::HIPModel, p::DenseAffine, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
+    A, lda, r, n = operand!(hm, p, rec)
+    xvar = upload_indices(hm.plan, Int64[v.index for v in p.x])
+    b = p.b === nothing ? DevPtr(C_NULL) : device_param!(hm, p.b).buf
+    H.affine_pack_vector!(terms + 24 * t0, constants + 8 * row0, A, lda, r, n, xvar, b, p.sign, hm.varmap, row0, rec)
+end
+function record_piece!(hm::HIPModel, p::VarBounds, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
+    xvar = upload_indices(hm.plan, Int64[v.index for v in p.x])
+    H.vars_addsub!(DevPtr(C_NULL), terms + 24 * t0, constants + 8 * row0, xvar, length(p.x), device_param!(hm, p.l).buf, p.sign, hm.varmap, row0, rec)
+end
+function record_piece!(hm::HIPModel, p::ScaledAffine, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
+    # the native block, scaled by the device scalar, then the MOI copy (scale! works on materialised terms: src/functions.jl:895-915)
+    A, lda, r, n = operand!(hm, p.inner, rec)
+    xvar = upload_indices(hm.plan, Int64[v.index for v in p.inner.x])
+    b = p.inner.b === nothing ? DevPtr(C_NULL) : device_param!(hm, p.inner.b).buf
+    res, resc, sc = H.alloc(hm.plan, 16 * r * n), H.alloc(hm.plan, 8 * r), H.alloc(hm.plan, 16 * r * n)
+    H.affine_assemble!(res, resc, A, lda, r, n, xvar, b, p.inner.sign, rec)
+    H.affvec_scale!(sc, constants + 8 * row0, r, r * n, res, resc, device_param!(hm, p.s).buf, rec)
+    H.pack_vector_affine!(terms + 24 * t0, sc, r, n, hm.varmap, row0, rec)
 end
 
 function record_constraint!(hm::HIPModel, constraint, rec)
-    da = analyse_affine(constraint.expr)
-    A, lda, r, n = operand!(hm, da, rec)
-    xvar = upload_indices(hm.plan, Int64[v.index for v in da.x])
-    b = da.b === nothing ? DevPtr(C_NULL) : device_param!(hm, da.b).buf
-    terms, constants = H.alloc(hm.plan, 24 * r * n), H.alloc(hm.plan, 8 * max(r, 1))
-    # A constraint that reads Parameter values only (no transposition recorded on the tape for it) is independent of every other record
-    # (update! of one Constraint, src/moi_interop.jl:168-175): beside a canonical least-squares objective it goes to the plan's side lane
-    side = !da.transposed && hm.objective !== nothing && hm.objective.nquad == div(n * (n + 1), 2) && hm.objective.nlin == n
+    pieces = analyse_pieces(constraint.expr)
+    rows = sum(p -> piece_rows(hm, p), pieces)
+    nterms = sum(p -> piece_terms(hm, p), pieces)
+    terms, constants = H.alloc(hm.plan, 24 * max(nterms, 1)), H.alloc(hm.plan, 8 * max(rows, 1))
+    # A constraint that reads Parameter values only (no node of the tape feeds it) is independent of every other record (update! of one
+    # Constraint, src/moi_interop.jl:168-175): beside a canonical least-squares objective it goes to the plan's side lane
+    independent = all(p -> !(p isa DenseAffine && p.transposed) && !(p isa ScaledAffine), pieces)
+    side = independent && hm.objective !== nothing && hm.objective.nlin > 0 && (hm.objective.nquad == 0 || hm.objective.nquad == div(hm.objective.nlin * (hm.objective.nlin + 1), 2))
     side && H.set_lane!(hm.plan, 1)
-    H.affine_pack_vector!(terms, constants, A, lda, r, n, xvar, b, da.sign, hm.varmap, 0, rec)
+    t0 = 0; row0 = 0
+    for p in pieces
+        record_piece!(hm, p, terms, constants, t0, row0, rec)
+        t0 += piece_terms(hm, p); row0 += piece_rows(hm, p)
+    end
     side && H.set_lane!(hm.plan, 0)
-    HIPConstraint(constraint, terms, constants, r * n, r)
+    dense = nothing
+    if length(pieces) == 1 && pieces[1] isa DenseAffine && !pieces[1].transposed
+        d = device_param!(hm, pieces[1].A)
+        dense = (d.buf, d.ld, d.rows, d.cols)
+    end
+    HIPConstraint(constraint, terms, constants, nterms, rows, dense)
 end
 
 "all Constraint records of the model in the reference's update order (the fields of Parametron.Constraints, src/moi_interop.jl:195-262)"
@@ -248,12 +414,54 @@ function constraint_records(model::Model)
     out
 end
 
-function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 << 24)
+set_kind(::MOI.Zeros) = 0
+set_kind(::MOI.Nonnegatives) = 1
+set_kind(::MOI.Nonpositives) = 2
+
+"""host_csc: q, l, u on the device (one block) and the recorded fetches.  A's CSC values ARE the dense blocks' Parameter values column by
+column (stacked), so they leave as pitched copies of the Parameter buffers — no kernel at all; q is the coefficient field of the objective's
+affine terms, l / u come from the constraint constants and the cone (pmt_qp_bounds_f64)."""
+function record_host_handoff!(hm::HIPModel, rec)
+    h = hm.host
+    n, m = h.n, h.m
+    h.small = H.host_alloc(n + 2 * m)
+    h.small_dev = H.alloc(hm.plan, 8 * (n + 2 * m))
+    h.Ax = H.host_alloc(n * m)
+    o = hm.objective
+    ident = upload_indices(hm.plan, Int64[i - 1 for i in 1:n])
+    seg = upload_indices(hm.plan, Int64[i - 1 for i in 1:n + 1])
+    H.set_lane!(hm.plan, 1)                         # behind the Gram node's affine part on the side stream (plan.hip `replay`)
+    H.csc_values!(h.small_dev, o.lin, 16, n, ident, seg, n, hm.model.backend.sense == MOI.MAX_SENSE ? -1.0 : 1.0, DevPtr(C_NULL), rec)
+    row0 = 0
+    for c in hm.constraints
+        H.qp_bounds!(h.small_dev + 8 * (n + row0), h.small_dev + 8 * (n + m + row0), c.constants, c.rows, set_kind(c.constraint.set), 0.0, 1e20, rec)
+        row0 += c.rows
+    end
+    H.record_fetch!(hm.plan, h.small, h.small_dev)
+    H.set_lane!(hm.plan, 0)
+    nothing
+end
+
+"A's values in the serial part of update!: one pitched copy per dense block straight out of its Parameter buffer (column j of A = the blocks' columns j, stacked)"
+function fetch_A!(hm::HIPModel)
+    h = hm.host
+    row0 = 0
+    for c in hm.constraints
+        buf, lda, r, n = c.dense
+        H.fetch_matrix!(hm.plan, pointer(h.Ax) + 8 * row0, 8 * h.m, buf, lda, r, n)
+        row0 += r
+    end
+    nothing
+end
+
+function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 << 24, handoff::Symbol = :moi, solver_update = nothing)
+    handoff in (:moi, :host_csc) || throw(ArgumentError("handoff must be :moi or :host_csc"))
     model.initialized || Parametron.initialize!(model)              # copy_to + mapindices! first: the index map is then final (src/model.jl:117-122)
     plan = H.Plan(device)
     nvars = length(model.model_var_to_optimizer)
     varmap = upload_indices(plan, Int64[vi.value for vi in model.model_var_to_optimizer])          # src/model.jl:100-107
-    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit)
+    host = handoff === :host_csc ? HostQP(Float64[], Float64[], Float64[], nvars, 0, DevPtr(C_NULL)) : nothing
+    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit, 0, handoff, host, solver_update)
     rec = H.recording_stream(plan)
     H.begin_record!(plan)
     try
@@ -265,6 +473,7 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
                 hm.objective = record_objective!(hm, obj, rec)
             catch err
                 err isa Unsupported || rethrow()
+                handoff === :host_csc && rethrow()                   # the host_csc hand-off has no CPU fallback for a record: say so
                 @info "ParametronHIP: the objective stays on the CPU path" reason = err.what
                 push!(hm.cpu_records, obj)
             end
@@ -275,9 +484,16 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
                 push!(hm.constraints, record_constraint!(hm, c, rec))
             catch err
                 err isa Unsupported || rethrow()
+                handoff === :host_csc && rethrow()
                 @info "ParametronHIP: a constraint stays on the CPU path" reason = err.what
                 push!(hm.cpu_records, c)
             end
+        end
+        if handoff === :host_csc
+            (hm.objective !== nothing && all(c -> c.dense !== nothing, hm.constraints)) ||
+                throw(ArgumentError("the host_csc hand-off covers a least-squares objective and unscaled dense constraint blocks"))
+            host.m = sum(c -> c.rows, hm.constraints; init = 0)
+            record_host_handoff!(hm, rec)
         end
     finally
         H.end_record!(plan)
@@ -291,14 +507,13 @@ end
 "update!(objective, optimizer, varmap) of src/moi_interop.jl:131-137 with the builders and the MOI copy done on the device"
 function Parametron.update!(o::HIPObjective, hm::HIPModel, optimizer)
     f = o.objective.f
-    resize!(f.quadratic_terms, o.nquad)                              # in place, as the reference does (:48,53)
+    resize!(f.quadratic_terms, o.nquad)                              # in place, as the reference does (:48,53): no-ops after the first solve
     resize!(f.affine_terms, o.nlin)
     H.fetch!(hm.plan, f.quadratic_terms, o.quad)
     H.fetch!(hm.plan, f.affine_terms, o.lin)
-    c = Vector{Float64}(undef, 1)
-    H.fetch!(hm.plan, c, o.constant)
+    H.fetch!(hm.plan, o.cbuf, o.constant)
     H.synchronize(hm.plan)
-    f.constant = c[1]
+    f.constant = o.cbuf[1]
     MOI.set(optimizer, MOI.ObjectiveFunction{typeof(f)}(), f)
     nothing
 end
@@ -315,14 +530,30 @@ function Parametron.update!(c::HIPConstraint, hm::HIPModel, optimizer)
     nothing
 end
 
-"update!(m::Model) of src/model.jl:132-143: setdirty!, Parameters, one tape replay, then the MOI hand-off record by record"
+"""update!(m::Model) of src/model.jl:132-143: setdirty!, Parameters, one tape replay, then the hand-off.  Nothing below allocates: the
+Parameter values go through their page-locked staging arrays onto the copy stream, the commits and the tape onto the plan's stream."""
 function Parametron.update!(hm::HIPModel)
     m = hm.model
     setdirty!(m)
+    slot = hm.slot
+    hm.slot = 1 - slot
+    H.stage_slot!(hm.plan, slot)
     for d in hm.params
-        refresh!(hm.plan, d)                                         # runs the user's callback once (dirty flag) and uploads
+        refresh!(hm.plan, d, slot)                                   # runs the user's callback once (dirty flag) and starts the upload
     end
-    H.update!(hm.plan)                                               # every device node of the model
+    for d in hm.params
+        commit!(hm.plan, d, slot)                                    # plan stream: staging -> the buffer the kernels read
+    end
+    H.staging_consumed!(hm.plan)
+    H.update!(hm.plan)                                               # every device node of the model (+ the recorded fetches / the delivery of P)
+    if hm.handoff === :host_csc
+        h = hm.host
+        fetch_A!(hm)                                                 # pitched copies out of the Parameter buffers, behind the commits
+        H.fetch_synchronize(hm.plan)                                 # q | l | u and P's band groups have landed
+        H.synchronize(hm.plan)
+        hm.solver_update === nothing || hm.solver_update(h.Px, h.Ax, q_of(h), l_of(h), u_of(h))
+        return nothing
+    end
     hm.objective === nothing || Parametron.update!(hm.objective, hm, m.optimizer)
     for c in hm.constraints
         Parametron.update!(c, hm, m.optimizer)

@@ -43,6 +43,9 @@
 #ifndef PMT_SK_ORDER
 #define PMT_SK_ORDER 0
 #endif
+#ifndef PMT_SK_BK
+#define PMT_SK_BK 16          // rows per stage (one barrier per stage)
+#endif
 #ifndef PMT_SK_WPS
 #define PMT_SK_WPS 2          // __launch_bounds__ waves-per-SIMD hint of the shipped instantiation
 #endif
@@ -616,8 +619,8 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #else
     // Two instantiations that differ only in the per-tile progress count of a host delivery.  (The 32-row-stage instantiation used for
     // tall matrices in rounds 1-2 spilled 49 VGPRs — +1 % at r = 16384 when it was introduced — and is gone: all shapes take 16-row stages.)
-    if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0, true>), grid, dim3(Cfg<2>::NT), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, 16, PMT_SK_WPS, 0, false>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, PMT_SK_BK, PMT_SK_WPS, 0, true>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, PMT_SK_BK, PMT_SK_WPS, 0, false>), grid, dim3(Cfg<2>::NT), 0, s, g);
 #endif
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
@@ -625,7 +628,12 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         // The split tiles are summed by a second launch.  (Round 3 measured the alternative — the workgroup that arrives last at a split tile
         // adds its partials inside the contraction: +55 us at n = r = 4096, one CU pulling 2 MB of partials, against 15 us of fix-up kernel
         // plus ~25 us of in-stream gaps; profiles/r03_gram_fold_experiment.txt.)
-        if (R * (Cfg<2>::NACC / 4) < 64) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+#ifdef PMT_TUNING
+        static const int apb = env_int("PMT_GRAM_SK_FIXUP_APB", 0);
+#else
+        constexpr int apb = 0;
+#endif
+        if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < 64)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }

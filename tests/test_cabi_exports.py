@@ -177,3 +177,31 @@ def test_shipped_library_reads_no_environment_switches():
                     stack.pop()
                 if "getenv(" in line and not t.startswith("//"):
                     assert any(stack), "%s reads the environment outside #ifdef PMT_TUNING: %s" % (src, t)
+
+
+def test_julia_update_path_has_no_allocating_constructors():
+    """The reference promises `@allocated solve!(model) == 0` (README.md:8,138, test/model.jl:116-124).  The Julia backend cannot be run
+    here, so its per-solve functions are scanned for constructs that allocate: array constructors, comprehensions, copies, conversions.
+    (Setup functions — HIPModel, record_*, DeviceParameter — may allocate: they run once.)"""
+    src = open(os.path.join(ROOT, "julia", "ParametronHIPBackend.jl")).read()
+    per_solve = [r"function refresh!\(", r"function commit!\(", r"function fetch_A!\(", r"function Parametron\.update!\(o::HIPObjective",
+                 r"function Parametron\.update!\(c::HIPConstraint", r"function Parametron\.update!\(hm::HIPModel\)", r"function solve!\(hm::HIPModel\)"]
+    banned = [r"\bVector\{[^}]*\}\(", r"\bMatrix\{[^}]*\}\(", r"\bArray\{", r"\bzeros\(", r"\bones\(", r"\bcollect\(", r"\bcopy\(", r"\bsimilar\(",
+              r"\b(?:Int64|Float64|Any)\[", r"\[[^\]\n]*\bfor\b[^\]\n]*\]", r"\bpush!\(", r"\bvcat\(", r"\bhcat\(", r"\bconvert\(", r"\bstring\("]
+    checked = 0
+    for head in per_solve:
+        m = re.search(head, src)
+        assert m, "per-solve function %s not found in the Julia backend" % head
+        body, depth = [], 0
+        for line in src[m.start():].splitlines():
+            code = line.split("#")[0]
+            depth += len(re.findall(r"\b(function|if|for|while|try|let|do|begin)\b", code)) - len(re.findall(r"\bend\b", code))
+            body.append(code)
+            if depth <= 0 and len(body) > 1:
+                break
+        text = "\n".join(body)
+        for pat in banned:
+            hit = re.search(pat, text)
+            assert not hit, "%s allocates in the per-solve path: %r" % (head, hit.group(0))
+        checked += 1
+    assert checked == len(per_solve)
