@@ -62,6 +62,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-configs", action="store_true", help="skip the C3 / C4 / C5 / host-API sections")
     p.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (no per-kernel events)")
+    p.add_argument("--pack-first", action="store_true", help="A/B: record the constraint pack in FRONT of the contraction (same stream)")
     p.add_argument("--side-lane", default="off", choices=["off", "tile", "background"],
                    help="A/B: record config 2's constraint pack on the plan's side lane (Model.initialize does so only when a model has "
                         "several such entries, e.g. config 3 or the device hand-off; for one kernel it does not pay, DESIGN.md section 4)")
@@ -109,7 +110,7 @@ class C2Workload:
 
     n, r, m = 4096, 4096, 512
 
-    def __init__(self, torch, _lib, rank, side_lane=False, background=False):
+    def __init__(self, torch, _lib, rank, side_lane=False, background=False, pack_first=False):
         self.torch, self._lib = torch, _lib
         n, r, m = self.n, self.r, self.m
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -140,13 +141,16 @@ class C2Workload:
         _lib.call("pmt_plan_create", torch.cuda.current_device(), self.stream, C.byref(self.plan))
         rec = C.c_void_p(_lib.load().pmt_plan_recording_stream(self.plan))
         _lib.call("pmt_plan_begin_record", self.plan)
+        if pack_first:
+            _lib.call("pmt_affine_pack_vector_f64", dptr(self.Cm), self.ldc, m, n, dptr(self.xvar), dptr(self.d), -1, dptr(self.varmap), 0, dptr(self.Ct), dptr(self.Cc), rec)
         _lib.call("pmt_quad_gram_f64", dptr(self.A), self.lda, r, n, dptr(self.xvar), dptr(self.b), -1, 1, dptr(self.varmap),
                   dptr(self.Q), dptr(self.q), dptr(self.const), dptr(self.ws), rec)
         # (A/B only: with ONE constraint copy and no hand-off Model.initialize() keeps it on the plan's stream)
         if side_lane:
             _lib.call("pmt_plan_set_lane", self.plan, 1)
-        _lib.call("pmt_affine_pack_vector_background_f64" if (side_lane and background) else "pmt_affine_pack_vector_f64", dptr(self.Cm), self.ldc, m, n, dptr(self.xvar),
-                  dptr(self.d), -1, dptr(self.varmap), 0, dptr(self.Ct), dptr(self.Cc), rec)
+        if not pack_first:
+            _lib.call("pmt_affine_pack_vector_background_f64" if (side_lane and background) else "pmt_affine_pack_vector_f64", dptr(self.Cm), self.ldc, m, n, dptr(self.xvar),
+                      dptr(self.d), -1, dptr(self.varmap), 0, dptr(self.Ct), dptr(self.Cc), rec)
         _lib.call("pmt_plan_end_record", self.plan)
         # setup, not measurement: first touch of every output buffer and code object, and the power-state ramp of the GPU —
         # the first ~20 ms of fp64 matrix work after an idle period run ~10 % slower (profiles/r01c_lda_padding.txt shows the
@@ -561,7 +565,7 @@ def main():
     if args.workload == "batch":
         return run_batch(args, torch, dist, _lib, rank, world)
 
-    wl = C2Workload(torch, _lib, rank, side_lane=args.side_lane != "off", background=args.side_lane == "background")
+    wl = C2Workload(torch, _lib, rank, side_lane=args.side_lane != "off", background=args.side_lane == "background", pack_first=args.pack_first)
     if args.graph:
         _lib.call("pmt_plan_instantiate_graph", wl.plan)
     for _ in range(args.warmup):
