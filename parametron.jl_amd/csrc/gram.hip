@@ -25,6 +25,7 @@
 namespace pmt {
 
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
+void mark_no_graph(void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
@@ -482,6 +483,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         dplan = deliver_plan(rows, cols, ngroups > 0 ? ngroups : 8, DELIVER_ORDER_W, host_csc);
         dplan.host_dev = static_cast<double *>(host_device_pointer(host_csc));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
+        mark_no_graph(stream);
     }
     return dispatch(stream, [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while

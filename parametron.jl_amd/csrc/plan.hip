@@ -54,6 +54,7 @@ struct pmt_plan {
     bool alloc_pending = false;
     // recorded fetches (pmt_plan_record_fetch): one ordering event per entry
     std::vector<hipEvent_t> fetch_events;
+    bool no_graph = false;            // the tape holds an entry whose replay has host-side effects (a host delivery): launches only
 };
 
 namespace pmt {
@@ -98,6 +99,11 @@ int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream) 
 }
 
 bool is_recording_handle(void *stream) { return recording_plan(stream) != nullptr; }
+
+// a recorded call whose replay does more than enqueue work on the stream (arms signals, submits copy-engine transfers) cannot be captured
+void mark_no_graph(void *stream) {
+    if (pmt_plan *plan = recording_plan(stream)) plan->no_graph = true;
+}
 
 int dispatch(void *stream, Launch launch) {
     if (stream) {
@@ -574,7 +580,8 @@ extern "C" int pmt_plan_instantiate_graph(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_instantiate_graph: null plan");
     PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");
     if (plan->graph_exec) return PMT_OK;
-    PMT_REQUIRE(plan->fetch_events.empty(), PMT_STATE_ERROR, "plan_instantiate_graph: a tape with recorded fetches is replayed as launches (its copies leave the capture)");
+    PMT_REQUIRE(plan->fetch_events.empty() && !plan->no_graph, PMT_STATE_ERROR,
+                "plan_instantiate_graph: a tape with recorded fetches or a host delivery is replayed as launches (its copies leave the capture)");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
     int rc = replay(plan, plan->stream);

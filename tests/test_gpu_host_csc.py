@@ -201,3 +201,48 @@ def test_recorded_fetch_c_abi_both_lanes():
     for h in hostp:
         _lib.call("pmt_host_free", h)
     _lib.call("pmt_plan_destroy", plan)
+
+
+def test_delivery_node_in_a_plan_refuses_graph_capture_and_small_shapes_deliver():
+    """a recorded pmt_quad_gram_csc_deliver_f64 arms signals and submits transfers at replay: such a tape is never captured into a hipGraph;
+    replayed as launches it delivers, including shapes of a single tile and of split tiles only"""
+    L = lib()
+    for rows, cols in ((48, 24), (700, 130), (300, 384)):
+        plan = C.c_void_p()
+        _lib.call("pmt_plan_create", 0, None, C.byref(plan))
+        rec = C.c_void_p(L.pmt_plan_recording_stream(plan))
+        nq = cols * (cols + 1) // 2
+        ptrs = {}
+        for name, nbytes in (("A", 8 * rows * cols), ("b", 8 * rows), ("x", 8 * cols), ("P", 8 * nq), ("lin", 16 * cols), ("c", 8),
+                             ("ws", int(L.pmt_quad_gram_workspace_bytes(rows, cols)))):
+            ptrs[name] = C.c_void_p()
+            _lib.call("pmt_plan_alloc", plan, max(nbytes, 16), C.byref(ptrs[name]))
+        xv = np.arange(1, cols + 1, dtype=np.int64)
+        _lib.call("pmt_plan_upload", plan, ptrs["x"], xv.ctypes.data_as(C.c_void_p), xv.nbytes)
+        st = C.c_void_p(L.pmt_plan_stream(plan))
+        _lib.call("pmt_fill_uniform_f64", ptrs["A"], rows * cols, 5, 1.0, st)
+        _lib.call("pmt_fill_uniform_f64", ptrs["b"], rows, 6, 1.0, st)
+        hp = C.c_void_p()
+        _lib.call("pmt_host_alloc", 8 * nq, C.byref(hp))
+        host = np.frombuffer((C.c_char * (8 * nq)).from_address(hp.value), dtype=np.float64)
+        _lib.call("pmt_plan_begin_record", plan)
+        _lib.call("pmt_quad_gram_csc_deliver_f64", ptrs["A"], rows, rows, cols, ptrs["x"], ptrs["b"], -1, None, 1.0, ptrs["P"], hp, 4, ptrs["lin"], ptrs["c"], ptrs["ws"], rec)
+        _lib.call("pmt_plan_end_record", plan)
+        with pytest.raises(P.ErrorException):
+            _lib.call("pmt_plan_instantiate_graph", plan)
+        for rep in range(3):
+            host[:] = np.nan
+            _lib.call("pmt_plan_update", plan)
+            _lib.call("pmt_plan_fetch_synchronize", plan)
+            _lib.call("pmt_plan_synchronize", plan)
+            dev = np.empty(nq)
+            _lib.call("pmt_plan_fetch", plan, dev.ctypes.data_as(C.c_void_p), ptrs["P"], 8 * nq)
+            _lib.call("pmt_plan_synchronize", plan)
+            assert np.array_equal(host, dev)
+        from oracle import oracle as O
+        A = O.fill_uniform(rows * cols, 5).reshape(cols, rows).T
+        ref = 2.0 * (A.T @ A)
+        got = np.concatenate([ref[:k + 1, k] for k in range(cols)])
+        np.testing.assert_allclose(host, got, rtol=1e-12, atol=0)
+        _lib.call("pmt_host_free", hp)
+        _lib.call("pmt_plan_destroy", plan)
