@@ -151,6 +151,9 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
             const double *trow = tile + row * EPITCH + coff;
             const u64 rv = rmap[row];
             auto word = [&](int q) -> u64 {
+#if defined(PMT_SK_EPI_ABL) && PMT_SK_EPI_ABL == 1
+                return (u64)q + rv;                          // ablation: no LDS reads, no selects
+#endif
                 const int t = q / 3, f = q - 3 * t;
                 return f == 0 ? (u64)__double_as_longlong(trow[t]) : (f == 1 ? rv : cmap[coff + t]);
             };
@@ -161,7 +164,11 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
                     u64x2 v;
                     v.x = word(q0);
                     v.y = word(q0 + 1);
+#if defined(PMT_SK_EPI_ABL) && PMT_SK_EPI_ABL == 2
+                    if (v.x == 0x7ff8dead7ff8deadull) seg[q0] = v.y;          // ablation: (practically) no global stores
+#else
                     *reinterpret_cast<u64x2 *>(seg + q0) = v;
+#endif
                 } else {
                     seg[q0] = word(q0);
                 }
