@@ -43,6 +43,12 @@
 #ifndef PMT_SK_ORDER
 #define PMT_SK_ORDER 0
 #endif
+#ifndef PMT_SK_STOREKS
+#define PMT_SK_STOREKS -1      // k-step in front of which the next stage's panels go from registers to LDS (-1: behind the last k-step)
+#endif
+#ifndef PMT_SK_STOREFENCE
+#define PMT_SK_STOREFENCE 0    // 1: a scheduling barrier behind those LDS stores (they may not sink to the end of the stage)
+#endif
 #ifndef PMT_SK_BK
 #define PMT_SK_BK 16          // rows per stage (one barrier per stage)
 #endif
@@ -277,6 +283,13 @@ __device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, 
                 sk_load_panel<TN, BK, FAST>(g, j0, inext, iend, rj, tid);
                 sk_load_panel<TN, BK, FAST>(g, k0, inext, iend, rk, tid);
             }
+            if (PMT_SK_STOREKS >= 0 && ks == PMT_SK_STOREKS && ABL != 2 && (FAST || s + 1 < nstage)) {
+                // the next stage's panels go to LDS HERE, a k-step or two before the barrier: their write latency and the wait for the global
+                // loads are then covered by this stage's remaining MFMAs instead of sitting between the last MFMA and the barrier
+                sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
+                sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
+                if (PMT_SK_STOREFENCE) __builtin_amdgcn_sched_barrier(0);
+            }
             double a[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) a[t] = (ABL == 1) ? (double)(tid + t) : pj[t * 16 * GP + ks * 4];
@@ -311,7 +324,7 @@ __device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, 
 #endif
             }
         }
-        if (ABL != 2 && (FAST || s + 1 < nstage)) {
+        if (PMT_SK_STOREKS < 0 && ABL != 2 && (FAST || s + 1 < nstage)) {
             sk_store_panel<TN, BK>(lds[cur ^ 1][0], rj, tid);
             sk_store_panel<TN, BK>(lds[cur ^ 1][1], rk, tid);
         }
