@@ -429,6 +429,25 @@ def host_api_c2(torch, P, steps):
             out["handoff_" + name]["bytes_to_host"] = nb
             out["handoff_" + name]["pcie_floor_ms"] = nb / 54e9 * 1e3      # 54 GB/s: the page-locked D2H rate of this box (tools/deliver_probe.hip)
         model.close()
+    # config 3 end to end for a host solver: G, h, l, u rewritten by the host before every solve (17 MB up, staged), objective + three constraint
+    # blocks re-evaluated, P / A / q / l / u (84 MB) delivered to the host while the contraction runs
+    model, bufs = workloads.config3(pinned=True, handoff="host_csc")
+    P.solve(model)
+
+    def c3_solve():
+        model.stage_parameters()
+        P.solve(model)
+    for _ in range(5):
+        c3_solve()
+    k = max(3, min(steps, 20))
+    t0 = time.perf_counter()
+    for _ in range(k):
+        c3_solve()
+    dt = (time.perf_counter() - t0) / k
+    model.wait_staged()
+    out["c3_host_csc"] = {"ms_per_solve": dt * 1e3, "solves_per_s": 1.0 / dt, "bytes_to_host": model.device_qp.host.nbytes(),
+                          "what": "config 3 (inequalities + bounds) with host-updated val= Parameters (17 MB staged up) and the host_csc delivery (84 MB down)"}
+    model.close()
     return out
 
 

@@ -246,3 +246,40 @@ def test_delivery_node_in_a_plan_refuses_graph_capture_and_small_shapes_deliver(
         np.testing.assert_allclose(host, got, rtol=1e-12, atol=0)
         _lib.call("pmt_host_free", hp)
         _lib.call("pmt_plan_destroy", plan)
+
+
+def test_host_delivery_with_host_updated_parameters_and_several_constraint_blocks():
+    """config-3 shape at a small size: inequality block + lower / upper bounds, their Parameters host-updated (`val=`) and uploaded through the
+    staging slots, results delivered to the host — the whole loop a host solver sees.  Host arrays == device hand-off, and A, l, u follow the
+    buffers the host rewrote."""
+    n, r, mi = 192, 256, 24
+    rng = np.random.default_rng(11)
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", handoff="host_csc")
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model)
+    b = P.DeviceUniformParameter((r,), 2, model)
+    residual = A * x - b
+    P.objective(model, P.Minimize, P.dot(residual, residual))
+    bufs = {"G": model.parameter_array(mi, n), "h": model.parameter_array(mi), "l": model.parameter_array(n), "u": model.parameter_array(n)}
+    for k, v in bufs.items():
+        v[...] = rng.random(v.shape)
+    G, h, lo, up = (P.Parameter(model, val=bufs[k]) for k in ("G", "h", "l", "u"))
+    P.constraint(model, G * x, "<=", h)
+    P.constraint(model, x, ">=", lo)
+    P.constraint(model, x, "<=", up)
+    P.solve(model)
+    import scipy.sparse as sp
+    for it in range(3):
+        for v in bufs.values():
+            v[...] = rng.random(v.shape)
+        if it == 1:
+            model.stage_parameters()                       # overlapped upload of this solve's values
+        P.solve(model)
+        host = assert_host_equals_device(model)
+        # rows are stacked in the reference's update order (src/moi_interop.jl:236-247): Nonnegatives (x >= l) before Nonpositives (G x <= h, x <= u)
+        Ad = sp.csc_matrix(host["A"], shape=(mi + 2 * n, n)).toarray()
+        assert np.array_equal(Ad[:n], np.eye(n)) and np.array_equal(Ad[n:n + mi], bufs["G"]) and np.array_equal(Ad[n + mi:], np.eye(n))
+        assert np.array_equal(host["l"][:n], bufs["l"]) and np.all(host["u"][:n] == 1e20)
+        assert np.array_equal(host["u"][n:n + mi], bufs["h"]) and np.all(host["l"][n:n + mi] == -1e20)
+        assert np.array_equal(host["u"][n + mi:], bufs["u"]) and np.all(host["l"][n + mi:] == -1e20)
+    model.close()
