@@ -22,8 +22,6 @@
 // with column group b, so the 16 (row group, column group) pairs of a 16x16 tile take 4 instructions whose B operand is read
 // from LDS with the column groups rotated by s = 0..3 (cbsz/abid broadcast is ignored for f64: tools/mfma_probe2.hip).
 // acc[tm][tn][s] of lane l = C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
-#include <type_traits>
-
 #include "gram_common.h"
 
 // Codegen knobs.  The compiler's schedule of the stage loop moves by +-10 % with source changes that do not touch the loop.  Rounds 1-2
@@ -50,9 +48,6 @@
 #endif
 #ifndef PMT_SK_STOREFENCE
 #define PMT_SK_STOREFENCE 0    // 1: a scheduling barrier behind those LDS stores (they may not sink to the end of the stage)
-#endif
-#ifndef PMT_SK_PIPE2
-#define PMT_SK_PIPE2 0         // 1: the whole-panel path prefetches TWO stages ahead (sk_accumulate_pipe2)
 #endif
 #ifndef PMT_SK_BK
 #define PMT_SK_BK 16          // rows per stage (one barrier per stage)
@@ -337,92 +332,11 @@ __device__ __forceinline__ void sk_accumulate_impl(const SKArgs &g, int64_t j0, 
     }
 }
 
-// The whole-panel path with the global loads TWO stages ahead: stage s issues the loads of stage s + 2 (register set s & 1) and, at its very
-// beginning, moves the panels of stage s + 1 — loaded during stage s - 1, a whole stage ago — from the other register set into the LDS
-// buffer stage s - 1 has just finished reading.  A stage then ends with the barrier alone; in sk_accumulate_impl it ends with
-// wait(global loads) - ds_write - wait(LDS) - barrier and no MFMA in between (profiles/r03_gram_codegen.txt section 7).  Two stages per loop
-// iteration so that the register sets and LDS buffers are static.  Same arithmetic, same order: bit-identical results.
-template <int TN, int BK>
-__device__ __forceinline__ void sk_accumulate_pipe2(const SKArgs &g, int64_t j0, int64_t k0, int64_t ibeg, int64_t iend,
-                                                    double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
-    using C = Cfg<TN>;
-    constexpr int GP = BK + 1;
-    constexpr int NREG = C::NLD * (BK / 16);
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / C::NWC, wc = wave % C::NWC;
-    const int lm = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < C::NACC; ++r) acc[r] = 0.0;
-    const int nstage = (int)((iend - ibeg) / BK);
-    auto stage_row = [&](int s) { return ibeg + (int64_t)min(s, nstage - 1) * BK; };      // past the end: re-load the last stage, never used
-    f64x2 rj0[NREG], rk0[NREG], rj1[NREG], rk1[NREG];
-    __syncthreads();                                   // previous users of the LDS buffers are done
-    sk_load_panel<TN, BK, true>(g, j0, stage_row(0), iend, rj0, tid);
-    sk_load_panel<TN, BK, true>(g, k0, stage_row(0), iend, rk0, tid);
-    sk_load_panel<TN, BK, true>(g, j0, stage_row(1), iend, rj1, tid);
-    sk_load_panel<TN, BK, true>(g, k0, stage_row(1), iend, rk1, tid);
-    sk_store_panel<TN, BK>(lds[0][0], rj0, tid);
-    sk_store_panel<TN, BK>(lds[0][1], rk0, tid);
-    __syncthreads();
-    // one stage: operands out of LDS buffer CUR; `store_set` (the panels of the next stage) goes into buffer CUR ^ 1 first, then the loads of
-    // the stage after next are issued into `load_set`
-    auto stage = [&](auto cur_t, f64x2 (&sj)[NREG], f64x2 (&sk_)[NREG], f64x2 (&lj)[NREG], f64x2 (&lk_)[NREG], int s) {
-        constexpr int CUR = decltype(cur_t)::value;
-        const double *pj = lds[CUR][0] + (wr * 64 + lm) * GP + lk;
-        const double *pk = lds[CUR][1] + (wc * C::WCOLS) * GP + lk;
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            if (ks == 0) {
-                sk_store_panel<TN, BK>(lds[CUR ^ 1][0], sj, tid);
-                sk_store_panel<TN, BK>(lds[CUR ^ 1][1], sk_, tid);
-            }
-            if (ks == (BK / 4 > PMT_SK_LOADKS ? PMT_SK_LOADKS : 0)) {
-                sk_load_panel<TN, BK, true>(g, j0, stage_row(s + 2), iend, lj, tid);
-                sk_load_panel<TN, BK, true>(g, k0, stage_row(s + 2), iend, lk_, tid);
-            }
-            double a[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) a[t] = pj[t * 16 * GP + ks * 4];
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                double b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks
-                    b[r] = pk[(tn * 16 + rc) * GP + ks * 4];
-                }
-#if PMT_SK_ORDER == 0
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
-#else
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int tm = 0; tm < 4; ++tm)
-                        acc[(tm * TN + tn) * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], b[r], acc[(tm * TN + tn) * 4 + r], 0, 0, 0);
-#endif
-            }
-        }
-        __syncthreads();
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    for (int s = 0; s < nstage; s += 2) {
-        stage(B0{}, rj1, rk1, rj0, rk0, s);            // reads buffer 0; set 1 (stage s + 1) -> buffer 1; loads stage s + 2 -> set 0
-        if (s + 1 >= nstage) break;
-        stage(B1{}, rj0, rk0, rj1, rk1, s + 1);        // reads buffer 1; set 0 (stage s + 2) -> buffer 0; loads stage s + 3 -> set 1
-    }
-}
-
 template <int TN, int BK, int ABL>
 __device__ __forceinline__ void sk_accumulate(const SKArgs &g, int64_t j0, int64_t k0, bool diag, int64_t ibeg, int64_t iend,
                                               double (&acc)[Cfg<TN>::NACC], double (&lds)[2][2][ST * (BK + 1)], int tid) {
     const bool fast = g.vec_in && (k0 + ST <= g.cols) && ((iend - ibeg) % BK == 0);   // j0 <= k0: panel J is in range too
-    if (fast && PMT_SK_PIPE2 && ABL == 0 && iend - ibeg >= 2 * BK) sk_accumulate_pipe2<TN, BK>(g, j0, k0, ibeg, iend, acc, lds, tid);
-    else if (fast) sk_accumulate_impl<TN, BK, ABL, true>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
+    if (fast) sk_accumulate_impl<TN, BK, ABL, true>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
     else sk_accumulate_impl<TN, BK, ABL, false>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
 }
 
