@@ -332,6 +332,28 @@ int pmt_sparse_pack_vector_slabs_u32_f64(const double *nzval, const uint32_t *pe
                                          pmt_vector_affine_term *out_terms, void *stream);
 int pmt_sparse_assemble_slabs_u32_f64(const double *nzval, const uint32_t *perm, const uint32_t *term_var, const int64_t *slab_ptr,
                                       int64_t rows, int nslab, pmt_linear_term *out_terms, void *stream);
+
+/* Block form of the same two nodes (same outputs, bit for bit): the matrix is cut into blocks of 128 rows x `cw` columns; a workgroup reads
+ * the coefficients of its block with coalesced loads (the rows of a CSC column ascend, so a column's part of a block is one contiguous run
+ * of nzval) into LDS and writes each row's terms of the column band from there.  No per-term gather from HBM / L2 and a 4-byte instead of
+ * an 8-byte static index per term: 36 bytes per non-zero.  The variable word of a term comes from the per-COLUMN array col_var[cols]
+ * (x[col]; with `varmap` non-null varmap[col_var[col] - 1] as in moi_interop.jl:64-81).
+ * Host helpers, once per pattern:
+ *   pmt_sparse_blocks_width  -> *out_cw = the widest band width (power of two, 32..1024) whose blocks all fit the kernel's LDS buffer,
+ *                               or 0 when the form does not apply (rows not ascending within a column, 2^32 or more non-zeros, empty matrix):
+ *                               use the slab form then;
+ *   pmt_sparse_blocks_build  -> desc[ceil(m/128) * n] (8 bytes per (row block, column)), idx[nnz] (4 bytes per term, row-major order),
+ *                               band_ptr[m * (ceil(n/cw) + 1)]; perm / term_col / row_ptr from pmt_sparse_rowmajor_order. */
+int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *host_colptr, const int64_t *host_rowval, int *out_cw);
+int pmt_sparse_blocks_build(int64_t m, int64_t n, const int64_t *host_colptr, const int64_t *host_rowval, const int64_t *host_perm,
+                            const int64_t *host_term_col, const int64_t *host_row_ptr, int cw, uint64_t *host_desc, uint32_t *host_idx,
+                            int64_t *host_band_ptr);
+int pmt_sparse_pack_vector_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
+                                      const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const int64_t *varmap,
+                                      int64_t row_offset, pmt_vector_affine_term *out_terms, void *stream);
+int pmt_sparse_assemble_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
+                                   const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, pmt_linear_term *out_terms,
+                                   void *stream);
 /* constants of the same node: out[i] = 0.0 (+|-) d[i]  (vecadd!/vecsubtract! on zero!'d functions, src/functions.jl:244,452,474) */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 

@@ -163,6 +163,35 @@ sparse_pack_vector_u32!(out_terms::DevPtr, nzval::DevPtr, perm32::DevPtr, term_v
                 (DevPtr, DevPtr, DevPtr, DevPtr, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
                 nzval, perm32, term_var32, slab_ptr, rows, nslab, varmap, row_offset, out_terms, stream))
 
+"block form of the sparse node (CSC -> row-major through LDS, sparse.hip): band width `cw` (0: use the slab form), column descriptors, the
+4-byte index word per term and the per-row band boundaries (host, once per pattern; `plan` from sparse_plan)"
+function sparse_block_plan(C::SparseMatrixCSC{Float64,Int64}, plan)
+    m, n = size(C)
+    nz = length(C.nzval)
+    cw = Ref{Cint}(0)
+    check(ccall((:pmt_sparse_blocks_width, lib), Cint, (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ref{Cint}), m, n, C.colptr, C.rowval, cw))
+    cw[] == 0 && return (cw = 0, desc = UInt64[], idx = UInt32[], band_ptr = Int64[])
+    nrb, ncb = cld(m, 128), cld(n, Int(cw[]))
+    desc, idx, band = zeros(UInt64, nrb * n), zeros(UInt32, nz), zeros(Int64, m * (ncb + 1))
+    check(ccall((:pmt_sparse_blocks_build, lib), Cint,
+                (Int64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Cint, Ptr{UInt64}, Ptr{UInt32}, Ptr{Int64}),
+                m, n, C.colptr, C.rowval, plan.perm, plan.term_col, plan.row_ptr, cw[], desc, idx, band))
+    (cw = Int(cw[]), desc = desc, idx = idx, band_ptr = band)
+end
+
+"C*x (+|-) d for a sparse C written straight into MOI.VectorAffineTerms, block form: `col_var[c]` = x[c] (or varmap[x[c]] with `varmap = C_NULL`)"
+sparse_pack_vector_blocks!(out_terms::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols, nnz, cw,
+                           varmap::DevPtr, row_offset, stream) =
+    check(ccall((:pmt_sparse_pack_vector_blocks_f64, lib), Cint,
+                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
+                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, varmap, row_offset, out_terms, stream))
+
+"native LinearTerms of the same node, block form"
+sparse_assemble_blocks!(out_terms::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols, nnz, cw, stream) =
+    check(ccall((:pmt_sparse_assemble_blocks_f64, lib), Cint,
+                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Ptr{Cvoid}),
+                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, out_terms, stream))
+
 "dst (cols x rows, leading dimension ldd) = transpose of src (rows x cols, leading dimension lds) — the adjoint rule, src/lazyexpression.jl:206-217"
 transpose!(dst::DevPtr, ldd, src::DevPtr, lds, rows, cols, stream) =
     check(ccall((:pmt_transpose_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, Int64, Ptr{Cvoid}), src, lds, rows, cols, dst, ldd, stream))

@@ -422,6 +422,23 @@ class DSpMat(DV):
             _lib.call("pmt_sparse_slab_ptr", self.rows, self.cols, self.nslab, self.row_ptr.ctypes.data_as(vp), self.term_col.ctypes.data_as(vp),
                       self.slab_ptr.ctypes.data_as(vp))
         self.slab_ptr_buf = ctx.upload_new(self.slab_ptr)
+        # block form (CSC -> row-major through LDS, sparse.hip): used when the pattern allows it and a row's part of a column band is long
+        # enough to be written as a run (>= 16 terms on average); block_cw == 0: slab form
+        self.block_cw = 0
+        if self.nnz and self.rows and self.cols:
+            cw = C.c_int(0)
+            _lib.call("pmt_sparse_blocks_width", self.rows, self.cols, colptr.ctypes.data_as(vp), rowval.ctypes.data_as(vp), C.byref(cw))
+            cw = cw.value
+            if cw and self.nnz >= 16 * self.rows * (-(-self.cols // cw)):
+                nrb, ncb = -(-self.rows // 128), -(-self.cols // cw)
+                desc = np.zeros(nrb * self.cols, dtype=np.uint64)
+                idx = np.zeros(self.nnz, dtype=np.uint32)
+                band = np.zeros(self.rows * (ncb + 1), dtype=np.int64)
+                _lib.call("pmt_sparse_blocks_build", self.rows, self.cols, colptr.ctypes.data_as(vp), rowval.ctypes.data_as(vp),
+                          self.perm.ctypes.data_as(vp), self.term_col.ctypes.data_as(vp), self.row_ptr.ctypes.data_as(vp), cw,
+                          desc.ctypes.data_as(vp), idx.ctypes.data_as(vp), band.ctypes.data_as(vp))
+                self.block_cw = cw
+                self.block_desc_buf, self.block_idx_buf, self.block_band_buf = ctx.upload_new(desc), ctx.upload_new(idx), ctx.upload_new(band)
 
     def same_pattern(self, csc):
         return csc.shape == (self.rows, self.cols) and np.array_equal(csc.indptr, self.indptr) and np.array_equal(csc.indices, self.indices)

@@ -420,8 +420,12 @@ def _emit_sparse_terms(c, out):
     if not out.need_terms:
         return
     sp = out.spmat
-    c.call("pmt_sparse_assemble_slabs_u32_f64" if sp.narrow else "pmt_sparse_assemble_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf),
-           P(sp.slab_ptr_buf), sp.rows, sp.nslab, P(out.terms))
+    if sp.block_cw:
+        c.call("pmt_sparse_assemble_blocks_f64", P(sp.buf), P(sp.block_desc_buf), P(sp.block_idx_buf), P(sp.block_band_buf), P(out.xvars.buf),
+               sp.rows, sp.cols, sp.nnz, sp.block_cw, P(out.terms))
+    else:
+        c.call("pmt_sparse_assemble_slabs_u32_f64" if sp.narrow else "pmt_sparse_assemble_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf),
+               P(sp.slab_ptr_buf), sp.rows, sp.nslab, P(out.terms))
     if out.vec is not None:
         c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(out.consts))
 

@@ -264,8 +264,24 @@ class _Record:
             self.dev = {"terms": dt, "consts": dc}
             self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
             sp = out.spmat
-            # varmap folded into the per-term variable stream: it changes with the optimizer's index map (mapindices!, src/model.jl:100-107),
-            # not per re-evaluation, so the kernel streams varmap[x[col]] instead of gathering it for every term
+            # varmap folded into the static variable words: it changes with the optimizer's index map (mapindices!, src/model.jl:100-107),
+            # not per re-evaluation, so the kernel reads varmap[x[col]] instead of gathering it for every term.  Block form: one word per
+            # COLUMN (staged in LDS per column band); slab form: one per term
+            if sp.block_cw:
+                colvar = ctx.alloc(8 * max(sp.cols, 1))
+
+                def refresh(varmap_host):
+                    v = out.xvars.vars if varmap_host is None else np.asarray(varmap_host, dtype=np.int64)[out.xvars.vars - 1]
+                    ctx.upload(colvar, np.ascontiguousarray(v, dtype=np.int64))
+                self.varmap_hooks.append(refresh)
+                refresh(handoff_varmap)
+
+                def emit(c):
+                    c.call("pmt_sparse_pack_vector_blocks_f64", P(sp.buf), P(sp.block_desc_buf), P(sp.block_idx_buf), P(sp.block_band_buf), P(colvar),
+                           sp.rows, sp.cols, sp.nnz, sp.block_cw, None, 0, P(dt))
+                    if out.vec is not None:
+                        c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
+                return emit
             mapped = ctx.alloc((4 if sp.narrow else 8) * max(sp.nnz, 1))
 
             def refresh(varmap_host):

@@ -158,3 +158,104 @@ def test_device_resident_sparse_parameter_matches_the_host_updated_one():
         assert prev is None or not np.array_equal(prev, dense)
         prev = dense
     model.close()
+
+
+def _pattern(m, n, density, seed, dense_cols=(), empty_rows=()):
+    rng = np.random.default_rng(seed)
+    C = sp.random(m, n, density=density, format="lil", random_state=rng, data_rvs=lambda k: rng.random(k) + 0.1)
+    for c in dense_cols:                                             # a column with every row set: runs of 128 inside one row block
+        C[:, c] = (rng.random(m) + 0.1).reshape(-1, 1)
+    for r in empty_rows:
+        C[r, :] = 0.0
+    C = C.tocsc()
+    C.eliminate_zeros()
+    C.sort_indices()
+    return C
+
+
+@pytest.mark.parametrize("m,n,density,kw", [
+    (300, 3000, 0.05, {}),                                           # three row blocks (the last one ragged), bands of 1024 with a ragged last one
+    (128, 1024, 0.04, {}),                                           # exactly one block
+    (513, 2049, 0.02, {"dense_cols": (0, 700, 2048), "empty_rows": (0, 17, 512)}),
+    (40, 70, 0.5, {}),                                               # smaller than a block
+    (1000, 900, 0.3, {}),                                            # dense enough to force narrower bands than 1024
+    (260, 5000, 0.06, {"dense_cols": tuple(range(100, 140))}),      # a cluster of full columns: per-block counts far above the average
+])
+def test_block_kernels_equal_the_flat_scatter(m, n, density, kw):
+    """pmt_sparse_pack_vector_blocks_f64 / pmt_sparse_assemble_blocks_f64 (CSC -> row-major through LDS) against the flat gather kernels,
+    bit for bit, with a permuting varmap and a row offset."""
+    import ctypes as C
+    from parametron_jl_amd import _lib
+    csc = _pattern(m, n, density, 11, **kw)
+    nnz = csc.nnz
+    colptr, rowval = csc.indptr.astype(np.int64) + 1, csc.indices.astype(np.int64) + 1
+    perm, trow, tcol = (np.empty(nnz, dtype=np.int64) for _ in range(3))
+    rptr = np.empty(m + 1, dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.call("pmt_sparse_rowmajor_order", m, n, vp(colptr), vp(rowval), vp(perm), vp(trow), vp(tcol), vp(rptr))
+    cw = C.c_int(0)
+    _lib.call("pmt_sparse_blocks_width", m, n, vp(colptr), vp(rowval), C.byref(cw))
+    cw = cw.value
+    assert cw >= 32 and cw & (cw - 1) == 0
+    nrb, ncb = -(-m // 128), -(-n // cw)
+    desc, idx, band = np.zeros(nrb * n, dtype=np.uint64), np.zeros(nnz, dtype=np.uint32), np.zeros(m * (ncb + 1), dtype=np.int64)
+    _lib.call("pmt_sparse_blocks_build", m, n, vp(colptr), vp(rowval), vp(perm), vp(tcol), vp(rptr), cw, vp(desc), vp(idx), vp(band))
+    # every block fits the kernel's LDS buffer, and the widest admissible band was chosen
+    counts = np.zeros((nrb, ncb), dtype=np.int64)
+    np.add.at(counts, ((trow - 1) // 128, (tcol - 1) // cw), 1)
+    assert counts.max() <= 7168
+    dev = torch.device("cuda:0")
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(5)
+    xvar = rng.permutation(np.arange(1, n + 1)).astype(np.int64) + 3                 # x[col]
+    varmap = rng.permutation(np.arange(1, n + 4)).astype(np.int64) + 100            # optimizer index of model variable v at varmap[v - 1]
+    nz = torch.from_numpy(csc.data.copy()).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a)).to(dev)
+    dperm, drow, dtvar = t(perm), t(trow), t(xvar[tcol - 1])
+    ddesc, dband, dxvar, dvarmap = t(desc), t(band), t(xvar), t(varmap)
+    didx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    want = torch.zeros(nnz * 3, dtype=torch.int64, device=dev)
+    got = torch.zeros(nnz * 3, dtype=torch.int64, device=dev)
+    want_lt = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
+    got_lt = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
+    for _ in range(2):                                               # second pass with new coefficients: same structure, new values
+        _lib.call("pmt_sparse_pack_vector_f64", dp(nz), dp(dperm), dp(drow), dp(dtvar), nnz, dp(dvarmap), 7, dp(want), stream)
+        _lib.call("pmt_sparse_pack_vector_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(dvarmap), 7, dp(got), stream)
+        _lib.call("pmt_sparse_assemble_f64", dp(nz), dp(dperm), dp(dtvar), nnz, dp(want_lt), stream)
+        _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(got_lt), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got_lt, want_lt)
+        nz.copy_(torch.from_numpy(rng.random(nnz) + 0.5).to(dev))
+    # against the pattern itself: row-major (row, col) order, coefficients of the CSR form
+    g = got_lt.cpu().numpy().reshape(-1, 2)
+    csr = sp.csc_matrix((nz.cpu().numpy(), csc.indices, csc.indptr), shape=(m, n)).tocsr()
+    csr.sort_indices()
+    _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(got_lt), stream)
+    torch.cuda.synchronize()
+    g = got_lt.cpu().numpy().reshape(-1, 2)
+    assert np.array_equal(g[:, 0].view(np.float64), csr.data) and np.array_equal(g[:, 1], xvar[csr.indices])
+
+
+def test_block_form_is_the_one_the_config5_model_runs():
+    """the host API picks the block form for a config-5-like pattern (and the profile shows its kernel), the slab form for a very sparse one"""
+    rng = np.random.default_rng(4)
+    for density, want_block in ((0.05, True), (0.002, False)):
+        m, n = 256, 4096
+        Cs = _pattern(m, n, density, 21)
+        model = P.Model(P.MockOptimizer())
+        x = [Variable(model) for _ in range(n)]
+        Cp = P.Parameter(model, val=Cs)
+        d = P.Parameter(model, val=rng.random(m))
+        P.constraint(model, Cp * x == d)
+        P.solve(model)
+        P.profile_enable(True)
+        P.solve(model)
+        rep = P.profile_report()
+        P.profile_enable(False)
+        assert ("sparse_block_kernel<VAT>" in rep) == want_block and ("sparse_slab_kernel<VAT,u32>" in rep) == (not want_block)
+        t = list(model.constraints)[0].f.terms
+        csr = Cs.tocsr()
+        csr.sort_indices()
+        assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
+        assert np.array_equal(t["out"], np.repeat(np.arange(1, m + 1), np.diff(csr.indptr)))

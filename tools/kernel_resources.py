@@ -5,6 +5,7 @@ The Makefile compiles every .hip with -Rpass-analysis=kernel-resource-usage and 
 parametron.jl_amd/build/<file>.resources.txt.  This script prints one line per kernel and, with --check, FAILS (exit 1) when a hot-path
 kernel spills a vector register or uses scratch, or exceeds the register budget its co-residency design depends on:
   gram_sk_kernel*       <= 216 VGPRs (the budget its amdgpu_num_vgpr attribute states)
+  sparse_block_kernel*  <= 128 VGPRs (two 512-thread workgroups per CU), sparse_slab_kernel* <= 64 (eight 256-thread workgroups per CU)
   courier / to_host / the Gram node's small reductions   <= 16 VGPRs (co-resident with any contraction build up to 248 VGPRs)
   batch_small_kernel*   no spills
   every kernel          no VGPR spills, no scratch
@@ -18,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIELDS = ("TotalSGPRs", "VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "SGPRs Spill", "VGPRs Spill", "LDS Size [bytes/block]")
-BUDGET = {"gram_sk_kernel": 216}          # VGPR ceilings that are part of the design
+BUDGET = {"gram_sk_kernel": 216, "sparse_block_kernel": 128, "sparse_slab_kernel": 64}          # VGPR ceilings that are part of the design
 SIDE_KERNELS = {"gram_linear_kernel": 16, "gram_linear_split_kernel": 16, "seq_dot_kernel": 16, "courier_kernel": 16, "to_host_kernel": 16}
 
 

@@ -59,13 +59,36 @@ def main():
 
     def pack_slabs_u32_premapped():
         _lib.call("pmt_sparse_pack_vector_slabs_u32_f64", dptr(nz), dptr(dperm32), dptr(dvar32), dptr(dslab), m, nslab, None, 0, dptr(out3), stream)
+    cw = C.c_int(0)
+    _lib.call("pmt_sparse_blocks_width", m, n, vp(colptr), vp(rowval), C.byref(cw))
+    cw = cw.value
+    print("block form: band width", cw, flush=True)
+    nrb, ncb = -(-m // 128), -(-n // cw)
+    desc, idx, band = np.zeros(nrb * n, dtype=np.uint64), np.zeros(nnz, dtype=np.uint32), np.zeros(m * (ncb + 1), dtype=np.int64)
+    _lib.call("pmt_sparse_blocks_build", m, n, vp(colptr), vp(rowval), vp(perm), vp(tcol), vp(rptr), cw, vp(desc), vp(idx), vp(band))
+    ddesc, didx, dband = torch.from_numpy(desc.view(np.int64)).to(dev), torch.from_numpy(idx.view(np.int32)).to(dev), torch.from_numpy(band).to(dev)
+    colvar = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
+    out4 = torch.zeros(nnz * 3, dtype=torch.int64, device=dev)
+    outlt4 = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
+
+    def pack_blocks():
+        _lib.call("pmt_sparse_pack_vector_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, None, 0, dptr(out4), stream)
+
+    def assemble_blocks():
+        _lib.call("pmt_sparse_assemble_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, dptr(outlt4), stream)
+    pack_blocks(); assemble_blocks()
     pack_slabs_u32_premapped()
     pack(); assemble(); pack_slabs(); assemble_slabs()
     torch.cuda.synchronize()
-    print("slab kernels bit-identical to the flat kernels:", bool(torch.equal(out, out2)), bool(torch.equal(outlt, outlt2)), bool(torch.equal(out, out3)), flush=True)
+    print("slab kernels bit-identical to the flat kernels:", bool(torch.equal(out, out2)), bool(torch.equal(outlt, outlt2)), bool(torch.equal(out, out3)),
+          " block kernels:", bool(torch.equal(out, out4)), bool(torch.equal(outlt, outlt4)), flush=True)
+    only = os.environ.get("SPARSE_PROBE_ONLY")
     for name, fn, bytes_per in (("sparse_pack_vector_kernel", pack, 56), ("sparse_assemble_kernel", assemble, 40),
                                 ("sparse_slab_kernel<VAT>", pack_slabs, 48), ("sparse_slab_kernel<LT>", assemble_slabs, 40),
-                                ("sparse_slab_kernel<VAT>", pack_slabs_premapped, 48), ("sparse_slab_kernel<VAT,u32>", pack_slabs_u32_premapped, 40)):
+                                ("sparse_slab_kernel<VAT>", pack_slabs_premapped, 48), ("sparse_slab_kernel<VAT,u32>", pack_slabs_u32_premapped, 40),
+                                ("sparse_block_kernel<VAT>", pack_blocks, 40), ("sparse_block_kernel<LT>", assemble_blocks, 32)):
+        if only and name not in only.split(";"):
+            continue
         for _ in range(30):
             fn()
         torch.cuda.synchronize()
