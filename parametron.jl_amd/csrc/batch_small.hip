@@ -196,7 +196,7 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
 template <bool FAST>
 __device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &sh, int lt, int n, int nchunk) {
     const int lane = lt & 63, lw = lt >> 6;
-    const int lm = lane & 15, lk = lane >> 4;
+    const int lm = lane & 15;
     const int kp = lt & 15, cc0 = lt >> 4;                    // chunk loads: 16-byte piece kp of columns cc0 + 8 q
     const int nq = n * (n + 1) / 2;
     const int64_t G = gridDim.x;
@@ -278,8 +278,15 @@ __device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &s
         else if (lt < CK) sh.cvec[buf * CK + lt] = signed_const(cval[S], csign);
     };
 
-    double qpart[4] = {0.0, 0.0, 0.0, 0.0};                   // lane: columns 64 lw + 16 j + lm, rows lk + 4u of every chunk
-    const int qoff = (64 * lw + lm) * SGP + lk;
+    // q = 2 A'c: column col of a chunk adds c[row] * A[row, col] into one partial sum per row class (row mod 4), rows ascending; the four classes
+    // are added in class order at the end of the instance (round 1's summation order, = pmt_quad_gram_f64's).  Lane (cg, lkp, lm) owns columns
+    // 64 lw + 32 j + 16 cg + lm (j = 0, 1) and the classes 2 lkp, 2 lkp + 1: qpart[2 j + k] = class 2 lkp + k of column j.  Rows 4u + 2 lkp and
+    // 4u + 2 lkp + 1 of a column are one aligned 16-byte LDS read (even pitch): 24 LDS reads per phase instead of 40, and 16 lanes x 16 bytes
+    // at a pitch of 272 bytes touch every bank exactly once.
+    static_assert(SGP % 2 == 0, "the q reads are 16-byte reads of row pairs");
+    double qpart[4] = {0.0, 0.0, 0.0, 0.0};
+    const int lkp = (lane >> 4) & 1, cg = lane >> 5;
+    const int qoff = (64 * lw + 16 * cg + lm) * SGP + 2 * lkp;
     auto next_of = [&](int64_t i, int c, int64_t &ni, int &nc) { nc = c + 1; ni = i; if (nc == nchunk) { nc = 0; ni = i + G; } };
 
     using P0 = std::integral_constant<int, 0>;
@@ -313,25 +320,31 @@ __device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &s
         load_chunk(par_t, n2i, n2c);                          // chunk g + 2 -> set PAR (chunk g left it during phase g - 1)
         wait_chunk(Other{}, OneSet{});                        // chunk g + 1 (set PAR ^ 1, issued a phase ago) has landed ...
         store_chunk(Other{}, PAR ^ 1);                        // ... and goes into the other panel
-        if (!(PMT_BS_SKIP & 2)) {                             // q: rows lk + 4 ks of this lane's four columns (vector ALU)
+        if (!(PMT_BS_SKIP & 2)) {                             // q (vector ALU): two rows of two columns per 16-byte LDS read
 #pragma unroll
-            for (int ks = 0; ks < CK / 4; ++ks) {
-                const double c = sh.cvec[PAR * CK + lk + 4 * ks];
+            for (int u = 0; u < CK / 4; ++u) {
+                const f64x2 c2 = *reinterpret_cast<const f64x2 *>(sh.cvec + PAR * CK + 4 * u + 2 * lkp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const double pr = c * pan[qoff + j * 16 * SGP + 4 * ks]; qpart[j] = qpart[j] + pr; }
+                for (int j = 0; j < 2; ++j) {
+                    const f64x2 a2 = *reinterpret_cast<const f64x2 *>(pan + qoff + j * 32 * SGP + 4 * u);
+                    const double p0 = c2.x * a2.x, p1 = c2.y * a2.y;
+                    qpart[2 * j] = qpart[2 * j] + p0;
+                    qpart[2 * j + 1] = qpart[2 * j + 1] + p1;
+                }
             }
         }
         if (last) {
             phase_barrier();                                  // the previous slab has left the staging buffer
             double *outp = p.out + inst * p.out_stride;
             double *st = sh.stage + (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
-            // q: the four row classes of a column, added in class order, x2
+            // q: the four row classes of a column, added in class order, x2 (classes 2, 3 live 16 lanes up)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double p1 = __shfl(qpart[j], lane + 16, 64), p2 = __shfl(qpart[j], lane + 32, 64), p3 = __shfl(qpart[j], lane + 48, 64);
-                const int col = 64 * lw + 16 * j + lm;
-                if (lk == 0 && col < n) st[nq + col] = 2 * (((qpart[j] + p1) + p2) + p3);
-                qpart[j] = 0.0;
+            for (int j = 0; j < 2; ++j) {
+                const double p2 = __shfl(qpart[2 * j], lane + 16, 64), p3 = __shfl(qpart[2 * j + 1], lane + 16, 64);
+                const int col = 64 * lw + 32 * j + 16 * cg + lm;
+                if (lkp == 0 && col < n) st[nq + col] = 2 * (((qpart[2 * j] + qpart[2 * j + 1]) + p2) + p3);
+                qpart[2 * j] = 0.0;
+                qpart[2 * j + 1] = 0.0;
             }
         }
         phase_barrier();
@@ -469,7 +482,7 @@ template <bool FAST>
 __global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
     __shared__ __attribute__((aligned(16))) double panel[2 * PANEL];
     __shared__ __attribute__((aligned(16))) double stage[STAGE_CAP + 2];
-    __shared__ double cvec[2 * CK];
+    __shared__ __attribute__((aligned(16))) double cvec[2 * CK];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int n = (int)p.cols;                                // <= 128
     const int nchunk = (int)max((int64_t)1, (p.rows + CK - 1) / CK);

@@ -7,6 +7,6 @@ for rep in 1 2 3; do
     echo "[$rep] $v: $(PMT_LIB_PATH=$lib python bench.py --workload batch --steps 30 --warmup 5 2>&1 | python -c 'import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
-        d=json.loads(l); print("compute %.4f ms  step %.4f ms" % (d["compute_only_ms_per_step"], d["ms_per_step"]))')"
+        d=json.loads(l); print("compute %.4f ms  step %.4f ms" % (d["compute_only"]["ms_per_step"], d["ms_per_step"]))')"
   done
 done
