@@ -193,12 +193,15 @@ int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t co
 
 /* The same node (values only, no term structs) with the values additionally DELIVERED TO THE HOST while the contraction runs — the
  * reference's boundary is a host solver (MOI.set, src/moi_interop.jl:131-137; OSQP's update_P takes exactly this array).  host_P_values
- * is page-locked host memory (pmt_host_alloc) of cols*(cols+1)/2 doubles.  The tiles are computed column band by column band; the kernel
- * counts finished tiles per band group (`ngroups` groups of about equal bytes, 0 = default 8, at most 16) and a co-resident courier kernel
- * on the calling stream's FETCH stream polls each count and stores that group's columns straight into the host array, so most of P has
- * crossed PCIe before the last tile is done.  `stream` does not wait for the delivery: pmt_plan_fetch_synchronize (or
- * pmt_fetch_synchronize for a plain stream) does — PMT_HIP_ERROR there if the courier timed out (no progress for 2 s); the next call on
- * the same stream waits by itself until the previous delivery has read out_P_values. */
+ * is page-locked host memory (pmt_host_alloc) of cols*(cols+1)/2 doubles.  The contraction runs in STAGES over the column bands of P
+ * (`ngroups` stages, 0 = default: half a grid's worth of 128 x 128 tiles per stage, at most 16): each stage is a launch over all CUs with
+ * its tiles split along the contraction and summed by a second launch, and the copy engine (HSA SDMA; a courier kernel where that is not
+ * available) ships the bands a stage has completed while the next stage is computed, so P leaves at PCIe speed from the first stage on.
+ * Splitting a tile changes its summation order (two half sums added): out_P_values here and from pmt_quad_gram_csc_f64 agree to rounding
+ * (a few ulp), not bit for bit; both are deterministic, and host_P_values is out_P_values of the same call bit for bit.  `stream` does not
+ * wait for the delivery: pmt_plan_fetch_synchronize (or pmt_fetch_synchronize for a plain stream) does — PMT_HIP_ERROR there if a transfer
+ * never started (10 s; courier: no progress for 2 s); the next call on the same stream waits by itself until the previous delivery has
+ * read out_P_values. */
 int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
                                   const int64_t *xvar, const double *b, int sign, const int64_t *varmap,
                                   double alpha, double *out_P_values, double *host_P_values, int ngroups,

@@ -10,10 +10,11 @@
 // FALLBACK: the preferred path hands the copies to the copy engine, gated by signals the kernels set (hsadma.hip) — a courier that shares
 // CUs with the contraction costs it dearly too (its stores to the host queue up in the CU's memory pipeline in front of the
 // contraction's panel loads: 1.19 -> 1.95 ms).  They run when the process's HSA runtime cannot be reached:
-//   courier_kernel   one launch per delivery: for every band group, ONE lane per workgroup polls the group's progress count (s_sleep
-//                    between polls), then the workgroup's slice of the group is copied straight into the host array;
+//   courier_kernel   one launch per delivery: for every band group, ONE lane per workgroup polls the group's flag (s_sleep between
+//                    polls; a one-thread kernel behind the stage that completes the group clears it, gram.hip), then the workgroup's
+//                    slice of the group is copied straight into the host array;
 //   to_host_kernel   a plain device -> host copy (recorded fetches: q, A's values, bounds).
-// Loads are agent-scope relaxed atomic loads (`sc1`): the producer wrote through, and no line of this XCD's L2 may serve a stale copy
+// Loads are agent-scope relaxed atomic loads (`sc1`): the producing launches have ended, and no line of this XCD's L2 may serve a stale copy
 // (a 128-byte line can straddle two band groups).  The courier gives up after ~2 s without progress and raises an error flag instead of
 // hanging the GPU.
 #include "gram_common.h"
@@ -23,7 +24,7 @@ namespace pmt {
 struct CourierArgs {
     const double *src;                    // out_csc (device)
     double *dst;                          // device address of the page-locked host array
-    long long *ready;                     // per band group: 1 = in the making, 0 = complete (set by gram_sk_kernel<..., SIGNAL> / the fix-up pass)
+    long long *ready;                     // per band group: 1 = in the making, 0 = complete (cleared by the one-thread kernel behind the group's stage)
     unsigned *done;                       // workgroups that have finished; the last one re-arms the flags for the next launch
     int *error;                           // set to 1 on timeout
     int ngroups;

@@ -32,11 +32,9 @@ size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s);
 int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
 void *host_device_pointer(void *host);
-struct SKDeliver;
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, const SKDeliver *deliver,
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
                    hipStream_t s);
-
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr int DELIVER_ORDER_W = 2; // a delivery computes the tiles in super-columns of two tile columns: the column bands finish in ascending order
 
@@ -123,7 +121,7 @@ struct SideStream {
     bool in_replay = false;                                              // a plan's tape is being replayed: P's transfers are submitted at its end
     std::vector<std::function<int()>> deferred;
 };
-// layout of `counters`: [MAXGROUPS x u64 progress][MAXGROUPS x i64 courier flags (armed = 1)][u32 courier done][i32 courier error]
+// layout of `counters`: [MAXGROUPS x u64 unused][MAXGROUPS x i64 courier flags (armed = 1)][u32 courier done][i32 courier error]
 constexpr size_t PROGRESS_OFFSET = 0;
 constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
 constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
@@ -388,78 +386,64 @@ struct DeliverSignals {
     }
 };
 
-// Host delivery of the CSC values (pmt_quad_gram_csc_deliver_f64): where the band groups end and what each of them ships.
+// Host delivery of the CSC values (pmt_quad_gram_csc_deliver_f64): the contraction runs as a sequence of STAGES, each a launch over a range
+// of the tile sequence (column-band-major, sk_colseq_unrank) followed by its fix-up; a stage that completes column bands ends with a one-thread
+// kernel that releases the copy engine's transfer of those bands.
 struct DeliverPlan {
     double *host = nullptr;                 // page-locked destination, same layout as out_csc
     double *host_dev = nullptr;             // ... and its device-visible address
+    int nstages = 0;
+    int64_t seq_begin[MAXGROUPS], seq_count[MAXGROUPS];
+    int group_of[MAXGROUPS];                // index of the band group the stage completes, or -1
     int ngroups = 0;
-    short gend[MAXGROUPS];                  // band group i = tile columns [gend[i-1], gend[i])
-    unsigned long long expect[MAXGROUPS];   // accumulator units of the group's tiles = 32 x sum over its bands kb of (kb + 1)
     int64_t off[MAXGROUPS + 1];             // CSC offsets (doubles) of the groups' first columns
 };
 
-// Band groups: a column band is complete when the LAST tile of its super-column has been written, and with the persistent grid all tiles of
-// one "round" (G consecutive tiles of the sequence) finish together.  Group boundaries therefore sit on the boundaries between rounds —
-// a group that straddled one would wait for the later round with all of its bytes — and each round's bands are cut into groups of about
-// equal bytes, so that the copy engine has something to ship as soon as a round ends and keeps shipping while the next one computes.
-static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int ngroups, int order_w, double *host) {
+// Stage size.  With the persistent grid all workgroups finish a round of whole tiles together, so one launch of everything delivers in two
+// bursts (at n = r = 4096: nothing for 0.6 ms, half of P then, the rest at the end: 1.95 ms per solve).  Stages of HALF a grid's worth of
+// tiles — every tile split in two along the contraction, stream-K over all workgroups, partial sums added by the fix-up launch — complete
+// a quarter of P every 0.3 ms, which is also what PCIe takes to ship it: the copy engine stays busy from the first stage on.  The split
+// costs ~15 % of contraction time (partial tiles through the workspace, 3 launches per stage; profiles/r03_host_delivery.txt) and changes
+// the summation order of a split tile (two half sums added) — within the stated tolerance, deterministic, and the delivered host array is
+// the device array of the same run bit for bit.  `nstages_hint` (the entry point's ngroups) > 0 overrides the number of stages.
+static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, int order_w, double *host) {
     DeliverPlan d;
     d.host = host;
     const int nt = (int)cdiv(cols, GT);
     const int64_t T = (int64_t)nt * (nt + 1) / 2;
     const int64_t nchunk = std::max<int64_t>(1, cdiv(rows, 256));
     const int64_t G = std::min<int64_t>(T * nchunk, 256);                  // as launch_gram_sk (gram_sk.hip)
-    const int64_t tfull = T / G;
-    ngroups = std::max(1, std::min(ngroups, std::min(nt, MAXGROUPS)));
-    // round in which band kb completes (tfull = the split tiles at the end of the launch)
-    std::vector<int64_t> round((size_t)nt), endoff((size_t)nt);
+    int64_t per = nchunk >= 2 ? std::max<int64_t>(1, G / 2) : G;           // tiles per stage: half a grid's worth (whole tiles if there is nothing to split)
+    if (nstages_hint > 0) per = std::max<int64_t>(1, cdiv(T, std::min(nstages_hint, MAXGROUPS)));
+    if (cdiv(T, per) > MAXGROUPS) per = cdiv(T, MAXGROUPS);
+    // tiles up to the end of each super-column, i.e. where its bands are complete
+    std::vector<int64_t> seq_end_of_band((size_t)nt), endoff((size_t)nt);
     int64_t seq_end = 0;
     for (int c0 = 0; c0 < nt; c0 += order_w) {
         const int h = std::min(order_w, nt - c0);
-        seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;             // tiles up to the end of this super-column (sk_colseq_unrank)
-        const int64_t r = seq_end <= tfull * G ? (seq_end - 1) / G : tfull;
-        for (int kb = c0; kb < c0 + h; ++kb) round[(size_t)kb] = r;
+        seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;             // (sk_colseq_unrank)
+        for (int kb = c0; kb < c0 + h; ++kb) seq_end_of_band[(size_t)kb] = seq_end;
     }
     for (int kb = 0; kb < nt; ++kb) {
         const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
         endoff[(size_t)kb] = cend * (cend + 1) / 2;
     }
-    // segments of equal round; groups per segment proportional to its bytes (at least one each)
-    struct Seg { int b0, b1; int64_t bytes; int groups; };
-    std::vector<Seg> segs;
-    for (int kb = 0; kb < nt; ++kb) {
-        if (segs.empty() || round[(size_t)kb] != round[(size_t)segs.back().b0]) segs.push_back({kb, kb + 1, 0, 1});
-        else segs.back().b1 = kb + 1;
-    }
-    while ((int)segs.size() > ngroups) { segs[segs.size() - 2].b1 = segs.back().b1; segs.pop_back(); }
-    const int64_t total = endoff[(size_t)nt - 1];
-    int spare = ngroups - (int)segs.size();
-    for (auto &sg : segs) sg.bytes = endoff[(size_t)sg.b1 - 1] - (sg.b0 ? endoff[(size_t)sg.b0 - 1] : 0);
-    for (auto &sg : segs) {
-        const int want = (int)std::min<int64_t>(sg.b1 - sg.b0 - 1, std::min<int64_t>(spare, sg.bytes * ngroups / std::max<int64_t>(1, total)));
-        sg.groups += std::max(0, want);
-        spare -= std::max(0, want);
-    }
-    int g = 0;
     d.off[0] = 0;
-    for (const auto &sg : segs) {
-        const int64_t base = sg.b0 ? endoff[(size_t)sg.b0 - 1] : 0;
-        int b0 = sg.b0, k = 0;
-        for (int kb = sg.b0; kb < sg.b1; ++kb) {
-            const bool last = kb == sg.b1 - 1;
-            const int left_groups = sg.groups - 1 - k, left_bands = sg.b1 - 1 - kb;
-            if (last || ((endoff[(size_t)kb] - base) * sg.groups >= sg.bytes * (k + 1) && left_bands >= left_groups && left_groups > 0)) {
-                d.gend[g] = (short)(kb + 1);
-                d.off[g + 1] = endoff[(size_t)kb];
-                unsigned long long tiles = 0;
-                for (int q = b0; q <= kb; ++q) tiles += (unsigned long long)(q + 1);
-                d.expect[g] = tiles * 32;           // Cfg<2>::NACC units per tile (gram_sk.hip: sk_signal_tile)
-                b0 = kb + 1;
-                ++g; ++k;
-            }
+    int done_bands = 0;
+    for (int64_t t0 = 0; t0 < T; t0 += per) {
+        const int st = d.nstages++;
+        d.seq_begin[st] = t0;
+        d.seq_count[st] = std::min<int64_t>(per, T - t0);
+        int nb = done_bands;
+        while (nb < nt && seq_end_of_band[(size_t)nb] <= t0 + d.seq_count[st]) ++nb;
+        d.group_of[st] = -1;
+        if (nb > done_bands) {
+            d.group_of[st] = d.ngroups;
+            d.off[d.ngroups + 1] = endoff[(size_t)nb - 1];
+            ++d.ngroups;
+            done_bands = nb;
         }
     }
-    d.ngroups = g;
     return d;
 }
 
@@ -480,7 +464,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     DeliverPlan dplan;
     std::shared_ptr<DeliverSignals> sig = std::make_shared<DeliverSignals>();      // lives as long as the recorded call
     if (host_csc && cols > 0) {
-        dplan = deliver_plan(rows, cols, ngroups > 0 ? ngroups : 8, DELIVER_ORDER_W, host_csc);
+        dplan = deliver_plan(rows, cols, ngroups, DELIVER_ORDER_W, host_csc);
         dplan.host_dev = static_cast<double *>(host_device_pointer(host_csc));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
         mark_no_graph(stream);
@@ -548,20 +532,22 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (!rc && defer_const) side->deferred.push_back(const_part);
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
-            SKDeliver sd;
-            if (deliver) {
+            if (!deliver) {
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, s);
+            } else {
+                // stage by stage; behind a stage that completes column bands, one thread stores 0 into the word the transfer of those bands waits
+                // for: the value of its dependency signal (copy engine, hsadma.hip) or the courier's flag (deliver.hip)
                 char *cb = static_cast<char *>(side->counters);
-                sd.progress = reinterpret_cast<unsigned long long *>(cb + PROGRESS_OFFSET);
-                sd.ngroups = dplan.ngroups;
-                for (int i = 0; i < MAXGROUPS; ++i) {
-                    sd.gend[i] = i < dplan.ngroups ? dplan.gend[i] : 0;
-                    sd.expect[i] = i < dplan.ngroups ? dplan.expect[i] : 0;
-                    sd.ready[i] = i >= dplan.ngroups ? nullptr : (sig->eng ? reinterpret_cast<long long *>(sig->dep[i].value)
-                                                                            : reinterpret_cast<long long *>(cb + FLAGS_OFFSET) + i);
+                for (int st = 0; !rc && st < dplan.nstages; ++st) {
+                    rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, DELIVER_ORDER_W, dplan.seq_begin[st],
+                                        dplan.seq_count[st], s);
+                    const int grp = dplan.group_of[st];
+                    if (!rc && grp >= 0) {
+                        dma::Signal word = sig->eng ? sig->dep[grp] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET) + grp};
+                        rc = dma::launch_signal_store(word, s);
+                    }
                 }
             }
-            // a delivery wants the column bands finished in ascending order: super-columns of two tile columns
-            rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver ? DELIVER_ORDER_W : 0, deliver ? &sd : nullptr, s);
             if (!rc && deliver) {
                 if (sig->eng) {
                     // The engine works through its queue in submission order.  Inside a plan's replay the groups' transfers are therefore

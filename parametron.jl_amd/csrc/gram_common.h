@@ -12,7 +12,7 @@ constexpr int ST = 128;            // output tile edge
 constexpr int SKC = 256;           // contraction depth per work unit
 constexpr int MAXG = 512;          // upper bound on persistent workgroups
 constexpr int SLOT = ST * ST;      // doubles per partial-tile slot
-constexpr int MAXGROUPS = 16;     // band groups of a host delivery
+constexpr int MAXGROUPS = 16;     // stages (band ranges) of a host delivery
 
 struct SKArgs {
     const double *A; int64_t lda, rows, cols;
@@ -28,19 +28,9 @@ struct SKArgs {
     // Tile order: 0 = super-rows of 4 tile rows (sk_seq_unrank); w > 0 = super-columns of w tile columns (sk_colseq_unrank): the column
     // bands of the output complete in ascending order, which is what a solver hand-off in CSC order wants to ship first.
     int order_w;
-    // Host delivery (pmt_quad_gram_csc_deliver_f64): progress[i] counts the finished work of the tiles whose column band lies in band group i
-    // (bands [gend[i-1], gend[i])) in units of accumulators per thread — a whole tile NACC, a fix-up workgroup its share; the workgroup
-    // that completes a group (count == expect[i]) puts the count back to 0 and stores 0 into *ready[i].
-    unsigned long long *progress;
-    int ngroups;
-    short gend[MAXGROUPS];
-    unsigned long long expect[MAXGROUPS];   // units of a complete group
-    long long *ready[MAXGROUPS];            // the word that is set to 0 when the group is complete: the value of the HSA signal the copy
-                                            // engine's transfer of this group depends on (hsadma.hip), or a flag the courier kernel polls
+    int seq_begin;    // this launch covers the tiles seq_begin .. seq_begin + T' - 1 of the sequence (a staged host delivery launches the
+                      // contraction band range by band range; 0 and all tiles otherwise)
 };
-
-// host delivery of the CSC values: the kernel counts finished tiles per band group (bands [gend[i-1], gend[i])) in progress[i]
-struct SKDeliver { unsigned long long *progress; int ngroups; short gend[MAXGROUPS]; unsigned long long expect[MAXGROUPS]; long long *ready[MAXGROUPS]; };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
 template <int TN>
@@ -117,6 +107,7 @@ __device__ __forceinline__ void sk_colseq_unrank(int idx, int nt, int w, int &jb
     jb = kb = nt - 1;
 }
 
+// idx: position in the tile sequence (a ranged launch adds its seq_begin itself)
 __device__ __forceinline__ void sk_tile_unrank(const SKArgs &g, int idx, int &jb, int &kb) {
     if (g.order_w > 0) sk_colseq_unrank(idx, g.ntiles, g.order_w, jb, kb);
     else sk_seq_unrank(idx, g.ntiles, jb, kb);
@@ -142,16 +133,13 @@ __device__ __forceinline__ void sk_acc_pos(int tid, int r, int &row, int &col) {
 }
 
 // 2*acc -> QuadraticTerm at the canonical upper-triangular position
-__device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, int row, int col, double v, bool system_scope = false) {
+__device__ __forceinline__ void sk_store_term(const SKArgs &g, int jb, int kb, int row, int col, double v) {
     const int64_t n = g.cols;
     const int64_t j = (int64_t)jb * ST + row, k = (int64_t)kb * ST + col;
     if (k >= n || j >= n || j > k) return;
     double c = v;
     if (g.moi || j != k) c = 2 * c;          // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
-    if (g.out_csc) {
-        if (system_scope) __hip_atomic_store(&g.out_csc[k * (k + 1) / 2 + j], g.alpha * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through (host delivery)
-        else g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
-    }
+    if (g.out_csc) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
     if (!g.out_quad) return;
     const int64_t jv = g.xvar[j], kv = g.xvar[k];
     const int64_t pos = j * n - (j * (j - 1)) / 2 + (k - j);

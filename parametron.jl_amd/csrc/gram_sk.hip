@@ -74,26 +74,7 @@ __device__ __forceinline__ int sk_fresh_tid() {
     return t;
 }
 
-// Host delivery: the tile's values are complete in memory before the count of its band group goes up — the delivery instantiation writes
-// them with system-scope write-through stores (sk_epilogue<.., SIGNAL>), so waiting for their acknowledgement is enough and this XCD's L2
-// is not flushed (a release fence at system scope writes back the WHOLE L2).  The workgroup that completes a group stores 0 into the
-// group's `ready` word: the dependency signal of the copy engine's transfer of that group (hsadma.hip), or the courier's flag.
-// `units`: a whole tile counts NACC units, a fix-up workgroup the accumulators it handled.
-__device__ __forceinline__ void sk_signal_tile(const SKArgs &g, int kb, int tid, unsigned long long units) {
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0) {
-        int grp = 0;
-        while (grp + 1 < g.ngroups && kb >= g.gend[grp]) ++grp;
-        const unsigned long long old = __hip_atomic_fetch_add(&g.progress[grp], units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + units == g.expect[grp]) {          // every other contributor's stores were acknowledged before its own count
-            __hip_atomic_store(&g.progress[grp], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.ready[grp], 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
-template <int TN, bool SIGNAL = false>
+template <int TN>
 __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int) {
     using C = Cfg<TN>;
     const int tid = sk_fresh_tid();
@@ -137,8 +118,7 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
                 if (k >= n) break;
                 if (j <= k) {
                     const double v = g.alpha * tile[lane * EPITCH + col];
-                    if (SIGNAL) __hip_atomic_store(&g.out_csc[k * (k + 1) / 2 + j], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through
-                    else g.out_csc[k * (k + 1) / 2 + j] = v;
+                    g.out_csc[k * (k + 1) / 2 + j] = v;
                 }
             }
         }
@@ -441,11 +421,12 @@ int launch_batch_gram(const double *A, int64_t lda, int64_t rows, int64_t cols, 
 }
 
 // ABL: ablation switch for profiling only; results are wrong for ABL != 0; selected with PMT_GRAM_SK_ABLATE.
-// SIGNAL: the host-delivery instantiation (counts finished tiles per band group, sk_signal_tile); everything else is identical.
 // amdgpu_num_vgpr(108): on gfx90a+ the attribute counts in pairs of the unified file, i.e. a budget of 216 registers.  The budget is part
 // of the source (and checked again by tools/kernel_resources.py at build time), not a by-product of which other instantiations share the
 // translation unit; the scheduler settles at 183-187 registers under it (see the knobs at the top of this file).
-template <int TN, int BK, int WPS, int ABL, bool SIGNAL>
+// RANGED: the launch covers the tiles from g.seq_begin on (a stage of a host delivery).  A separate instantiation: the one extra add in the
+// tile numbering of the plain kernel moved its schedule by 1 % (1.192 -> 1.204 ms at n = r = 4096).
+template <int TN, int BK, int WPS, int ABL, bool RANGED>
 __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(108))) void gram_sk_kernel(SKArgs g) {
     using C = Cfg<TN>;
     constexpr int GP = BK + 1;
@@ -466,7 +447,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
             const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
             const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
             int jb, kb;
-            sk_tile_unrank(g, tile, jb, kb);
+            sk_tile_unrank(g, tile + (RANGED ? g.seq_begin : 0), jb, kb);
             const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
             const bool diag = (jb == kb);
             const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
@@ -476,8 +457,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
 
             if (c0 == 0 && c1 == g.nchunk) {
                 static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
-                sk_epilogue<TN, SIGNAL>(g, jb, kb, acc, &lds[0][0][0], tid);
-                if (SIGNAL) sk_signal_tile(g, kb, tid, C::NACC);
+                sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
             } else {
                 // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
                 const int slot = 2 * bid + (u == u0 ? 0 : 1);
@@ -493,11 +473,10 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
-        sk_tile_unrank(g, sk_phase_a_index(g, bid, t), jb, kb);
+        sk_tile_unrank(g, sk_phase_a_index(g, bid, t) + (RANGED ? g.seq_begin : 0), jb, kb);
         double acc[C::NACC];
         sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
-        sk_epilogue<TN, SIGNAL>(g, jb, kb, acc, &lds[0][0][0], tid);
-        if (SIGNAL) sk_signal_tile(g, kb, tid, C::NACC);
+        sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
     }
 
     if (!b_first) phase_b();
@@ -508,7 +487,6 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
 // over up to 256 partials) so that the sum is spread over NACC instead of NACC/4 workgroups per tile
 template <int TN, int APB>
 __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
-    const bool signal = g.progress != nullptr;                                  // host delivery: system-scope stores + a count per workgroup
     using C = Cfg<TN>;
     const int rtile = blockIdx.x;                                              // index among the remainder (split) tiles
     const int tile = g.tfull * g.G + rtile;
@@ -557,14 +535,13 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         for (int r = 0; r < APB; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
-    sk_tile_unrank(g, tile, jb, kb);
+    sk_tile_unrank(g, tile + g.seq_begin, jb, kb);
 #pragma unroll
     for (int r = 0; r < APB; ++r) {
         int row, col;
         sk_acc_pos<TN>(tid, r0 + r, row, col);
-        sk_store_term(g, jb, kb, row, col, acc[r], signal);
+        sk_store_term(g, jb, kb, row, col, acc[r]);
     }
-    if (signal) sk_signal_tile(g, kb, tid, APB);
 }
 
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
@@ -581,15 +558,19 @@ static int env_int(const char *name, int dflt) {
 }
 #endif
 
+// seq_count < 0: all tiles.  Otherwise the launch covers the tiles [seq_begin, seq_begin + seq_count) of the tile sequence (gram_common.h:
+// sk_tile_unrank) — a host delivery runs the contraction band range by band range (gram.hip), every range as its own stream-K launch over
+// the whole chip, so that the copy engine can ship a range while the next one is computed.
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
-                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, const SKDeliver *deliver,
+                   pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
                    hipStream_t s) {
     SKArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
     g.ntiles = (int)cdiv(cols, ST);
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
-    const int64_t T = (int64_t)g.ntiles * (g.ntiles + 1) / 2;
+    const int64_t T = seq_count >= 0 ? seq_count : (int64_t)g.ntiles * (g.ntiles + 1) / 2;      // tiles of this launch
+    g.seq_begin = (int)seq_begin;
     // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16
 #ifdef PMT_TUNING
 #ifdef PMT_TUNING_ABLATE
@@ -612,14 +593,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
     g.ws = reinterpret_cast<double *>(workspace);
     g.order_w = order_w;
-    g.progress = nullptr; g.ngroups = 0;
-    for (int i = 0; i < MAXGROUPS; ++i) { g.gend[i] = 0; g.expect[i] = 0; g.ready[i] = nullptr; }
-    if (deliver) {
-        PMT_REQUIRE(out_csc && deliver->progress && deliver->ngroups >= 1 && deliver->ngroups <= MAXGROUPS, PMT_INVALID_ARGUMENT,
-                    "quad_gram: bad delivery description");
-        g.progress = deliver->progress; g.ngroups = deliver->ngroups;
-        for (int i = 0; i < deliver->ngroups; ++i) { g.gend[i] = deliver->gend[i]; g.expect[i] = deliver->expect[i]; g.ready[i] = deliver->ready[i]; }
-    }
+    if (T <= 0) return PMT_OK;
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
 #ifdef PMT_TUNING_ABLATE
@@ -627,8 +601,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     // the translation unit moves the register allocation of the shipped kernel)
 #define SK_LAUNCH(TN, BK, WPS)                                                                                              \
     do {                                                                                                                    \
-        if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0, true>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
-        else if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1, false>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
+        if (abl == 1) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 1, false>), grid, dim3(Cfg<TN>::NT), 0, s, g);  \
         else if (abl == 2) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 2, false>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else if (abl == 3) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 3, false>), grid, dim3(Cfg<TN>::NT), 0, s, g); \
         else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<TN, BK, WPS, 0, false>), grid, dim3(Cfg<TN>::NT), 0, s, g);       \
@@ -637,9 +610,10 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     else SK_LAUNCH(2, 16, PMT_SK_WPS);
 #undef SK_LAUNCH
 #else
-    // Two instantiations that differ only in the per-tile progress count of a host delivery.  (The 32-row-stage instantiation used for
-    // tall matrices in rounds 1-2 spilled 49 VGPRs — +1 % at r = 16384 when it was introduced — and is gone: all shapes take 16-row stages.)
-    if (deliver) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, PMT_SK_BK, PMT_SK_WPS, 0, true>), grid, dim3(Cfg<2>::NT), 0, s, g);
+    // Two instantiations, plain and ranged.  (The 32-row-stage instantiation used for tall matrices in rounds 1-2 spilled 49 VGPRs — +1 % at r = 16384 when it
+    // was introduced — and is gone: all shapes take 16-row stages.  So is the delivery instantiation that counted finished tiles per band
+    // group inside the kernel: a delivery is now a sequence of plain launches, gram.hip.)
+    if (seq_count >= 0) PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, PMT_SK_BK, PMT_SK_WPS, 0, true>), grid, dim3(Cfg<2>::NT), 0, s, g);
     else PMT_LAUNCH_NAMED("gram_sk_kernel", (gram_sk_kernel<2, PMT_SK_BK, PMT_SK_WPS, 0, false>), grid, dim3(Cfg<2>::NT), 0, s, g);
 #endif
     int rc = check_launch("gram_sk_kernel");

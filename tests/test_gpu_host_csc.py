@@ -87,7 +87,7 @@ def test_host_csc_equals_moi_boundary():
 @pytest.mark.parametrize("rows,cols,ngroups", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 5)])
 def test_deliver_entry_point_matches_plain_csc(rows, cols, ngroups):
     """C ABI: pmt_quad_gram_csc_deliver_f64 — the host array equals the device array of the same call bit for bit, both equal
-    pmt_quad_gram_csc_f64's values (1e-13: the tile order differs), and q / constant are identical"""
+    pmt_quad_gram_csc_f64's values (1e-13: a stage splits its tiles along the contraction and adds two half sums), and q / constant are identical"""
     L = lib()
     s = stream()
     A = torch.empty(rows * cols, dtype=torch.float64, device=DEV)
@@ -104,13 +104,16 @@ def test_deliver_entry_point_matches_plain_csc(rows, cols, ngroups):
             hp = C.c_void_p()
             _lib.call("pmt_host_alloc", 8 * nq, C.byref(hp))
             host = np.frombuffer((C.c_char * (8 * nq)).from_address(hp.value), dtype=np.float64)
-            for rep in range(3):                          # repeated calls: the counters come back to zero by themselves
+            prev = None
+            for rep in range(3):                          # repeated calls: the signals are re-armed, the staged summation order is fixed
                 host[:] = np.nan
                 _lib.call("pmt_quad_gram_csc_deliver_f64", ptr(A), rows, rows, cols, ptr(xvar), ptr(b), -1, None, 1.0, ptr(Pv), hp, ngroups,
                           ptr(lin), ptr(const), ptr(ws), s)
                 _lib.call("pmt_fetch_synchronize", s)
                 torch.cuda.synchronize()
                 assert np.array_equal(host, Pv.cpu().numpy()), "delivered values differ from the device buffer (repeat %d)" % rep
+                assert prev is None or np.array_equal(host, prev), "a staged delivery is deterministic: same bits every time"
+                prev = host.copy()
             outs.append((host.copy(), lin.cpu().numpy(), const.cpu().numpy()))
             _lib.call("pmt_host_free", hp)
         else:
