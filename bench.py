@@ -650,7 +650,14 @@ def main():
             rc = guarded(constraint_pack_microbench, torch, _lib, wl)
             if isinstance(rc, dict) and "avg_ms" in rc:
                 rc["in_step_event_ms"] = v["avg_ms"]
-                rc["note"] = "stand-alone launches of the step's constraint-pack kernel; in_step_event_ms includes the in-stream gap before it"
+                # the same kernel where it runs — between the contraction's fix-up pass and the end of the step; the HIP events around an
+                # in-step launch include the in-stream gap in front of it, so this fraction is a lower bound (rocprofv3 of the same command:
+                # profiles/rNN_c2_rocprofv3_timed_region.txt)
+                rc["in_step"] = {"avg_ms": v["avg_ms"], "achieved": rc["algorithmic_bytes"] / (v["avg_ms"] * 1e-3) / 1e9 if "algorithmic_bytes" in rc else None,
+                                 "unit": "GB/s"}
+                if rc["in_step"]["achieved"]:
+                    rc["in_step"]["frac"] = rc["in_step"]["achieved"] / HBM_PEAK_GBS
+                rc["note"] = "stand-alone launches of the step's constraint-pack kernel; in_step = the launch inside the timed step (events include the in-stream gap before it)"
             out["roofline_constraint_pack"] = rc
         elif bg:
             # side lane: the constraint block is packed by the <= 16-VGPR background kernel INSIDE the contraction; its duration is time spent
