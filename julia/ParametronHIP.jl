@@ -192,6 +192,10 @@ sparse_assemble_blocks!(out_terms::DevPtr, nzval::DevPtr, desc::DevPtr, idx::Dev
                 (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Ptr{Cvoid}),
                 nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, out_terms, stream))
 
+"out[i] = 0.0 (+|-) d[i] (sign -1 / +1): the constants of C*x (+|-) d (src/functions.jl:751-764)"
+consts!(out::DevPtr, d::DevPtr, n, sign, stream) =
+    check(ccall((:pmt_consts_f64, lib), Cint, (DevPtr, Int64, Cint, DevPtr, Ptr{Cvoid}), d, n, sign, out, stream))
+
 "dst (cols x rows, leading dimension ldd) = transpose of src (rows x cols, leading dimension lds) — the adjoint rule, src/lazyexpression.jl:206-217"
 transpose!(dst::DevPtr, ldd, src::DevPtr, lds, rows, cols, stream) =
     check(ccall((:pmt_transpose_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, Int64, Ptr{Cvoid}), src, lds, rows, cols, dst, ldd, stream))

@@ -45,6 +45,7 @@ import Parametron.Functions
 import MathOptInterface
 const MOI = MathOptInterface
 using LinearAlgebra
+using SparseArrays
 
 import ..ParametronHIP
 const H = ParametronHIP
@@ -61,6 +62,7 @@ mutable struct DeviceParameter
     ld::Int              # leading dimension of the device copy (rows rounded up to 16, + 64 when a multiple of 512: DESIGN.md §2)
     host::Vector{Float64}             # page-locked staging copy of the value (dense, column-major): the asynchronous upload reads it
     staging::NTuple{2, DevPtr}        # one device staging buffer per slot (pmt_plan_stage_slot)
+    nnz::Int             # > 0: a SparseMatrixCSC with a FIXED pattern — buf / host / staging hold nzval only (BASELINE config 5)
 end
 
 padded_rows(r) = r >= 64 ? 16 * cld(r, 16) : r
@@ -68,17 +70,22 @@ padded_ld(r) = (p = padded_rows(r); p >= 512 && p % 512 == 0 ? p + 64 : p)
 
 function DeviceParameter(plan::H.Plan, p::Parameter)
     val = p()
-    if val isa AbstractMatrix
+    if val isa SparseMatrixCSC{Float64, Int64}
+        r, c = size(val)
+        nz = length(val.nzval)
+        bytes = 8 * max(nz, 1)
+        return DeviceParameter(p, H.alloc(plan, bytes), r, c, r, H.host_alloc(max(nz, 1)), (H.alloc(plan, bytes), H.alloc(plan, bytes)), nz)
+    elseif val isa AbstractMatrix
         r, c = size(val)
         ld = padded_ld(r)
         bytes = 8 * ld * max(c, 1)
-        return DeviceParameter(p, H.alloc(plan, bytes), r, c, ld, H.host_alloc(r * c), (H.alloc(plan, bytes), H.alloc(plan, bytes)))     # zero filled: the padding rows stay zero
+        return DeviceParameter(p, H.alloc(plan, bytes), r, c, ld, H.host_alloc(r * c), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0)     # zero filled: the padding rows stay zero
     elseif val isa AbstractVector
         r = length(val)
         bytes = 8 * max(padded_rows(r), 1)
-        return DeviceParameter(p, H.alloc(plan, bytes), r, 0, padded_rows(r), H.host_alloc(r), (H.alloc(plan, bytes), H.alloc(plan, bytes)))
+        return DeviceParameter(p, H.alloc(plan, bytes), r, 0, padded_rows(r), H.host_alloc(r), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0)
     elseif val isa Number
-        return DeviceParameter(p, H.alloc(plan, 8), 1, -1, 1, H.host_alloc(1), (H.alloc(plan, 8), H.alloc(plan, 8)))
+        return DeviceParameter(p, H.alloc(plan, 8), 1, -1, 1, H.host_alloc(1), (H.alloc(plan, 8), H.alloc(plan, 8)), 0)
     end
     throw(ArgumentError("Parameters of type $(typeof(val)) are not supported on the device"))
 end
@@ -88,7 +95,11 @@ end
 `slot`; `commit!` consumes it on the plan's stream"""
 function refresh!(plan::H.Plan, d::DeviceParameter, slot::Int)
     val = d.param()
-    if d.cols > 0
+    if d.nnz > 0
+        length(val.nzval) == d.nnz || throw(DimensionMismatch("the sparsity pattern of a sparse Parameter must stay fixed"))
+        copyto!(d.host, val.nzval)                      # the pattern is fixed (checked by length; rowval / colptr are the plan's)
+        H.stage_upload!(plan, d.staging[slot + 1], d.host)
+    elseif d.cols > 0
         copyto!(d.host, val)
         H.stage_upload_pitched!(plan, d.staging[slot + 1], d.ld, d.host, d.rows, d.cols)
     elseif d.cols == 0
@@ -102,7 +113,7 @@ function refresh!(plan::H.Plan, d::DeviceParameter, slot::Int)
 end
 
 function commit!(plan::H.Plan, d::DeviceParameter, slot::Int)
-    H.commit_staged!(plan, d.buf, d.staging[slot + 1], d.cols > 0 ? 8 * d.ld * d.cols : 8 * max(d.ld, 1))
+    H.commit_staged!(plan, d.buf, d.staging[slot + 1], d.nnz > 0 ? 8 * d.nnz : (d.cols > 0 ? 8 * d.ld * d.cols : 8 * max(d.ld, 1)))
     nothing
 end
 
@@ -160,6 +171,14 @@ function analyse_affine(arg)::DenseAffine
     throw(Unsupported("builder $(e.f)"))
 end
 
+"C*x (+|-) d for a SparseMatrixCSC Parameter C with a fixed pattern (BASELINE config 5): terms for the structural non-zeros only, row-major"
+struct SparseAffine
+    C::Parameter
+    x::Vector{Variable}
+    d::Union{Nothing, Parameter}
+    sign::Int
+end
+
 "x (+|-) l for x::Vector{Variable} and a vector Parameter l: one term (1.0, x[i]) per row (src/lazyexpression.jl:249-258 -> vecsubtract!, src/functions.jl:421)"
 struct VarBounds
     x::Vector{Variable}
@@ -174,7 +193,22 @@ struct ScaledAffine
 end
 
 "one piece of a constraint function: what `analyse_piece` understands"
-const Piece = Union{DenseAffine, VarBounds, ScaledAffine}
+const Piece = Union{DenseAffine, VarBounds, ScaledAffine, SparseAffine}
+
+is_sparse_param(a) = a isa Parameter && a() isa SparseMatrixCSC{Float64, Int64}
+
+function analyse_sparse(e::LazyExpression)::Union{Nothing, SparseAffine}
+    if e.f === Functions.matvecmul! && length(e.args) == 3 && e.args[3] isa Vector{Variable} && is_sparse_param(e.args[2])
+        return SparseAffine(e.args[2], e.args[3], nothing, 0)
+    elseif (e.f === Functions.vecsubtract! || e.f === Functions.vecadd!) && length(e.args) == 3 && e.args[3] isa Parameter
+        inner = unwrap(e.args[2])
+        if inner isa LazyExpression
+            sp = analyse_sparse(inner)
+            sp !== nothing && sp.d === nothing && return SparseAffine(sp.C, sp.x, e.args[3], e.f === Functions.vecsubtract! ? -1 : 1)
+        end
+    end
+    nothing
+end
 
 function analyse_piece(arg)::Piece
     e = unwrap(arg)
@@ -184,6 +218,8 @@ function analyse_piece(arg)::Piece
     elseif e.f === Functions.scale! && length(e.args) == 3 && e.args[2] isa Parameter && e.args[2]() isa Number
         return ScaledAffine(e.args[2], analyse_affine(e.args[3]))
     end
+    sp = analyse_sparse(e)
+    sp !== nothing && return sp
     analyse_affine(e)
 end
 
@@ -353,6 +389,8 @@ end
 
 piece_rows(hm::HIPModel, p::DenseAffine) = (d = device_param!(hm, p.A); p.transposed ? d.cols : d.rows)
 piece_rows(hm::HIPModel, p::VarBounds) = length(p.x)
+piece_rows(hm::HIPModel, p::SparseAffine) = device_param!(hm, p.C).rows
+piece_terms(hm::HIPModel, p::SparseAffine) = device_param!(hm, p.C).nnz
 piece_rows(hm::HIPModel, p::ScaledAffine) = piece_rows(hm, p.inner)
 piece_terms(hm::HIPModel, p::DenseAffine) = (d = device_param!(hm, p.A); d.rows * d.cols)
 piece_terms(hm::HIPModel, p::VarBounds) = length(p.x)
@@ -364,6 +402,28 @@ function record_piece!(hm::HIPModel, p::DenseAffine, terms::DevPtr, constants::D
     xvar = upload_indices(hm.plan, Int64[v.index for v in p.x])
     b = p.b === nothing ? DevPtr(C_NULL) : device_param!(hm, p.b).buf
     H.affine_pack_vector!(terms + 24 * t0, constants + 8 * row0, A, lda, r, n, xvar, b, p.sign, hm.varmap, row0, rec)
+end
+"""sparse block: the row-major order of the pattern is worked out once (pmt_sparse_rowmajor_order); per re-evaluation one launch scatters nzval into
+the MOI terms — the block form (CSC -> row-major through LDS, 36 bytes per non-zero) where the pattern allows it and a row's share of a column
+band is long enough to be written as a run, the slab form (one column slab per XCD) otherwise; constants 0 (+|-) d by pmt_consts_f64"""
+function record_piece!(hm::HIPModel, p::SparseAffine, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
+    d = device_param!(hm, p.C)
+    C = p.C()
+    plan = H.sparse_plan(C)
+    xmap = Int64[hm.model.model_var_to_optimizer[v.index].value for v in p.x]          # the optimizer's index of every column's variable
+    blk = H.sparse_block_plan(C, plan)
+    ncb = blk.cw > 0 ? cld(d.cols, blk.cw) : 0
+    if blk.cw > 0 && d.nnz >= 16 * d.rows * ncb
+        desc, idx, band = H.alloc(hm.plan, 8 * length(blk.desc)), H.alloc(hm.plan, 4 * max(length(blk.idx), 1)), H.alloc(hm.plan, 8 * length(blk.band_ptr))
+        H.upload!(hm.plan, desc, blk.desc); H.upload!(hm.plan, idx, blk.idx); H.upload!(hm.plan, band, blk.band_ptr)
+        H.sparse_pack_vector_blocks!(terms + 24 * t0, d.buf, desc, idx, band, upload_indices(hm.plan, xmap), d.rows, d.cols, d.nnz, blk.cw, DevPtr(C_NULL), row0, rec)
+    else
+        perm, slab = upload_indices(hm.plan, plan.perm), upload_indices(hm.plan, plan.slab_ptr)
+        tvar = upload_indices(hm.plan, Int64[xmap[c] for c in plan.term_col[1:max(d.nnz, 0)]])
+        H.sparse_pack_vector!(terms + 24 * t0, d.buf, perm, tvar, slab, d.rows, 8, DevPtr(C_NULL), row0, rec)
+    end
+    # without a d the constants keep the zeros the plan's allocation was filled with
+    p.d === nothing || H.consts!(constants + 8 * row0, device_param!(hm, p.d).buf, d.rows, p.sign, rec)
 end
 function record_piece!(hm::HIPModel, p::VarBounds, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
     xvar = upload_indices(hm.plan, Int64[v.index for v in p.x])
