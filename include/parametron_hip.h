@@ -340,7 +340,8 @@ int pmt_sparse_assemble_slabs_u32_f64(const double *nzval, const uint32_t *perm,
  * the coefficients of its block with coalesced loads (the rows of a CSC column ascend, so a column's part of a block is one contiguous run
  * of nzval) into LDS and writes each row's terms of the column band from there.  No per-term gather from HBM / L2 and a 4-byte instead of
  * an 8-byte static index per term: 36 bytes per non-zero.  The variable word of a term comes from the per-COLUMN array col_var[cols]
- * (x[col]; with `varmap` non-null varmap[col_var[col] - 1] as in moi_interop.jl:64-81).
+ * (x[col]; with `varmap` non-null varmap[col_var[col] - 1] as in moi_interop.jl:64-81).  out_consts (optional) = 0.0 (+|-) d[row], the
+ * constants of C*x (+|-) d, written by the same launch (d may be NULL with sign 0: zeros).
  * Host helpers, once per pattern:
  *   pmt_sparse_blocks_width  -> *out_cw = the widest band width (power of two, 32..1024) whose blocks all fit the kernel's LDS buffer,
  *                               or 0 when the form does not apply (rows not ascending within a column, 2^32 or more non-zeros, empty matrix):
@@ -353,10 +354,11 @@ int pmt_sparse_blocks_build(int64_t m, int64_t n, const int64_t *host_colptr, co
                             int64_t *host_band_ptr);
 int pmt_sparse_pack_vector_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
                                       const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const int64_t *varmap,
-                                      int64_t row_offset, pmt_vector_affine_term *out_terms, void *stream);
+                                      int64_t row_offset, const double *d, int sign, pmt_vector_affine_term *out_terms,
+                                      double *out_consts, void *stream);
 int pmt_sparse_assemble_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
-                                   const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, pmt_linear_term *out_terms,
-                                   void *stream);
+                                   const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const double *d, int sign,
+                                   pmt_linear_term *out_terms, double *out_consts, void *stream);
 /* constants of the same node: out[i] = 0.0 (+|-) d[i]  (vecadd!/vecsubtract! on zero!'d functions, src/functions.jl:244,452,474) */
 int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream);
 

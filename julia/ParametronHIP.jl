@@ -179,18 +179,20 @@ function sparse_block_plan(C::SparseMatrixCSC{Float64,Int64}, plan)
     (cw = Int(cw[]), desc = desc, idx = idx, band_ptr = band)
 end
 
-"C*x (+|-) d for a sparse C written straight into MOI.VectorAffineTerms, block form: `col_var[c]` = x[c] (or varmap[x[c]] with `varmap = C_NULL`)"
-sparse_pack_vector_blocks!(out_terms::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols, nnz, cw,
-                           varmap::DevPtr, row_offset, stream) =
+"C*x (+|-) d for a sparse C written straight into MOI.VectorAffineTerms, block form: `col_var[c]` = x[c] (or varmap[x[c]] with `varmap = C_NULL`);
+the constants 0 (+|-) d come out of the same launch (`d = C_NULL`, `sign = 0`: zeros; `out_consts = C_NULL`: not written)"
+sparse_pack_vector_blocks!(out_terms::DevPtr, out_consts::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols,
+                           nnz, cw, varmap::DevPtr, row_offset, d::DevPtr, sign, stream) =
     check(ccall((:pmt_sparse_pack_vector_blocks_f64, lib), Cint,
-                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Int64, DevPtr, Ptr{Cvoid}),
-                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, varmap, row_offset, out_terms, stream))
+                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Int64, DevPtr, Cint, DevPtr, DevPtr, Ptr{Cvoid}),
+                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, varmap, row_offset, d, sign, out_terms, out_consts, stream))
 
 "native LinearTerms of the same node, block form"
-sparse_assemble_blocks!(out_terms::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols, nnz, cw, stream) =
+sparse_assemble_blocks!(out_terms::DevPtr, out_consts::DevPtr, nzval::DevPtr, desc::DevPtr, idx::DevPtr, band_ptr::DevPtr, col_var::DevPtr, rows, cols, nnz,
+                        cw, d::DevPtr, sign, stream) =
     check(ccall((:pmt_sparse_assemble_blocks_f64, lib), Cint,
-                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Ptr{Cvoid}),
-                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, out_terms, stream))
+                (DevPtr, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Cint, DevPtr, Cint, DevPtr, DevPtr, Ptr{Cvoid}),
+                nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, d, sign, out_terms, out_consts, stream))
 
 "out[i] = 0.0 (+|-) d[i] (sign -1 / +1): the constants of C*x (+|-) d (src/functions.jl:751-764)"
 consts!(out::DevPtr, d::DevPtr, n, sign, stream) =

@@ -416,14 +416,16 @@ function record_piece!(hm::HIPModel, p::SparseAffine, terms::DevPtr, constants::
     if blk.cw > 0 && d.nnz >= 16 * d.rows * ncb
         desc, idx, band = H.alloc(hm.plan, 8 * length(blk.desc)), H.alloc(hm.plan, 4 * max(length(blk.idx), 1)), H.alloc(hm.plan, 8 * length(blk.band_ptr))
         H.upload!(hm.plan, desc, blk.desc); H.upload!(hm.plan, idx, blk.idx); H.upload!(hm.plan, band, blk.band_ptr)
-        H.sparse_pack_vector_blocks!(terms + 24 * t0, d.buf, desc, idx, band, upload_indices(hm.plan, xmap), d.rows, d.cols, d.nnz, blk.cw, DevPtr(C_NULL), row0, rec)
+        dd = p.d === nothing ? DevPtr(C_NULL) : device_param!(hm, p.d).buf
+        H.sparse_pack_vector_blocks!(terms + 24 * t0, constants + 8 * row0, d.buf, desc, idx, band, upload_indices(hm.plan, xmap), d.rows, d.cols, d.nnz, blk.cw,
+                                     DevPtr(C_NULL), row0, dd, p.d === nothing ? 0 : p.sign, rec)
     else
         perm, slab = upload_indices(hm.plan, plan.perm), upload_indices(hm.plan, plan.slab_ptr)
         tvar = upload_indices(hm.plan, Int64[xmap[c] for c in plan.term_col[1:max(d.nnz, 0)]])
         H.sparse_pack_vector!(terms + 24 * t0, d.buf, perm, tvar, slab, d.rows, 8, DevPtr(C_NULL), row0, rec)
+        # without a d the constants keep the zeros the plan's allocation was filled with
+        p.d === nothing || H.consts!(constants + 8 * row0, device_param!(hm, p.d).buf, d.rows, p.sign, rec)
     end
-    # without a d the constants keep the zeros the plan's allocation was filled with
-    p.d === nothing || H.consts!(constants + 8 * row0, device_param!(hm, p.d).buf, d.rows, p.sign, rec)
 end
 function record_piece!(hm::HIPModel, p::VarBounds, terms::DevPtr, constants::DevPtr, t0::Int, row0::Int, rec)
     xvar = upload_indices(hm.plan, Int64[v.index for v in p.x])

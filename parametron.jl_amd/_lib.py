@@ -94,8 +94,8 @@ SIGNATURES = {
     "pmt_sparse_assemble_slabs_u32_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _ci, _vp, _vp]),
     "pmt_sparse_blocks_width": (_ci, [_i64, _i64, _vp, _vp, _vp]),
     "pmt_sparse_blocks_build": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _vp, _vp]),
-    "pmt_sparse_pack_vector_blocks_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _i64, _vp, _vp]),
-    "pmt_sparse_assemble_blocks_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _vp]),
+    "pmt_sparse_pack_vector_blocks_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _i64, _vp, _ci, _vp, _vp, _vp]),
+    "pmt_sparse_assemble_blocks_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _ci, _vp, _ci, _vp, _vp, _vp]),
     "pmt_batch_lsq_slab_doubles": (_i64, [_i64, _i64]),
     "pmt_batch_lsq_coeffs_f64": (_ci, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _i64, _vp]),
     "pmt_batch_expand_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

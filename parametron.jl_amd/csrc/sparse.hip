@@ -142,7 +142,7 @@ template <bool VAT_OUT>
 __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void sparse_block_kernel(
     const double *__restrict__ nzval, const uint2 *__restrict__ desc, const uint32_t *__restrict__ idx, const int64_t *__restrict__ band_ptr,
     const int64_t *__restrict__ col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, int nrb, int ncb, const int64_t *__restrict__ varmap,
-    int64_t row_offset, unsigned long long *__restrict__ out) {
+    int64_t row_offset, unsigned long long *__restrict__ out, const double *__restrict__ d, int sign, double *__restrict__ out_consts) {
     typedef unsigned long long u64;
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     constexpr int W = VAT_OUT ? 3 : 2;                           // 8-byte words per term
@@ -161,6 +161,11 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     const int b = blockIdx.x;
     const int cb = (b / (8 * nrb)) * 8 + (b & 7), rb = (b >> 3) % nrb;
     if (cb >= ncb) return;
+    // the constants of the node, 0.0 (+|-) d[row]: by the blocks of the first column band (one launch less: 6 us of config 5's 43)
+    if (cb == 0 && out_consts && tid < SB_RB) {
+        const int64_t row = (int64_t)rb * SB_RB + tid;
+        if (row < rows) out_consts[row] = signed_const(d ? d[row] : 0.0, d ? sign : 0);
+    }
     const int64_t c0 = (int64_t)cb * cw;
     const int ncol = (int)min((int64_t)cw, cols - c0);
     const int64_t wrow0 = (int64_t)rb * SB_RB + wave * R;        // first row of this wave
@@ -467,9 +472,12 @@ extern "C" int pmt_sparse_blocks_build(int64_t m, int64_t n, const int64_t *colp
 
 static int launch_sparse_blocks(bool vat, const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
                                 const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const int64_t *varmap, int64_t row_offset, void *out,
-                                void *stream) {
+                                const double *d, int sign, double *out_consts, void *stream) {
     PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "sparse_pack_blocks: negative dimension");
     PMT_REQUIRE(nnz >= 0 && nnz < ((int64_t)1 << 32), PMT_DIMENSION_MISMATCH, "sparse_pack_blocks: bad number of non-zeros");
+    PMT_REQUIRE(sign >= -1 && sign <= 1 && (sign == 0 || d || !out_consts), PMT_INVALID_ARGUMENT, "sparse_pack_blocks: sign must be -1, 0 or +1 and needs d");
+    if (rows > 0 && out_consts && (cols == 0 || nnz == 0)) return d && sign ? pmt_consts_f64(d, rows, sign, out_consts, stream)
+        : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
     if (rows == 0 || cols == 0 || nnz == 0) return PMT_OK;
     PMT_REQUIRE(cw >= 32 && cw <= SB_MAXCW && (cw & (cw - 1)) == 0, PMT_INVALID_ARGUMENT, "sparse_pack_blocks: bad band width");
     PMT_REQUIRE(nzval && desc && idx && band_ptr && col_var && out, PMT_INVALID_ARGUMENT, "sparse_pack_blocks: null pointer");
@@ -477,23 +485,25 @@ static int launch_sparse_blocks(bool vat, const double *nzval, const uint64_t *d
     PMT_REQUIRE(cdiv(ncb, 8) * 8 * nrb < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH, "sparse_pack_blocks: too many blocks");
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)(cdiv(ncb, 8) * 8 * nrb);
-        const uint2 *d = reinterpret_cast<const uint2 *>(desc);
-        if (vat) PMT_LAUNCH_NAMED("sparse_block_kernel<VAT>", (sparse_block_kernel<true>), dim3(blocks), dim3(SB_NT), 0, s, nzval, d, idx, band_ptr, col_var,
-                                  rows, cols, nnz, cw, (int)nrb, (int)ncb, varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
-        else PMT_LAUNCH_NAMED("sparse_block_kernel<LT>", (sparse_block_kernel<false>), dim3(blocks), dim3(SB_NT), 0, s, nzval, d, idx, band_ptr, col_var,
-                              rows, cols, nnz, cw, (int)nrb, (int)ncb, varmap, row_offset, reinterpret_cast<unsigned long long *>(out));
+        const uint2 *dd = reinterpret_cast<const uint2 *>(desc);
+        if (vat) PMT_LAUNCH_NAMED("sparse_block_kernel<VAT>", (sparse_block_kernel<true>), dim3(blocks), dim3(SB_NT), 0, s, nzval, dd, idx, band_ptr, col_var,
+                                  rows, cols, nnz, cw, (int)nrb, (int)ncb, varmap, row_offset, reinterpret_cast<unsigned long long *>(out), d, sign, out_consts);
+        else PMT_LAUNCH_NAMED("sparse_block_kernel<LT>", (sparse_block_kernel<false>), dim3(blocks), dim3(SB_NT), 0, s, nzval, dd, idx, band_ptr, col_var,
+                              rows, cols, nnz, cw, (int)nrb, (int)ncb, varmap, row_offset, reinterpret_cast<unsigned long long *>(out), d, sign, out_consts);
         return check_launch("sparse_block_kernel");
     });
 }
 
 extern "C" int pmt_sparse_pack_vector_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
                                                  const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const int64_t *varmap,
-                                                 int64_t row_offset, pmt_vector_affine_term *out_terms, void *stream) {
-    return launch_sparse_blocks(true, nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, varmap, row_offset, out_terms, stream);
+                                                 int64_t row_offset, const double *d, int sign, pmt_vector_affine_term *out_terms,
+                                                 double *out_consts, void *stream) {
+    return launch_sparse_blocks(true, nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, varmap, row_offset, out_terms, d, sign, out_consts, stream);
 }
 
 extern "C" int pmt_sparse_assemble_blocks_f64(const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,
-                                              const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, pmt_linear_term *out_terms,
-                                              void *stream) {
-    return launch_sparse_blocks(false, nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, (const int64_t *)nullptr, 0, out_terms, stream);
+                                              const int64_t *col_var, int64_t rows, int64_t cols, int64_t nnz, int cw, const double *d, int sign,
+                                              pmt_linear_term *out_terms, double *out_consts, void *stream) {
+    return launch_sparse_blocks(false, nzval, desc, idx, band_ptr, col_var, rows, cols, nnz, cw, (const int64_t *)nullptr, 0, out_terms, d, sign, out_consts,
+                                stream);
 }

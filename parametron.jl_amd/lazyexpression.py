@@ -422,7 +422,9 @@ def _emit_sparse_terms(c, out):
     sp = out.spmat
     if sp.block_cw:
         c.call("pmt_sparse_assemble_blocks_f64", P(sp.buf), P(sp.block_desc_buf), P(sp.block_idx_buf), P(sp.block_band_buf), P(out.xvars.buf),
-               sp.rows, sp.cols, sp.nnz, sp.block_cw, P(out.terms))
+               sp.rows, sp.cols, sp.nnz, sp.block_cw, P(out.vec.buf) if out.vec is not None else None, out.sign if out.vec is not None else 0,
+               P(out.terms), P(out.consts) if out.vec is not None else None)
+        return
     else:
         c.call("pmt_sparse_assemble_slabs_u32_f64" if sp.narrow else "pmt_sparse_assemble_slabs_f64", P(sp.buf), P(sp.perm_buf), P(out.term_var_buf),
                P(sp.slab_ptr_buf), sp.rows, sp.nslab, P(out.terms))

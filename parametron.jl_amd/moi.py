@@ -277,10 +277,10 @@ class _Record:
                 refresh(handoff_varmap)
 
                 def emit(c):
+                    # terms and constants (0 (+|-) d) in one launch
                     c.call("pmt_sparse_pack_vector_blocks_f64", P(sp.buf), P(sp.block_desc_buf), P(sp.block_idx_buf), P(sp.block_band_buf), P(colvar),
-                           sp.rows, sp.cols, sp.nnz, sp.block_cw, None, 0, P(dt))
-                    if out.vec is not None:
-                        c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
+                           sp.rows, sp.cols, sp.nnz, sp.block_cw, None, 0, P(out.vec.buf) if out.vec is not None else None,
+                           out.sign if out.vec is not None else 0, P(dt), P(dc))
                 return emit
             mapped = ctx.alloc((4 if sp.narrow else 8) * max(sp.nnz, 1))
 

@@ -219,19 +219,23 @@ def test_block_kernels_equal_the_flat_scatter(m, n, density, kw):
     got = torch.zeros(nnz * 3, dtype=torch.int64, device=dev)
     want_lt = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
     got_lt = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
+    dvec = torch.from_numpy(rng.random(m) - 0.5).to(dev)                        # d of C*x - d: the constants come out of the same launch
+    gconst = torch.full((m,), 7.0, dtype=torch.float64, device=dev)
+    gconst_lt = torch.full((m,), 7.0, dtype=torch.float64, device=dev)
     for _ in range(2):                                               # second pass with new coefficients: same structure, new values
         _lib.call("pmt_sparse_pack_vector_f64", dp(nz), dp(dperm), dp(drow), dp(dtvar), nnz, dp(dvarmap), 7, dp(want), stream)
-        _lib.call("pmt_sparse_pack_vector_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(dvarmap), 7, dp(got), stream)
+        _lib.call("pmt_sparse_pack_vector_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(dvarmap), 7, dp(dvec), -1, dp(got), dp(gconst), stream)
         _lib.call("pmt_sparse_assemble_f64", dp(nz), dp(dperm), dp(dtvar), nnz, dp(want_lt), stream)
-        _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(got_lt), stream)
+        _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, None, 0, dp(got_lt), dp(gconst_lt), stream)
         torch.cuda.synchronize()
         assert torch.equal(got, want) and torch.equal(got_lt, want_lt)
+        assert torch.equal(gconst, 0.0 - dvec) and torch.equal(gconst_lt, torch.zeros_like(gconst_lt))      # 0 - d (src/functions.jl:751-764); no d: zeros
         nz.copy_(torch.from_numpy(rng.random(nnz) + 0.5).to(dev))
     # against the pattern itself: row-major (row, col) order, coefficients of the CSR form
     g = got_lt.cpu().numpy().reshape(-1, 2)
     csr = sp.csc_matrix((nz.cpu().numpy(), csc.indices, csc.indptr), shape=(m, n)).tocsr()
     csr.sort_indices()
-    _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(got_lt), stream)
+    _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, None, 0, dp(got_lt), dp(gconst_lt), stream)
     torch.cuda.synchronize()
     g = got_lt.cpu().numpy().reshape(-1, 2)
     assert np.array_equal(g[:, 0].view(np.float64), csr.data) and np.array_equal(g[:, 1], xvar[csr.indices])

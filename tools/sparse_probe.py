@@ -72,10 +72,10 @@ def main():
     outlt4 = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
 
     def pack_blocks():
-        _lib.call("pmt_sparse_pack_vector_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, None, 0, dptr(out4), stream)
+        _lib.call("pmt_sparse_pack_vector_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, None, 0, None, 0, dptr(out4), None, stream)
 
     def assemble_blocks():
-        _lib.call("pmt_sparse_assemble_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, dptr(outlt4), stream)
+        _lib.call("pmt_sparse_assemble_blocks_f64", dptr(nz), dptr(ddesc), dptr(didx), dptr(dband), dptr(colvar), m, n, nnz, cw, None, 0, dptr(outlt4), None, stream)
     pack_blocks(); assemble_blocks()
     pack_slabs_u32_premapped()
     pack(); assemble(); pack_slabs(); assemble_slabs()
