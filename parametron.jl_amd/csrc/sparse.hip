@@ -195,10 +195,10 @@ __global__ __launch_bounds__(SB_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int c = grp + 64 * q;
-        const uint2 d = c < ncol ? s_desc[c] : make_uint2(0u, 0u);
-        dl[q] = d.y;
-        const int len = (int)(d.y & 0xffffu);
-        const int64_t p = (int64_t)d.x + sub2;
+        const uint2 cd = c < ncol ? s_desc[c] : make_uint2(0u, 0u);
+        dl[q] = cd.y;
+        const int len = (int)(cd.y & 0xffffu);
+        const int64_t p = (int64_t)cd.x + sub2;
         v[q].x = 0.0; v[q].y = 0.0;
         if (sub2 < len) {
             if (p + 1 < nnz) v[q] = *reinterpret_cast<const f64x2u *>(nzval + p);     // the second one may belong to the next block: not stored
