@@ -106,8 +106,8 @@ namespace pmt {
 // One non-blocking side stream + fork/join events PER CALLING STREAM (= per plan: a plan is one stream), created on first use on the
 // calling stream's device.  Two plans driven from two host threads therefore never share an event (different plans are
 // independent); calls on ONE stream must be serialised by the caller, as for any HIP stream.
-// `counters` (library-owned device memory, zeroed once here, put back to zero by the courier kernel): the progress counts of a host
-// delivery (MAXGROUPS x u64) and the courier's own completion count / error flag — calls on one stream are serialised, so one set per
+// `counters` (library-owned device memory, zeroed once here, re-armed by the courier kernel): the courier's per-group flags of a host
+// delivery (MAXGROUPS x i64) and its own completion count / error flag — calls on one stream are serialised, so one set per
 // calling stream is enough.
 // `fetch` is the calling stream's DEVICE-TO-HOST stream (created on first use, highest priority so that it has a hardware queue of its
 // own class): recorded fetches (pmt_plan_record_fetch) and the band-wise delivery of pmt_quad_gram_csc_deliver_f64 travel on it while
@@ -372,8 +372,8 @@ extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
                                                                    blocked_dot_scratch_doubles());
 }
 
-// the signals of one recorded delivery: a dependency signal per band group (the contraction stores 0 into its value when the group is in
-// memory) and one completion signal that counts the groups' transfers down
+// the signals of one recorded delivery: a dependency signal per band group (a one-thread kernel behind the stage that completes the group
+// stores 0 into its value when the group is in memory) and one completion signal that counts the groups' transfers down
 struct DeliverSignals {
     dma::Engine *eng = nullptr;
     dma::Signal dep[MAXGROUPS], done;
@@ -476,7 +476,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         const bool deliver = dplan.host != nullptr;
         if (deliver) {
             PMT_REQUIRE(side && side->counters, PMT_STATE_ERROR, "quad_gram_csc_deliver: no auxiliary streams for this stream");
-            // Preferred: one copy-engine transfer per band group, each started by the signal the contraction sets (hsadma.hip)
+            // Preferred: one copy-engine transfer per band group, each started by the signal set behind the group's stage (hsadma.hip)
             if (!sig->tried) {
                 sig->tried = true;
                 dma::Engine *eng = dma::get(side->device);

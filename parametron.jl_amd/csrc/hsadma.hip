@@ -5,8 +5,9 @@
 // stream-level "wait until this memory word changes" (hipStreamWaitValue64) is a spinning kernel in both.  Kernels that copy or spin sit on
 // the CUs of the persistent contraction and slowed it by 40-60 %.  The HSA runtime underneath both offers what the hardware has:
 // hsa_amd_memory_async_copy runs on an SDMA engine and starts when its DEPENDENCY SIGNALS read 0 — and a signal's value is an ordinary
-// 64-bit word in memory that a kernel can write.  So the contraction's epilogue stores 0 into the signal of a band group when the group's
-// last tile is in memory, and the engine ships that group while the matrix cores go on; no CU is involved in waiting or copying.
+// 64-bit word in memory that a kernel can write.  So a one-thread kernel behind the stage of the contraction that completes a band group
+// stores 0 into the group's signal, and the engine ships that group while the matrix cores go on with the next stage; no CU is involved in
+// waiting or copying.
 //
 // The HSA runtime is the one the HIP runtime of this process has already loaded (found with dl_iterate_phdr, opened RTLD_NOLOAD): no second
 // runtime, no new dependency at link time.  If it cannot be found, or the device cannot be matched to an HSA agent, dma::get() returns null
