@@ -34,8 +34,9 @@ int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
 void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   hipStream_t s);
+                   unsigned *pair_flags, unsigned epoch, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
+constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
 constexpr int DELIVER_ORDER_W = 2; // a delivery computes the tiles in super-columns of two tile columns: the column bands finish in ascending order
 
 // out_lin[j] = (2 * sum_i c_i * A[i,j], vm[xvar[j]]),  c_i = 0.0 (+|-) b[i]; one wave per column (coalesced along i)
@@ -533,14 +534,18 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
             if (!deliver) {
-                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, s);
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, nullptr, 0, s);
             } else {
                 // stage by stage; behind a stage that completes column bands, one thread stores 0 into the word the transfer of those bands waits
                 // for: the value of its dependency signal (copy engine, hsadma.hip) or the courier's flag (deliver.hip)
                 char *cb = static_cast<char *>(side->counters);
+                // flags of the pair fold (gram_sk.hip): the tail of the partial-tile workspace, beyond the slots a grid of 256 uses; cleared
+                // per delivery, stage st writes / waits for the value st + 1
+                unsigned *pair_flags = workspace ? reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + gram_sk_workspace_bytes(rows, cols) - PAIR_FLAG_BYTES) : nullptr;
+                if (pair_flags) PMT_HIP_CHECK(hipMemsetAsync(pair_flags, 0, PAIR_FLAG_BYTES, s));
                 for (int st = 0; !rc && st < dplan.nstages; ++st) {
                     rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, DELIVER_ORDER_W, dplan.seq_begin[st],
-                                        dplan.seq_count[st], s);
+                                        dplan.seq_count[st], pair_flags, (unsigned)(st + 1), s);
                     const int grp = dplan.group_of[st];
                     if (!rc && grp >= 0) {
                         dma::Signal word = sig->eng ? sig->dep[grp] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET) + grp};

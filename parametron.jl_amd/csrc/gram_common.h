@@ -30,6 +30,7 @@ struct SKArgs {
     int order_w;
     int seq_begin;    // this launch covers the tiles seq_begin .. seq_begin + T' - 1 of the sequence (a staged host delivery launches the
                       // contraction band range by band range; 0 and all tiles otherwise)
+    unsigned *pair_flags; unsigned epoch;      // pair fold of a ranged launch (gram_sk.hip), or null
 };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)

@@ -455,15 +455,56 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
             double acc[C::NACC];
             sk_accumulate<TN, BK, ABL>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
 
-            if (c0 == 0 && c1 == g.nchunk) {
+            bool whole = c0 == 0 && c1 == g.nchunk;
+            const bool pair = RANGED && g.pair_flags != nullptr && !whole;
+            if (pair && c0 != 0) {
+                // PAIR FOLD, second half (stages of a host delivery whose tiles are split exactly in two, launcher): the workgroup with the
+                // first half is the previous one (both run at the same time, one workgroup per CU); wait for its flag, add its sum IN FRONT of
+                // this one — 0 + first + second, the order of the fix-up pass — and write the tile with the coalescing epilogue below.  No
+                // fix-up launch for this stage: 17 us + two in-stream gaps less per stage.
+                // (workgroups are dispatched in order, so the partner — one block id lower — is on the chip or done when this one runs; the
+                // wait is bounded all the same, and a tile whose partner never showed up is written as NaN, not as a plausible half sum)
+                if (tid == 0) {
+                    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                    double late = 0.0;
+                    while (__hip_atomic_load(&g.pair_flags[rtile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) { late = 1.0; break; }      // 2 s at 100 MHz
+                    }
+                    lds[0][0][0] = late;                         // (the panels are idle between the stage loop and the epilogue)
+                }
+                __syncthreads();
+                const bool late = lds[0][0][0] != 0.0;
+                const double *w = g.ws + (int64_t)(2 * (bid - 1)) * SLOT + sk_fresh_tid();      // (fresh: nothing of this is live across the stage loop)
+    #pragma unroll
+                for (int r0 = 0; r0 < C::NACC; r0 += 8) {      // eight loads in flight at a time
+                    double first[8];
+    #pragma unroll
+                    for (int r = 0; r < 8; ++r) first[r] = __hip_atomic_load(&w[(r0 + r) * C::NT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    #pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[r0 + r] = late ? __builtin_nan("") : first[r] + acc[r0 + r];
+                    asm volatile("" ::: "memory");
+                }
+                whole = true;
+            }
+            if (whole) {
                 static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
                 sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
             } else {
-                // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
+                // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map.  Pair fold,
+                // first half: agent-scope write-through stores, and once they are acknowledged the tile's flag takes the launch's epoch
                 const int slot = 2 * bid + (u == u0 ? 0 : 1);
-                double *w = g.ws + (int64_t)slot * SLOT + tid;
+                double *w = g.ws + (int64_t)slot * SLOT + (RANGED ? sk_fresh_tid() : tid);
+                if (pair) {
     #pragma unroll
-                for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+                    for (int r = 0; r < C::NACC; ++r) __hip_atomic_store(&w[r * C::NT], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(&g.pair_flags[rtile], g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+    #pragma unroll
+                    for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+                }
             }
             u += (c1 - c0);
         }
@@ -560,10 +601,11 @@ static int env_int(const char *name, int dflt) {
 
 // seq_count < 0: all tiles.  Otherwise the launch covers the tiles [seq_begin, seq_begin + seq_count) of the tile sequence (gram_common.h:
 // sk_tile_unrank) — a host delivery runs the contraction band range by band range (gram.hip), every range as its own stream-K launch over
-// the whole chip, so that the copy engine can ship a range while the next one is computed.
+// the whole chip, so that the copy engine can ship a range while the next one is computed.  pair_flags (ranged launches; R words, holding
+// anything but `epoch`): tiles split exactly in two are summed inside the launch (see the kernel) instead of by the fix-up pass.
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   hipStream_t s) {
+                   unsigned *pair_flags, unsigned epoch, hipStream_t s) {
     SKArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
@@ -594,6 +636,10 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.ws = reinterpret_cast<double *>(workspace);
     g.order_w = order_w;
     if (T <= 0) return PMT_OK;
+    // pair fold: every tile of this ranged launch is split in exactly two halves held by neighbouring workgroups
+    g.pair_flags = nullptr; g.epoch = 0;
+    const bool fold = seq_count >= 0 && pair_flags && g.tfull == 0 && (g.nchunk & 1) == 0 && 2 * R == g.G && g.U == (int64_t)g.G * (g.nchunk / 2);
+    if (fold) { g.pair_flags = pair_flags; g.epoch = epoch; }
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
 #ifdef PMT_TUNING_ABLATE
@@ -618,7 +664,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #endif
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
-    if (g.nchunk > 1 && R > 0) {
+    if (g.nchunk > 1 && R > 0 && !fold) {
         // The split tiles are summed by a second launch.  (Round 3 measured the alternative — the workgroup that arrives last at a split tile
         // adds its partials inside the contraction: +55 us at n = r = 4096, one CU pulling 2 MB of partials, against 15 us of fix-up kernel
         // plus ~25 us of in-stream gaps; profiles/r03_gram_fold_experiment.txt.)
