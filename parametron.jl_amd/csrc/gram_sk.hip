@@ -638,7 +638,8 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     if (T <= 0) return PMT_OK;
     // pair fold: every tile of this ranged launch is split in exactly two halves held by neighbouring workgroups
     g.pair_flags = nullptr; g.epoch = 0;
-    const bool fold = seq_count >= 0 && pair_flags && g.tfull == 0 && (g.nchunk & 1) == 0 && 2 * R == g.G && g.U == (int64_t)g.G * (g.nchunk / 2);
+    // (the flags live in the tail of the workspace, behind the partial-tile slots of a grid of at most MAXG / 2 workgroups: gram.hip)
+    const bool fold = seq_count >= 0 && pair_flags && g.tfull == 0 && (g.nchunk & 1) == 0 && 2 * R == g.G && g.U == (int64_t)g.G * (g.nchunk / 2) && g.G <= MAXG / 2;
     if (fold) { g.pair_flags = pair_flags; g.epoch = epoch; }
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
