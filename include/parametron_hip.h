@@ -484,6 +484,12 @@ int pmt_plan_stage_upload_2d(pmt_plan *plan, void *device_staging, size_t dst_pi
 int pmt_plan_wait_staged(pmt_plan *plan);
 int pmt_plan_commit_staged(pmt_plan *plan, void *device_dst, const void *device_staging, size_t bytes);
 int pmt_plan_staging_consumed(pmt_plan *plan);
+/* Lane of the commits that follow (pmt_plan_wait_staged / pmt_plan_commit_staged): 0 = the plan's stream (default), 1 = its side stream, the
+ * one the side-lane entries of the tape run on (pmt_plan_set_lane).  A Parameter that ONLY side-lane entries read — the data of a constraint
+ * whose MOI copy sits on the side lane — may be committed there: the plan's stream, i.e. the contraction of a least-squares objective, then
+ * starts at once instead of waiting for this solve's upload (config 3 through the host hand-off: -0.3 ms per solve).  The caller
+ * guarantees that nothing on the plan's stream reads those Parameters; pmt_plan_staging_consumed covers both lanes. */
+int pmt_plan_commit_lane(pmt_plan *plan, int lane);
 int pmt_plan_staged_synchronize(pmt_plan *plan);
 /* Two staging SLOTS (0 / 1): the four calls above act on the current slot, each slot with its own staged / consumed events.  Alternating
  * the slot — and the staging buffers — from one update to the next lets the copy of update k+1 start while the commits of update k are

@@ -222,6 +222,9 @@ staged_synchronize(plan::Plan) = check(ccall((:pmt_plan_staged_synchronize, lib)
 "staging slot (0 / 1) of the calls above; alternate it (and the staging buffers) per update so the next copy does not wait for this update's commits"
 stage_slot!(plan::Plan, slot::Integer) = check(ccall((:pmt_plan_stage_slot, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, slot))
 
+"lane of the commits that follow: 0 = the plan's stream, 1 = its side stream (Parameters that only side-lane entries of the tape read)"
+commit_lane!(plan::Plan, lane::Integer) = check(ccall((:pmt_plan_commit_lane, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, lane))
+
 "plan stream: wait for the staged uploads of the current slot (then commit / consume them)"
 wait_staged!(plan::Plan) = check(ccall((:pmt_plan_wait_staged, lib), Cint, (Ptr{Cvoid},), plan.handle))
 

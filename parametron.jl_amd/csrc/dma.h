@@ -14,7 +14,8 @@ Engine *get(int device);                                             // null: no
 int signal_create(Engine *e, int64_t initial, Signal *out);
 void signal_destroy(Engine *e, Signal s);
 void signal_set(Engine *e, Signal s, int64_t v);
-int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes, const Signal *dep, Signal completion);
+// queue 0 / 1: two independent first-in-first-out queues (two SDMA engines) when the runtime offers a choice, else one
+int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes, const Signal *dep, Signal completion, int queue = 0);
 int wait(Engine *e, Signal completion, double timeout_s);
 int launch_signal_store(Signal s, hipStream_t stream);
 

@@ -561,7 +561,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     auto submit = [=]() -> int {
                         for (int i = 0; i < dplan.ngroups; ++i)
                             if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.off[i], out_csc + dplan.off[i],
-                                                            sizeof(double) * (size_t)(dplan.off[i + 1] - dplan.off[i]), &sig->dep[i], sig->done)) return rc2;
+                                                            sizeof(double) * (size_t)(dplan.off[i + 1] - dplan.off[i]), &sig->dep[i], sig->done, 1)) return rc2;
                         return PMT_OK;
                     };
                     sig->pending = true;

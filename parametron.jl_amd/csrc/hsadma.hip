@@ -40,11 +40,15 @@ struct Api {
     decltype(&hsa_signal_load_relaxed) signal_load_relaxed = nullptr;
     decltype(&hsa_signal_wait_scacquire) signal_wait_scacquire = nullptr;
     decltype(&hsa_amd_memory_async_copy) memory_async_copy = nullptr;
+    // optional (HSA 1.2+): a chosen SDMA engine per copy, so that two FIFO queues exist instead of one
+    decltype(&hsa_amd_memory_async_copy_on_engine) memory_async_copy_on_engine = nullptr;
+    decltype(&hsa_amd_memory_copy_engine_status) memory_copy_engine_status = nullptr;
 };
 
 struct Engine {
     Api api;
     hsa_agent_t gpu{}, cpu{};
+    uint32_t queue_engine[2] = {0, 0};      // SDMA engine of queue 0 (recorded fetches) / queue 1 (P's stages); 0: the runtime chooses
 };
 
 static std::mutex g_mu;
@@ -85,6 +89,8 @@ static bool load_api() {
     PMT_HSA_SYM(signal_wait_scacquire, "hsa_signal_wait_scacquire")
     PMT_HSA_SYM(memory_async_copy, "hsa_amd_memory_async_copy")
 #undef PMT_HSA_SYM
+    g_api.memory_async_copy_on_engine = reinterpret_cast<decltype(g_api.memory_async_copy_on_engine)>(dlsym(lib, "hsa_amd_memory_async_copy_on_engine"));
+    g_api.memory_copy_engine_status = reinterpret_cast<decltype(g_api.memory_copy_engine_status)>(dlsym(lib, "hsa_amd_memory_copy_engine_status"));
     if (g_api.init() != HSA_STATUS_SUCCESS) { dlclose(lib); return false; }     // reference-counted: HIP initialised it long ago
     g_lib = lib;
     return true;
@@ -122,6 +128,22 @@ Engine *get(int device) {
     if (!found) return nullptr;
     Engine *e = new Engine();
     e->api = g_api; e->gpu = gpu; e->cpu = l.cpus[0];
+    // Two device -> host queues when the runtime lets us pick engines: a transfer whose data appears late (A's values behind this solve's
+    // Parameter upload, config 3) then does not hold back P's stages queued behind it, and vice versa.  PCIe is shared either way.
+#ifdef PMT_TUNING
+    const bool two_queues = !(getenv("PMT_DMA_QUEUES") && getenv("PMT_DMA_QUEUES")[0] == '1');
+#else
+    const bool two_queues = true;
+#endif
+    if (two_queues && g_api.memory_async_copy_on_engine && g_api.memory_copy_engine_status) {
+        uint32_t mask = 0;
+        if (g_api.memory_copy_engine_status(e->cpu, e->gpu, &mask) == HSA_STATUS_SUCCESS) {
+            int n = 0;
+            for (uint32_t bit = 1; bit && n < 2; bit <<= 1)
+                if (mask & bit) e->queue_engine[n++] = bit;
+            if (n < 2) e->queue_engine[0] = e->queue_engine[1] = 0;
+        }
+    }
     if (g_engines.size() <= (size_t)device) g_engines.resize((size_t)device + 1, nullptr);
     g_engines[(size_t)device] = e;
     return e;
@@ -147,13 +169,24 @@ static bool dbg() { static const bool on = getenv("PMT_DMA_DEBUG") != nullptr; r
 static double dnow() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 #endif
 
-int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes, const Signal *dep, Signal completion) {
+int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes, const Signal *dep, Signal completion, int queue) {
     hsa_signal_t d{};
     if (dep) d.handle = dep->handle;
 #ifdef PMT_TUNING
     if (dbg()) fprintf(stderr, "[dma %.0f] submit %zu bytes dep=%ld done=%ld (done handle %lx)\n", dnow(), bytes, dep ? (long)*dep->value : -99L, (long)*completion.value, (unsigned long)completion.handle);
 #endif
-    hsa_status_t st = e->api.memory_async_copy(host_dst, e->cpu, device_src, e->gpu, bytes, dep ? 1 : 0, dep ? &d : nullptr, hsa_signal_t{completion.handle});
+    hsa_status_t st;
+    const uint32_t eng = e->queue_engine[queue & 1];
+    if (eng) {
+        st = e->api.memory_async_copy_on_engine(host_dst, e->cpu, device_src, e->gpu, bytes, dep ? 1 : 0, dep ? &d : nullptr, hsa_signal_t{completion.handle},
+                                                (hsa_amd_sdma_engine_id_t)eng, false);
+        if (st != HSA_STATUS_SUCCESS) {                    // the engine went away (busy, reset): one queue from now on
+            e->queue_engine[0] = e->queue_engine[1] = 0;
+            st = e->api.memory_async_copy(host_dst, e->cpu, device_src, e->gpu, bytes, dep ? 1 : 0, dep ? &d : nullptr, hsa_signal_t{completion.handle});
+        }
+    } else {
+        st = e->api.memory_async_copy(host_dst, e->cpu, device_src, e->gpu, bytes, dep ? 1 : 0, dep ? &d : nullptr, hsa_signal_t{completion.handle});
+    }
     if (st != HSA_STATUS_SUCCESS) return fail(PMT_HIP_ERROR, "hsa_amd_memory_async_copy failed (status " + std::to_string((int)st) + ")");
     return PMT_OK;
 }

@@ -48,6 +48,11 @@ struct pmt_plan {
     hipEvent_t staged[2] = {nullptr, nullptr};     // recorded on the copy stream behind every staged upload of the slot
     hipEvent_t consumed[2] = {nullptr, nullptr};   // recorded on the plan stream behind the slot's commits (its staging buffers may be overwritten after it)
     bool consumed_recorded[2] = {false, false};
+    // commits that went to the SIDE stream (pmt_plan_commit_lane): their own event per slot, which the copy stream waits for as well
+    hipEvent_t consumed_side[2] = {nullptr, nullptr};
+    bool consumed_side_recorded[2] = {false, false};
+    bool side_commits = false;         // since the last pmt_plan_staging_consumed
+    int commit_lane = 0;
     int slot = 0;
     // pmt_plan_alloc zero-fills on the plan's stream; a staged upload into a fresh buffer must not overtake that fill on the copy stream
     hipEvent_t alloc_done = nullptr;
@@ -270,6 +275,7 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     }
     if (plan->alloc_done) (void)hipEventDestroy(plan->alloc_done);
     for (hipEvent_t e : plan->fetch_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (plan->consumed_side[i]) (void)hipEventDestroy(plan->consumed_side[i]);
     if (plan->lane_fork) (void)hipEventDestroy(plan->lane_fork);
     if (plan->lane_join) (void)hipEventDestroy(plan->lane_join);
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
@@ -382,6 +388,7 @@ static int ensure_copy_stream(pmt_plan *plan) {
     for (int i = 0; i < 2; ++i) {
         PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->staged[i], hipEventDisableTiming));
         PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->consumed[i], hipEventDisableTiming));
+        PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->consumed_side[i], hipEventDisableTiming));
     }
     return PMT_OK;
 }
@@ -396,6 +403,7 @@ static int stage_prologue(pmt_plan *plan) {
     }
     // the slot's staging buffers may still be being read by the commits of the update that used the slot last
     if (plan->consumed_recorded[plan->slot]) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed[plan->slot], 0));
+    if (plan->consumed_side_recorded[plan->slot]) PMT_HIP_CHECK(hipStreamWaitEvent(plan->copy_stream, plan->consumed_side[plan->slot], 0));
     return PMT_OK;
 }
 
@@ -422,11 +430,18 @@ extern "C" int pmt_plan_stage_upload_2d(pmt_plan *plan, void *device_staging, si
 
 // plan stream: wait for every staged upload issued so far; the caller then enqueues whatever consumes the staging buffers on the plan's
 // stream (pmt_plan_commit_staged, or a transposition / permutation kernel) and finishes with pmt_plan_staging_consumed
+// the stream the commits of the current commit lane go to: the plan's stream, or (lane 1) the side stream its side-lane entries run on
+static hipStream_t commit_stream(pmt_plan *plan) {
+    if (plan->commit_lane == 1)
+        if (hipStream_t side = pmt::side_stream_of(plan->stream)) return side;
+    return plan->stream;
+}
+
 extern "C" int pmt_plan_wait_staged(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_wait_staged: null plan");
     if (!plan->copy_stream) return PMT_OK;
     PMT_HIP_CHECK(hipSetDevice(plan->device));
-    PMT_HIP_CHECK(hipStreamWaitEvent(plan->stream, plan->staged[plan->slot], 0));
+    PMT_HIP_CHECK(hipStreamWaitEvent(commit_stream(plan), plan->staged[plan->slot], 0));
     return PMT_OK;
 }
 
@@ -435,7 +450,20 @@ extern "C" int pmt_plan_commit_staged(pmt_plan *plan, void *device_dst, const vo
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(device_dst && device_staging, PMT_INVALID_ARGUMENT, "plan_commit_staged: null pointer");
     if (int rc = pmt_plan_wait_staged(plan)) return rc;
-    PMT_HIP_CHECK(hipMemcpyAsync(device_dst, device_staging, bytes, hipMemcpyDeviceToDevice, plan->stream));
+    hipStream_t target = commit_stream(plan);
+    PMT_HIP_CHECK(hipMemcpyAsync(device_dst, device_staging, bytes, hipMemcpyDeviceToDevice, target));
+    if (target != plan->stream) plan->side_commits = true;
+    return PMT_OK;
+}
+
+// Lane of the commits that follow (0 = the plan's stream, the default; 1 = its side stream).  A Parameter that only side-lane entries of the
+// tape read (pmt_plan_set_lane) can be committed on the side stream: the plan's stream — the contraction of a least-squares objective — then
+// does not wait for the upload of, say, the constraint data of this solve.  The caller guarantees that nothing on the plan's stream reads
+// the Parameter.
+extern "C" int pmt_plan_commit_lane(pmt_plan *plan, int lane) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_commit_lane: null plan");
+    PMT_REQUIRE(lane == 0 || lane == 1, PMT_INVALID_ARGUMENT, "plan_commit_lane: lane must be 0 or 1");
+    plan->commit_lane = lane;
     return PMT_OK;
 }
 
@@ -445,6 +473,13 @@ extern "C" int pmt_plan_staging_consumed(pmt_plan *plan) {
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipEventRecord(plan->consumed[plan->slot], plan->stream));
     plan->consumed_recorded[plan->slot] = true;
+    if (plan->side_commits) {
+        if (hipStream_t side = pmt::side_stream_of(plan->stream)) {
+            PMT_HIP_CHECK(hipEventRecord(plan->consumed_side[plan->slot], side));
+            plan->consumed_side_recorded[plan->slot] = true;
+        }
+        plan->side_commits = false;
+    }
     return PMT_OK;
 }
 

@@ -114,6 +114,10 @@ class DeviceContext:
     def wait_staged(self):
         _lib.call("pmt_plan_wait_staged", self.plan)
 
+    def commit_lane(self, lane):
+        """0: the commits that follow go to the plan's stream; 1: to its side stream (Parameters only side-lane entries read)"""
+        _lib.call("pmt_plan_commit_lane", self.plan, int(lane))
+
     def staging_consumed(self):
         _lib.call("pmt_plan_staging_consumed", self.plan)
 

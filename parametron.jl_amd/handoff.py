@@ -239,6 +239,7 @@ class DeviceQP:
             finally:
                 ctx.end_record()
             self._in_tape = True
+            self._in_tape_lane = in_tape
             model._run_tape(fetch=False)
         else:
             self.refresh()

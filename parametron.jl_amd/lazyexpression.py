@@ -124,7 +124,15 @@ def device_value_of(x, ctx=None):
         ctx = ctx or x.model.device()
         if getattr(x, "_staged_pending", False) and x._dev is not None:
             # the value of this solve was evaluated and put on the copy stream by Model.stage_parameters(): consume it on the plan's stream
-            _commit_staged_value(ctx, x._dev)
+            # (a Parameter only side-lane records read is committed on the side stream: the plan's stream does not wait for its upload)
+            side = getattr(x, "_commit_on_side_lane", False) and not (isinstance(x._dev, DMat) and getattr(x._dev, "_staged_kind", None) == "rowmajor")
+            if side:
+                ctx.commit_lane(1)
+            try:
+                _commit_staged_value(ctx, x._dev)
+            finally:
+                if side:
+                    ctx.commit_lane(0)
             x._staged_pending = False
             x._dev_version = x.version
             ctx._staging_dirty = True

@@ -332,8 +332,27 @@ class Model:
                 any(not c.isconstant for c in self.constraints)
             host = None if self.handoff == "device" else ("overlap" if self._overlap_fetch else "serial")
             self.device_qp = DeviceQP(self, in_tape="side" if in_tape else False, host=host)
+        self._mark_side_lane_parameters()
         if records and self._use_graph:
             self.device().instantiate_graph()
+
+    def _mark_side_lane_parameters(self):
+        """Host-updated Parameters that ONLY side-lane records read (and, with a hand-off, only when its launches are side-lane entries too)
+        are committed on the side stream (pmt_plan_commit_lane): the upload of a constraint's data then overlaps the contraction of the
+        objective instead of standing in front of it.  Every other Parameter keeps the plan's stream."""
+        lane_records = getattr(self, "_lane_records", [])
+        handoff_ok = self.device_qp is None or getattr(self.device_qp, "_in_tape_lane", None) == "side"
+        readers = {}
+        for r in self._records:
+            if not isinstance(r.expr, DeviceNode):
+                continue
+            on_side = any(r is x for x in lane_records)
+            for x in schedule([r.expr]):
+                if isinstance(x, Parameter):
+                    readers.setdefault(id(x), [x, True])[1] &= on_side
+        for x, side_only in readers.values():
+            # (a graph replay launches the side-lane entries as nodes of ONE graph on the plan's stream: no side stream to order against)
+            x._commit_on_side_lane = bool(side_only and handoff_ok and lane_records and not self._use_graph)
 
     @staticmethod
     def _side_lane_ok(r):
