@@ -206,6 +206,13 @@ int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, in
                                   const int64_t *xvar, const double *b, int sign, const int64_t *varmap,
                                   double alpha, double *out_P_values, double *host_P_values, int ngroups,
                                   pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
+/* pmt_quad_gram_f64 with the QUADRATIC TERMS delivered to the host the same way — the reference's own boundary (MOI.set of the objective's
+ * ScalarQuadraticFunction, src/moi_interop.jl:131-137): host_quad is page-locked memory for cols*(cols+1)/2 pmt_quadratic_term; the stages run
+ * over tile ROW bands (the term array is row-major), each completed band range leaves while the next stage is computed.  Same remarks as above
+ * (stages, summation order of split tiles, pmt_plan_fetch_synchronize / pmt_fetch_synchronize). */
+int pmt_quad_gram_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                              int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_quadratic_term *host_quad, int nstages,
+                              pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
 /* host: block until every copy on the fetch stream of `stream` (a HIP stream, not a recording handle) has landed */
 int pmt_fetch_synchronize(void *stream);
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_csc_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_csc_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
+    "pmt_quad_gram_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
     "pmt_fetch_synchronize": (_ci, [_vp]),
     "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_fill_uniform_matrix_f64": (_ci, [_vp, _i64, _i64, _i64, _u64, _f64, _vp]),

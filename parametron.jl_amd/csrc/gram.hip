@@ -407,7 +407,9 @@ struct DeliverPlan {
 // costs ~15 % of contraction time (partial tiles through the workspace, 3 launches per stage; profiles/r03_host_delivery.txt) and changes
 // the summation order of a split tile (two half sums added) — within the stated tolerance, deterministic, and the delivered host array is
 // the device array of the same run bit for bit.  `nstages_hint` (the entry point's ngroups) > 0 overrides the number of stages.
-static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, int order_w, double *host) {
+// quad: the delivered array is out_quad (24-byte terms, ROW-major upper triangle): tile order 0 (super-rows of four tile rows, sk_seq_unrank), the
+// groups are row bands and the offsets count doubles (three per term); else out_csc (column bands, super-columns of `order_w`).
+static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, int order_w, double *host, bool quad) {
     DeliverPlan d;
     d.host = host;
     const int nt = (int)cdiv(cols, GT);
@@ -420,14 +422,26 @@ static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, in
     // tiles up to the end of each super-column, i.e. where its bands are complete
     std::vector<int64_t> seq_end_of_band((size_t)nt), endoff((size_t)nt);
     int64_t seq_end = 0;
-    for (int c0 = 0; c0 < nt; c0 += order_w) {
-        const int h = std::min(order_w, nt - c0);
-        seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;             // (sk_colseq_unrank)
-        for (int kb = c0; kb < c0 + h; ++kb) seq_end_of_band[(size_t)kb] = seq_end;
-    }
-    for (int kb = 0; kb < nt; ++kb) {
-        const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
-        endoff[(size_t)kb] = cend * (cend + 1) / 2;
+    if (quad) {
+        for (int j0 = 0; j0 < nt; j0 += 4) {
+            const int h = std::min(4, nt - j0), W = nt - j0;
+            seq_end += (int64_t)h * (h + 1) / 2 + (int64_t)(W - h) * h;    // (sk_seq_unrank)
+            for (int jb = j0; jb < j0 + h; ++jb) seq_end_of_band[(size_t)jb] = seq_end;
+        }
+        for (int jb = 0; jb < nt; ++jb) {
+            const int64_t J = std::min<int64_t>(cols, (int64_t)(jb + 1) * GT);
+            endoff[(size_t)jb] = 3 * (J * cols - J * (J - 1) / 2);         // rows 0 .. J-1 of the row-major upper triangle, 3 doubles per term
+        }
+    } else {
+        for (int c0 = 0; c0 < nt; c0 += order_w) {
+            const int h = std::min(order_w, nt - c0);
+            seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;         // (sk_colseq_unrank)
+            for (int kb = c0; kb < c0 + h; ++kb) seq_end_of_band[(size_t)kb] = seq_end;
+        }
+        for (int kb = 0; kb < nt; ++kb) {
+            const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
+            endoff[(size_t)kb] = cend * (cend + 1) / 2;
+        }
     }
     d.off[0] = 0;
     int done_bands = 0;
@@ -453,7 +467,7 @@ static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, in
 // page-locked host buffer, band group by band group, on the stream's fetch stream while the contraction is still running.
 static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
                      int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
-                     double *out_const, void *workspace, double *host_csc, int ngroups, void *stream) {
+                     double *out_const, void *workspace, double *host_csc, int ngroups, void *stream, pmt_quadratic_term *host_quad = nullptr) {
     PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "quad_gram: negative dimension");
     PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "quad_gram: lda < rows");
     PMT_REQUIRE(sign >= -1 && sign <= 1, PMT_INVALID_ARGUMENT, "quad_gram: sign must be -1, 0 or +1");
@@ -464,9 +478,14 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     if (int rc = check_strictly_increasing(xvar, cols, stream)) return rc;
     DeliverPlan dplan;
     std::shared_ptr<DeliverSignals> sig = std::make_shared<DeliverSignals>();      // lives as long as the recorded call
-    if (host_csc && cols > 0) {
-        dplan = deliver_plan(rows, cols, ngroups, DELIVER_ORDER_W, host_csc);
-        dplan.host_dev = static_cast<double *>(host_device_pointer(host_csc));
+    PMT_REQUIRE(!(host_csc && host_quad), PMT_INVALID_ARGUMENT, "quad_gram: one delivered array per call");
+    // the array a delivery ships, as doubles: out_csc, or out_quad (three doubles per term)
+    double *deliver_host = host_quad ? reinterpret_cast<double *>(host_quad) : host_csc;
+    const double *deliver_src = host_quad ? reinterpret_cast<const double *>(out_quad) : out_csc;
+    const int deliver_order = host_quad ? 0 : DELIVER_ORDER_W;
+    if (deliver_host && cols > 0) {
+        dplan = deliver_plan(rows, cols, ngroups, DELIVER_ORDER_W, deliver_host, host_quad != nullptr);
+        dplan.host_dev = static_cast<double *>(host_device_pointer(deliver_host));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
         mark_no_graph(stream);
     }
@@ -544,7 +563,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                 unsigned *pair_flags = workspace ? reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + gram_sk_workspace_bytes(rows, cols) - PAIR_FLAG_BYTES) : nullptr;
                 if (pair_flags) PMT_HIP_CHECK(hipMemsetAsync(pair_flags, 0, PAIR_FLAG_BYTES, s));
                 for (int st = 0; !rc && st < dplan.nstages; ++st) {
-                    rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, DELIVER_ORDER_W, dplan.seq_begin[st],
+                    rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver_order, dplan.seq_begin[st],
                                         dplan.seq_count[st], pair_flags, (unsigned)(st + 1), s);
                     const int grp = dplan.group_of[st];
                     if (!rc && grp >= 0) {
@@ -560,7 +579,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     // first tenth of the contraction) — submitted here they would hold those back until the last band group has left.
                     auto submit = [=]() -> int {
                         for (int i = 0; i < dplan.ngroups; ++i)
-                            if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.off[i], out_csc + dplan.off[i],
+                            if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.off[i], deliver_src + dplan.off[i],
                                                             sizeof(double) * (size_t)(dplan.off[i + 1] - dplan.off[i]), &sig->dep[i], sig->done, 1)) return rc2;
                         return PMT_OK;
                     };
@@ -573,7 +592,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     // fallback, fetch stream: ONE courier launch, queued now that the contraction's workgroups are on their way; it polls the
                     // band groups' flags and stores each finished group straight into the host array (deliver.hip)
                     char *cb = static_cast<char *>(side->counters);
-                    rc = launch_courier(out_csc, dplan.host_dev, reinterpret_cast<long long *>(cb + FLAGS_OFFSET), reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
+                    rc = launch_courier(deliver_src, dplan.host_dev, reinterpret_cast<long long *>(cb + FLAGS_OFFSET), reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
                                         reinterpret_cast<int *>(cb + DONE_OFFSET + sizeof(unsigned)), dplan.ngroups, dplan.off, side->fetch);
                     if (rc) return rc;
                     PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
@@ -599,6 +618,14 @@ extern "C" int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows,
                                      pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream) {
     if (cols > 0) PMT_REQUIRE(out_P_values, PMT_INVALID_ARGUMENT, "quad_gram_csc: null out_P_values");
     return gram_node(A, lda, rows, cols, xvar, b, sign, 1, varmap, out_quad, out_P_values, alpha, out_lin, out_const, workspace, nullptr, 0, stream);
+}
+
+extern "C" int pmt_quad_gram_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
+                                         int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_quadratic_term *host_quad, int nstages,
+                                         pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream) {
+    if (cols > 0) PMT_REQUIRE(out_quad && host_quad, PMT_INVALID_ARGUMENT, "quad_gram_deliver: null out_quad / host_quad");
+    PMT_REQUIRE(nstages >= 0 && nstages <= MAXGROUPS, PMT_INVALID_ARGUMENT, "quad_gram_deliver: nstages must be 0 (default) .. 16");
+    return gram_node(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, nullptr, 1.0, out_lin, out_const, workspace, nullptr, nstages, stream, host_quad);
 }
 
 extern "C" int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
