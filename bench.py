@@ -405,15 +405,20 @@ def host_api_c2(torch, P, steps):
       handoff_host_csc         what a host OSQP's update takes (P.x 67.1 MB, A.x 16.8 MB, q, l, u = 84 MB) in page-locked host arrays,
                                shipped WHILE the re-evaluation runs: recorded fetches + band-wise delivery of P out of the contraction
       handoff_host_csc_serial  the same 84 MB fetched behind the re-evaluation
-      handoff_moi              the reference's boundary: 252 MB of MOI term arrays fetched into page-locked host buffers
+      handoff_moi              the reference's boundary: 252 MB of MOI term arrays in page-locked host buffers, shipped WHILE the re-evaluation
+                               runs (recorded fetches; the objective's quadratic terms row band by row band, pmt_quad_gram_deliver_f64)
+      handoff_moi_serial       the same 252 MB fetched behind the re-evaluation
     Every solve! ends with the host holding the data (synchronised); Parameters are regenerated on the device before each one."""
     from parametron_jl_amd import workloads
     out = {}
     what = {"device": "CSC QP data left in HBM", "moi": "MOI term arrays fetched to the host (252 MB over PCIe)",
             "host_csc": "CSC values of P and A, q, l, u (84 MB) delivered to page-locked host arrays while the contraction runs",
             "host_csc_serial": "the same 84 MB fetched behind the re-evaluation"}
-    for name in ("device", "host_csc", "host_csc_serial", "moi"):
-        kw = {"handoff": "host_csc", "overlap_fetch": name == "host_csc"} if name.startswith("host_csc") else {"handoff": name}
+    what["moi_serial"] = "the same 252 MB fetched behind the re-evaluation"
+    what["moi"] = "MOI term arrays (252 MB) delivered to page-locked host buffers while the contraction runs: recorded fetches + the quadratic terms row band by row band"
+    for name in ("device", "host_csc", "host_csc_serial", "moi", "moi_serial"):
+        kw = {"handoff": "host_csc", "overlap_fetch": name == "host_csc"} if name.startswith("host_csc") else \
+            ({"handoff": "moi", "overlap_fetch": name == "moi"} if name.startswith("moi") else {"handoff": name})
         model = workloads.config2(**kw)
         P.solve(model)
         for _ in range(5):

@@ -253,6 +253,13 @@ quad_gram_csc_deliver!(out_P_values, host_P::Vector{Float64}, out_lin, out_const
                 (DevPtr, Int64, Int64, Int64, DevPtr, DevPtr, Cint, DevPtr, Cdouble, DevPtr, Ptr{Cvoid}, Cint, DevPtr, DevPtr, DevPtr, Ptr{Cvoid}),
                 A, lda, rows, cols, xvar, b, sign, varmap, alpha, out_P_values, host_P, ngroups, out_lin, out_const, workspace, stream))
 
+"the Gram node with the MOI quadratic terms DELIVERED row band by row band into page-locked `host_quad` (pmt_host_alloc'ed memory viewed as
+24-byte terms) while the contraction runs — the reference's own boundary, src/moi_interop.jl:131-137"
+quad_gram_deliver!(out_quad::DevPtr, host_quad::Ptr{Cvoid}, out_lin, out_const, A, lda, rows, cols, xvar, b, sign, moi, varmap, workspace, stream; nstages::Integer = 0) =
+    check(ccall((:pmt_quad_gram_deliver_f64, lib), Cint,
+                (DevPtr, Int64, Int64, Int64, DevPtr, DevPtr, Cint, Cint, DevPtr, DevPtr, Ptr{Cvoid}, Cint, DevPtr, DevPtr, DevPtr, Ptr{Cvoid}),
+                A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, host_quad, nstages, out_lin, out_const, workspace, stream))
+
 # ---- further builders used by ParametronHIPBackend.jl
 "x (+|-) v for x::Vector{Variable} (bounds): one term per row; native and/or MOI output may be C_NULL — src/functions.jl:421,751-764"
 vars_addsub!(out_lt::DevPtr, out_vat::DevPtr, out_consts::DevPtr, xvar::DevPtr, n, v::DevPtr, sign, varmap::DevPtr, row_offset, stream) =

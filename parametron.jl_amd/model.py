@@ -134,6 +134,10 @@ class Model:
         # host_csc: the arrays leave for the host while the re-evaluation is still running (recorded fetches, band-wise delivery of P);
         # False fetches them behind it (the A/B in bench.py)
         self._overlap_fetch = bool(overlap_fetch) and handoff == "host_csc"
+        # the reference's own boundary (MOI function objects on the host): the MOI buffers leave as recorded fetches while the tape is still
+        # running and the objective's quadratic terms row band by row band out of the contraction (pmt_quad_gram_deliver_f64) — not under
+        # a hipGraph replay (copies leave the capture)
+        self._overlap_moi = bool(overlap_fetch) and handoff == "moi" and not use_graph
         if handoff == "host_csc" and use_graph:
             raise ArgumentError("handoff='host_csc' replays the tape as launches (its copies leave a graph capture); use_graph must be False")
         self.device_qp = None
@@ -303,7 +307,8 @@ class Model:
                 # one small kernel on the lane does not pay (config 2: the co-resident pack slows the contraction by what it saves); several
                 # do (config 3: -0.15 ms), and so does the device hand-off, whose launches join them on the lane
                 eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane) else []
-                use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and self.handoff != "moi")
+                # (and with the overlapped MOI boundary a constraint on the lane is packed early: its terms cross PCIe during the contraction)
+                use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and (self.handoff != "moi" or self._overlap_moi))
                 for r, e in zip(records, emitters):
                     side = use_lane and any(r is x for x in eligible)
                     if side:
@@ -311,6 +316,8 @@ class Model:
                         self._lane_records.append(r)
                         r.on_side_lane = True
                     e(ctx)
+                    if self._overlap_moi:
+                        r.record_fetch(ctx)                    # behind its producers, on their lane
                     if side:
                         ctx.set_lane(0)
             finally:
@@ -395,6 +402,8 @@ class Model:
             return
         for r in self._records:
             r.fetch(ctx)
+        if self._overlap_moi:
+            ctx.fetch_synchronize()                            # recorded fetches + the delivered quadratic terms have landed
         ctx.synchronize()
         for r in self._records:
             r.finish_fetch()

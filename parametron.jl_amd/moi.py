@@ -222,9 +222,17 @@ class _Record:
                 self.mode = "canonical"
                 vec = gram.vec.buf if gram.vec is not None else None
 
+                deliver = bool(getattr(self.model, "_overlap_moi", False)) and nq > 0
+                self._quad_delivered = deliver
+
                 def emit(c):
-                    c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
-                           1, P(varmap_buf), P(dq), P(dl), P(dc), P(ws))
+                    if deliver:
+                        # the quadratic terms leave for f.quadratic_terms (page-locked) row band by row band while the contraction runs
+                        c.call("pmt_quad_gram_deliver_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec),
+                               gram.sign if vec else 0, 1, P(varmap_buf), P(dq), self.f.quadratic_terms.ctypes.data_as(C.c_void_p), 0, P(dl), P(dc), P(ws))
+                    else:
+                        c.call("pmt_quad_gram_f64", P(gram.mat.buf), gram.mat.lda, _gram_rows(gram), n, P(gram.xvars.buf), P(vec), gram.sign if vec else 0,
+                               1, P(varmap_buf), P(dq), P(dl), P(dc), P(ws))
                 return emit
             self.mode = "literal"
             out.materialize()
@@ -306,8 +314,32 @@ class _Record:
             c.call("pmt_pack_vector_affine_f64", P(m.terms), P(m.row_ptr_buf), m.rows, m.row_len, P(varmap_buf), 0, P(dt))
         return emit
 
+    def record_fetch(self, ctx):
+        """while recording (Model._overlap_moi): the same copies as fetch(), as tape entries behind this record's launches on their lane —
+        they leave while the rest of the tape is still running (pmt_plan_record_fetch); the objective's quadratic terms are delivered by
+        the contraction itself when it is the canonical node"""
+        f, d = self.f, self.dev
+        if self.isconstant or d is None:
+            return
+        if self.kind in ("aff", "quad"):
+            self._c = ctx.pinned_array(1, np.float64)
+        if self.kind == "aff":
+            ctx.record_fetch(f.terms, d["terms"], f.terms.nbytes)
+            ctx.record_fetch(self._c, d["const"], 8)
+        elif self.kind == "quad":
+            if "quad" in d and not getattr(self, "_quad_delivered", False):
+                ctx.record_fetch(f.quadratic_terms, d["quad"], f.quadratic_terms.nbytes)
+            ctx.record_fetch(f.affine_terms, d["lin"], f.affine_terms.nbytes)
+            ctx.record_fetch(self._c, d["const"], 8)
+        else:
+            ctx.record_fetch(f.terms, d["terms"], f.terms.nbytes)
+            ctx.record_fetch(f.constants, d["consts"], f.constants.nbytes)
+        self._fetch_recorded = True
+
     def fetch(self, ctx):
         """D2H of the MOI buffers into the host function object (asynchronous; caller synchronises)."""
+        if getattr(self, "_fetch_recorded", False):
+            return
         f, d = self.f, self.dev
         if self.kind == "aff":
             ctx.fetch(f.terms, d["terms"], f.terms.nbytes)

@@ -325,3 +325,22 @@ def test_deliver_quadratic_terms_matches_plain_node(rows, cols, nstages):
     np.testing.assert_allclose(got[:, 0].copy().view(np.float64), want[:, 0].copy().view(np.float64), rtol=1e-13, atol=0)
     assert torch.equal(lin0, lin1) and torch.equal(c0, c1)
     _lib.call("pmt_host_free", hp)
+
+
+@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (700, 1100, 33)])
+def test_overlapped_moi_boundary_equals_the_serial_one(n, r, m):
+    """handoff="moi" (the reference's boundary): with overlap_fetch the MOI buffers leave as recorded fetches and the objective's quadratic
+    terms row band by row band out of the contraction; what the optimizer's function objects hold after every solve equals the serial
+    fetch — indices exactly, coefficients to 1e-13 (split tiles), everything else bit for bit — while all Parameters change"""
+    a, b_ = lsq_model(n, r, m, handoff="moi", overlap_fetch=True), lsq_model(n, r, m, handoff="moi", overlap_fetch=False)
+    assert a._overlap_moi and not b_._overlap_moi
+    for _ in range(3):
+        P.solve(a); P.solve(b_)
+        fa, fb = a.objective.f, b_.objective.f
+        assert np.array_equal(fa.quadratic_terms["row"], fb.quadratic_terms["row"]) and np.array_equal(fa.quadratic_terms["col"], fb.quadratic_terms["col"])
+        np.testing.assert_allclose(fa.quadratic_terms["coeff"], fb.quadratic_terms["coeff"], rtol=1e-13, atol=0)
+        assert np.array_equal(fa.affine_terms.view(np.int64), fb.affine_terms.view(np.int64)) and fa.constant == fb.constant
+        ca, cb = list(a.constraints)[0].f, list(b_.constraints)[0].f
+        assert np.array_equal(ca.terms.view(np.int64), cb.terms.view(np.int64)) and np.array_equal(ca.constants, cb.constants)
+        assert np.all(fa.quadratic_terms["coeff"] != 0)
+    a.close(); b_.close()
