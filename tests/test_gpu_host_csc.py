@@ -344,3 +344,46 @@ def test_overlapped_moi_boundary_equals_the_serial_one(n, r, m):
         assert np.array_equal(ca.terms.view(np.int64), cb.terms.view(np.int64)) and np.array_equal(ca.constants, cb.constants)
         assert np.all(fa.quadratic_terms["coeff"] != 0)
     a.close(); b_.close()
+
+
+@pytest.mark.parametrize("handoff", ["host_csc", "device", "moi"])
+def test_side_lane_commits_of_staged_parameters(handoff):
+    """Parameters that only side-lane records read (the constraint data of a config-3 shaped model) are committed on the SIDE stream
+    (pmt_plan_commit_lane) so that the contraction does not wait for their upload; eight staged solves in a row (both staging slots, every
+    value rewritten each time): what the solver sees always belongs to THIS solve's buffers"""
+    n, r, mi = 256, 1024, 40                                      # r > 256: the contraction has split tiles, i.e. takes a while
+    rng = np.random.default_rng(5)
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", handoff=handoff)
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model)
+    b = P.DeviceUniformParameter((r,), 2, model)
+    residual = A * x - b
+    P.objective(model, P.Minimize, P.dot(residual, residual))
+    bufs = {"G": model.parameter_array(mi, n), "h": model.parameter_array(mi), "l": model.parameter_array(n)}
+    for v in bufs.values():
+        v[...] = rng.random(v.shape)
+    G, h, lo = (P.Parameter(model, val=bufs[k]) for k in ("G", "h", "l"))
+    P.constraint(model, G * x, "<=", h)
+    P.constraint(model, x, ">=", lo)
+    P.solve(model)
+    cG = next(c for c in model.constraints if c.nrows == mi)
+    cl = next(c for c in model.constraints if c.nrows == n)
+    assert all(getattr(p, "_commit_on_side_lane", False) for p in (G, h, lo)), "constraint data should be committed on the side lane"
+    assert not getattr(A, "_commit_on_side_lane", False)
+    for it in range(8):
+        for v in bufs.values():
+            v[...] = rng.random(v.shape) + it
+        model.stage_parameters()
+        P.solve(model)
+        if handoff == "moi":
+            fG, fl = cG.f, cl.f
+            assert np.array_equal(fG.terms["coeff"].reshape(mi, n), bufs["G"]) and np.array_equal(fG.constants, 0.0 - bufs["h"])
+            assert np.array_equal(fl.constants, 0.0 - bufs["l"])
+        else:
+            got = model.device_qp.host.as_dict() if handoff == "host_csc" else model.device_qp.fetch()
+            import scipy.sparse as sp
+            Ad = sp.csc_matrix(got["A"], shape=(n + mi, n)).toarray()
+            assert np.array_equal(Ad[:n], np.eye(n)) and np.array_equal(Ad[n:], bufs["G"])
+            assert np.array_equal(got["l"][:n], bufs["l"]) and np.array_equal(got["u"][n:], bufs["h"])
+    model.wait_staged()
+    model.close()
