@@ -200,6 +200,17 @@ int wait(Engine *e, Signal completion, double timeout_s) {
 #ifdef PMT_TUNING
     if (dbg()) fprintf(stderr, "[dma %.0f] wait on %lx: value %ld\n", dnow(), (unsigned long)completion.handle, (long)*completion.value);
 #endif
+    // The transfers of a re-evaluation are a couple of milliseconds away at most: poll the signal's word first, as the HIP runtime's own
+    // stream synchronisation does by default (a blocked wait wakes up 10-40 us after the engine's interrupt, more on a busy host); block
+    // only when the copies are not about to finish
+    for (;;) {
+        const int64_t v = __atomic_load_n(completion.value, __ATOMIC_ACQUIRE);
+        if (v < 0) return fail(PMT_HIP_ERROR, "host delivery: the copy engine reported an error");
+        if (v == 0) return PMT_OK;
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        if ((double)(ts.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts.tv_nsec - ts0.tv_nsec) > 6e-3) break;
+        __builtin_ia32_pause();
+    }
     for (;;) {
         const hsa_signal_value_t v = e->api.signal_wait_scacquire(hsa_signal_t{completion.handle}, HSA_SIGNAL_CONDITION_LT, 1, slice, HSA_WAIT_STATE_BLOCKED);
         if (v < 0) return fail(PMT_HIP_ERROR, "host delivery: the copy engine reported an error");
