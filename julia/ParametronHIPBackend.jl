@@ -277,6 +277,7 @@ mutable struct HIPObjective
     nlin::Int
     cbuf::Vector{Float64}  # where the constant is fetched to: preallocated (update! allocates nothing)
     P_values::DevPtr       # host_csc: alpha * P in CSC order, upper triangle
+    host_quad::Vector{Float64}   # :moi with a canonical objective: the page-locked memory the objective's quadratic_terms vector views (empty otherwise)
 end
 
 struct HIPConstraint
@@ -355,7 +356,7 @@ function record_objective!(hm::HIPModel, objective, rec)
         nq = d.rows * d.cols
         quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16), H.alloc(hm.plan, 8)
         H.bilinear!(quad, d.buf, d.ld, d.rows, d.cols, xv, yv, 1, hm.varmap, rec)
-        return HIPObjective(objective, quad, lin, constant, nq, 0, zeros(1), DevPtr(C_NULL))
+        return HIPObjective(objective, quad, lin, constant, nq, 0, zeros(1), DevPtr(C_NULL), Float64[])
     end
     da = analyse_lsq(objective.expr)
     A, lda, r, n = operand!(hm, da, rec)
@@ -368,7 +369,7 @@ function record_objective!(hm::HIPModel, objective, rec)
         ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(r, n))
         hm.host.Px = H.host_alloc(nq)
         H.quad_gram_csc_deliver!(Pv, hm.host.Px, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, hm.varmap, sense_sign, ws, rec)
-        return HIPObjective(objective, DevPtr(C_NULL), lin, constant, 0, n, zeros(1), Pv)
+        return HIPObjective(objective, DevPtr(C_NULL), lin, constant, 0, n, zeros(1), Pv, Float64[])
     end
     if r * n * n <= hm.literal_limit
         # literal: the reference's term order and coefficients bit for bit (src/functions.jl:702-709 over :548-576, moi_interop.jl:45-62)
@@ -377,14 +378,24 @@ function record_objective!(hm::HIPModel, objective, rec)
         quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * nl), H.alloc(hm.plan, 8)
         H.affine_assemble!(res, resc, A, lda, r, n, xvar, b, da.sign, rec)
         H.quad_expand!(quad, lin, constant, r, res, n, resc, res, n, resc, 1, hm.varmap, rec)
-        return HIPObjective(objective, quad, lin, constant, nq, nl, zeros(1), DevPtr(C_NULL))
+        return HIPObjective(objective, quad, lin, constant, nq, nl, zeros(1), DevPtr(C_NULL), Float64[])
     end
     issorted([v.index for v in da.x], lt = <=) || throw(Unsupported("canonical objective needs strictly increasing variables"))
     nq = div(n * (n + 1), 2)
     quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * n), H.alloc(hm.plan, 8)
     ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(r, n))
+    # The reference's own boundary, overlapped: the objective's quadratic_terms vector is made a view of page-locked memory (24-byte isbits
+    # MOI.ScalarQuadraticTerm{Float64} = pmt_quadratic_term; the function object is mutable, src/moi_interop.jl:44-47) and the contraction
+    # delivers the terms into it row band by row band while it runs (pmt_quad_gram_deliver_f64): nothing is copied on the host afterwards.
+    T = MOI.ScalarQuadraticTerm{Float64}
+    if isbitstype(T) && sizeof(T) == 24 && nq > 0
+        hq = H.host_alloc(3 * nq)
+        H.quad_gram_deliver!(quad, Ptr{Cvoid}(pointer(hq)), lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, 1, hm.varmap, ws, rec)
+        objective.f.quadratic_terms = unsafe_wrap(Vector{T}, Ptr{T}(pointer(hq)), nq)
+        return HIPObjective(objective, quad, lin, constant, nq, n, zeros(1), DevPtr(C_NULL), hq)
+    end
     H.quad_gram!(quad, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, 1, hm.varmap, ws, rec)
-    HIPObjective(objective, quad, lin, constant, nq, n, zeros(1), DevPtr(C_NULL))
+    HIPObjective(objective, quad, lin, constant, nq, n, zeros(1), DevPtr(C_NULL), Float64[])
 end
 
 piece_rows(hm::HIPModel, p::DenseAffine) = (d = device_param!(hm, p.A); p.transposed ? d.cols : d.rows)
@@ -569,9 +580,13 @@ end
 "update!(objective, optimizer, varmap) of src/moi_interop.jl:131-137 with the builders and the MOI copy done on the device"
 function Parametron.update!(o::HIPObjective, hm::HIPModel, optimizer)
     f = o.objective.f
-    resize!(f.quadratic_terms, o.nquad)                              # in place, as the reference does (:48,53): no-ops after the first solve
-    resize!(f.affine_terms, o.nlin)
-    H.fetch!(hm.plan, f.quadratic_terms, o.quad)
+    resize!(f.affine_terms, o.nlin)                                  # in place, as the reference does (:48,53): no-ops after the first solve
+    if isempty(o.host_quad)
+        resize!(f.quadratic_terms, o.nquad)
+        H.fetch!(hm.plan, f.quadratic_terms, o.quad)
+    else
+        H.fetch_synchronize(hm.plan)                                 # the delivered quadratic terms have landed in f.quadratic_terms' memory
+    end
     H.fetch!(hm.plan, f.affine_terms, o.lin)
     H.fetch!(hm.plan, o.cbuf, o.constant)
     H.synchronize(hm.plan)
