@@ -586,6 +586,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # the FIRST collective builds the RCCL communicator (hundreds of ms with the GPU idle): pay for that here, in front of the workload's
+        # spin-up and warm-up steps, not in the barrier that brackets the timed region — behind it the first timed steps ran 8 % slow while
+        # the clocks came back (20 steps under torchrun: 746/s against 810/s without)
+        dist.barrier()
+        torch.cuda.synchronize()
     if args.workload == "batch":
         return run_batch(args, torch, dist, _lib, rank, world)
 
