@@ -704,10 +704,24 @@ def main():
         # every rank: BASELINE config 4 sharded by instance over the N ranks (N = 1: the same code path, single-rank communicator)
         from parametron_jl_amd import batch
         ksteps = max(20, min(args.steps, 100))
+        # This section has only ever run with one rank on hardware.  Should a collective of it hang with N > 1 (one rank failing alone), the
+        # headline — complete at this point — must still come out: after 150 s rank 0 prints the line without the section and every rank exits.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out.setdefault("configs", {})["C4_sharded"] = {"error": "timeout: the sharded section did not finish within 150 s"}
+                out["ranks_seen"] = None
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(150.0, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             sharded = batch.measure(torch, dist, rank, world, ksteps, args.warmup)
         except Exception as e:                  # (a failing side section must not take the headline with it; every rank fails alike)
             sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
         if rank == 0:
             out.setdefault("configs", {})["C4_sharded"] = sharded
             out["ranks_seen"] = sharded.get("ranks_seen") if isinstance(sharded, dict) else None
