@@ -213,8 +213,22 @@ int pmt_quad_gram_csc_deliver_f64(const double *A, int64_t lda, int64_t rows, in
 int pmt_quad_gram_deliver_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
                               int moi, const int64_t *varmap, pmt_quadratic_term *out_quad, pmt_quadratic_term *host_quad, int nstages,
                               pmt_linear_term *out_lin, double *out_const, void *workspace, void *stream);
-/* host: block until every copy on the fetch stream of `stream` (a HIP stream, not a recording handle) has landed */
+/* host: block until every copy on the fetch stream of `stream` (a HIP stream, not a recording handle) has landed.  PMT_HIP_ERROR when a
+ * delivery failed on the device: a transfer that never started, a courier without progress, or a split tile of a staged contraction whose
+ * first half never arrived (the tile is then NaN in out_P_values / out_quad — never a plausible half sum — and this call says so). */
 int pmt_fetch_synchronize(void *stream);
+
+/* How results leave for the host (recorded fetches, the deliveries above), process-wide, from the next replay / call on:
+ *   0  automatic (default): the copy engine (HSA SDMA transfers started by signals the kernels set) when the process's HSA runtime and the
+ *      device's agent are found — matched by PCI domain:bus:device, an ambiguous match counts as none — kernel copies otherwise;
+ *   1  the copy engine or PMT_STATE_ERROR (a deployment that must not fall back silently);
+ *   2  kernel copies (a courier kernel for deliveries, copy kernels for recorded fetches) on the stream's fetch stream.
+ * Same bytes in the host arrays either way.  pmt_get_host_delivery reports the mode and whether `device` has a usable copy engine. */
+int pmt_set_host_delivery(int mode);
+int pmt_get_host_delivery(int device, int *out_mode, int *out_copy_engine);
+/* TEST HOOK (fault injection; 0 = off, the default).  1: in a staged contraction the first halves of split tiles never announce
+ * themselves, and the second halves' bounded wait is cut from 2 s to 20 ms — exercises the error path of pmt_fetch_synchronize above. */
+int pmt_set_fault_injection(int what);
 
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
  * bilinearmul! src/functions.jl:840-858 (the Q' pairing quirk is reproduced).
@@ -417,7 +431,10 @@ int64_t pmt_profile_report(char *host_buf, size_t cap);
  * rank 0 to the others (any launcher: torch.distributed, MPI, a file).  xGMI is point-to-point, so the exchange is the DIRECT schedule
  * — one grouped ncclSend / ncclRecv pair per peer, each over that peer's own link — not a ring.
  *   pmt_comm_unique_id        rank 0: a fresh id (128 bytes)
- *   pmt_comm_init_rank        every rank; nranks == 1 needs neither an id nor RCCL
+ *   pmt_comm_init_rank        every rank; nranks == 1 with a NULL id needs no RCCL (nothing to exchange); nranks == 1 WITH an id builds a
+ *                             real one-rank RCCL communicator whose exchange is a grouped ncclSend/ncclRecv to itself — the N-rank
+ *                             code path on a single GPU
+ *   pmt_comm_rccl_calls       ncclSend + ncclRecv calls this communicator has issued so far
  *   pmt_batch_num_chunks / pmt_batch_chunk_range / pmt_batch_gathered_offset
  *                             the chunk schedule, pure host arithmetic: chunk c of a rank = local instances [c * chunk, min(., per_rank))
  *                             (chunk <= 0: one chunk); the slab of global instance i sits at i * stride doubles of `gathered`
@@ -428,6 +445,7 @@ int64_t pmt_profile_report(char *host_buf, size_t cap);
  * ------------------------------------------------------------------------------------- */
 int pmt_comm_unique_id(void *out_id_128_bytes);
 int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_128_bytes, int device, void **out_comm);
+int64_t pmt_comm_rccl_calls(void *comm);
 int pmt_comm_destroy(void *comm);
 int64_t pmt_batch_num_chunks(int64_t per_rank, int64_t chunk);
 int pmt_batch_chunk_range(int64_t per_rank, int64_t chunk, int64_t c, int64_t *lo, int64_t *hi);
@@ -471,6 +489,13 @@ int pmt_plan_synchronize(pmt_plan *plan);
  * pmt_quad_gram_csc_deliver_f64) have landed; the next pmt_plan_update waits on the device until they have read their buffers.
  * A plan with recorded fetches cannot be instantiated as a hipGraph. */
 int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
+/* pitched recorded fetch: `height` rows of `width_bytes`, row r at device_src + r*src_pitch -> host_dst + r*dst_pitch.  The CSC values of a
+ * DENSE constraint block are its Parameter matrix column by column (update!(::MOI.VectorAffineFunction) writes one term per entry,
+ * src/moi_interop.jl:64-81): they leave straight out of the Parameter's (padded) device buffer for the block's row range in every column
+ * of the solver's stacked matrix — no kernel, the copy engine's rectangle copy where it exists. */
+int pmt_plan_record_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
+                             size_t height);
+/* host: block until the plan's recorded fetches / deliveries have landed; errors as pmt_fetch_synchronize */
 int pmt_plan_fetch_synchronize(pmt_plan *plan);
 
 /* Staged (overlapped) uploads of host-updated Parameter values — `Parameter(model, val=buf)` / `Parameter(f, val, model)`,

@@ -241,6 +241,19 @@ host_free(v::Vector{Float64}) = check(ccall((:pmt_host_free, lib), Cint, (Ptr{Cv
 "while recording: `dst` (page-locked) receives `bytes` from `src` on the plan's fetch path as soon as what was recorded before it on its lane is done"
 record_fetch!(plan::Plan, dst::Array, src::DevPtr, bytes::Integer = sizeof(dst)) =
     check(ccall((:pmt_plan_record_fetch, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Csize_t), plan.handle, dst, src, bytes))
+"while recording, pitched: `cols` columns of `rows` doubles out of a padded device matrix (leading dimension `lds`) into host columns `dst_pitch_bytes` apart —
+the CSC values of a dense constraint block leave straight out of its Parameter buffer"
+record_fetch_matrix!(plan::Plan, dst::Ptr{Float64}, dst_pitch_bytes, src::DevPtr, lds, rows, cols) =
+    check(ccall((:pmt_plan_record_fetch_2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, DevPtr, Csize_t, Csize_t, Csize_t),
+                plan.handle, dst, dst_pitch_bytes, src, 8 * lds, 8 * rows, cols))
+"how results leave for the host: 0 automatic, 1 copy engine or an error, 2 kernel copies (include/parametron_hip.h)"
+set_host_delivery(mode::Integer) = check(ccall((:pmt_set_host_delivery, lib), Cint, (Cint,), mode))
+"(mode, copy engine usable on `device`)"
+function host_delivery(device::Integer = 0)
+    mode, engine = Ref{Cint}(0), Ref{Cint}(0)
+    check(ccall((:pmt_get_host_delivery, lib), Cint, (Cint, Ref{Cint}, Ref{Cint}), device, mode, engine))
+    (Int(mode[]), engine[] != 0)
+end
 "host: every recorded fetch / delivered band group of the last update has landed"
 fetch_synchronize(plan::Plan) = check(ccall((:pmt_plan_fetch_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
 "pitched device -> host copy on the plan's stream: the columns of a padded device matrix into a dense host column range (setup / serial path)"

@@ -38,6 +38,21 @@ def profile_report():
     return out
 
 
+def set_host_delivery(mode):
+    """How results leave for the host (recorded fetches, band-wise deliveries): 0 / "auto" copy engine when there is one, 1 / "engine" copy
+    engine or an error, 2 / "kernels" the kernel-copy fallback (pmt_set_host_delivery)."""
+    mode = {"auto": 0, "engine": 1, "kernels": 2}.get(mode, mode)
+    _lib.call("pmt_set_host_delivery", int(mode))
+
+
+def host_delivery(device=0):
+    """(mode, copy engine usable on `device`)"""
+    import ctypes as C
+    mode, engine = C.c_int(0), C.c_int(0)
+    _lib.call("pmt_get_host_delivery", int(device), C.byref(mode), C.byref(engine))
+    return mode.value, bool(engine.value)
+
+
 def findallocs(io, expr):
     """findallocs(io, expr) (src/debug.jl:4-23): re-evaluate `expr` and report what it costs.  The reference prints the heap bytes each
     node of the expression tree allocates (they must be 0); on the device the analogue of an allocation is growth of the plan's

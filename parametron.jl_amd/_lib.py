@@ -64,6 +64,9 @@ SIGNATURES = {
     "pmt_quad_gram_csc_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),
     "pmt_fetch_synchronize": (_ci, [_vp]),
+    "pmt_set_host_delivery": (_ci, [_ci]),
+    "pmt_get_host_delivery": (_ci, [_ci, C.POINTER(_ci), C.POINTER(_ci)]),
+    "pmt_set_fault_injection": (_ci, [_ci]),
     "pmt_bilinear_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _vp, _vp]),
     "pmt_fill_uniform_matrix_f64": (_ci, [_vp, _i64, _i64, _i64, _u64, _f64, _vp]),
     "pmt_plan_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
@@ -103,6 +106,7 @@ SIGNATURES = {
     "pmt_comm_unique_id": (_ci, [_vp]),
     "pmt_comm_init_rank": (_ci, [_ci, _ci, _vp, _ci, C.POINTER(_vp)]),
     "pmt_comm_destroy": (_ci, [_vp]),
+    "pmt_comm_rccl_calls": (_i64, [_vp]),
     "pmt_batch_num_chunks": (_i64, [_i64, _i64]),
     "pmt_batch_chunk_range": (_ci, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "pmt_batch_gathered_offset": (_i64, [_ci, _i64, _i64, _i64]),
@@ -126,6 +130,7 @@ SIGNATURES = {
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
     "pmt_plan_record_fetch": (_ci, [_vp, _vp, _vp, _sz]),
+    "pmt_plan_record_fetch_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "pmt_plan_fetch_synchronize": (_ci, [_vp]),
     "pmt_plan_stage_upload": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_stage_upload_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),

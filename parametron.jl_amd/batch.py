@@ -79,7 +79,9 @@ def exchange_chunks(dist, local, gathered, rank, world, chunk):
 class Communicator:
     """pmt_comm_*: the library's own RCCL communicator.  The launcher (torch.distributed here) only carries rank 0's unique id."""
 
-    def __init__(self, torch, dist, rank, world, device_index):
+    def __init__(self, torch, dist, rank, world, device_index, rccl_single=False):
+        """rccl_single: a single rank still builds a real (one-rank) RCCL communicator and exchanges with itself — the N-rank code path on
+        one GPU; False: a single rank loads no RCCL at all"""
         self.rank, self.world = rank, world
         self.handle = C.c_void_p()
         if world > 1:
@@ -90,8 +92,15 @@ class Communicator:
             dist.broadcast(t, src=0)
             ident = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
             _lib.call("pmt_comm_init_rank", world, rank, C.cast(ident, C.c_void_p), device_index, C.byref(self.handle))
+        elif rccl_single:
+            ident = (C.c_char * 128)()
+            _lib.call("pmt_comm_unique_id", C.cast(ident, C.c_void_p))
+            _lib.call("pmt_comm_init_rank", 1, 0, C.cast(ident, C.c_void_p), device_index, C.byref(self.handle))
         else:
             _lib.call("pmt_comm_init_rank", 1, 0, None, device_index, C.byref(self.handle))
+
+    def rccl_calls(self):
+        return int(_lib.load().pmt_comm_rccl_calls(self.handle))
 
     def close(self):
         if self.handle:

@@ -89,8 +89,9 @@ int rccl_fail(const char *what, int code) {
 }  // namespace
 
 struct Comm {
-    void *nccl = nullptr;
+    void *nccl = nullptr;                    // null: a single rank without RCCL (nothing to exchange, nothing loaded)
     int rank = 0, nranks = 1, device = 0;
+    int64_t rccl_calls = 0;                  // ncclSend + ncclRecv issued so far (pmt_comm_rccl_calls)
     hipStream_t comm_stream = nullptr;       // the exchange runs here, beside the computation on the caller's stream
     hipEvent_t computed = nullptr, gathered = nullptr;
 };
@@ -112,7 +113,11 @@ extern "C" int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_12
     PMT_REQUIRE(out_comm && nranks >= 1 && rank >= 0 && rank < nranks, PMT_INVALID_ARGUMENT, "comm_init_rank: bad argument");
     PMT_REQUIRE(nranks == 1 || unique_id_128_bytes, PMT_INVALID_ARGUMENT, "comm_init_rank: null unique id");
     Rccl *R = nullptr;
-    if (nranks > 1) {                        // a single rank needs no communicator (and no RCCL); checked BEFORE anything is allocated
+    // A single rank needs no communicator (and no RCCL) — unless it brings a unique id: then it gets a real one-rank RCCL communicator and
+    // its exchange is a grouped ncclSend/ncclRecv to itself, i.e. the code path of N ranks on one GPU (how the binding is tested on a
+    // single-GPU box).  Checked BEFORE anything is allocated.
+    const bool use_rccl = nranks > 1 || unique_id_128_bytes != nullptr;
+    if (use_rccl) {
         R = rccl();
         if (!R->handle || !R->why.empty()) return fail(PMT_STATE_ERROR, "RCCL is not available: " + R->why);
     }
@@ -124,7 +129,7 @@ extern "C" int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_12
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gathered, hipEventDisableTiming);
     // every failure from here on leaves through pmt_comm_destroy: the stream and the events go with the communicator
     if (e != hipSuccess) { (void)hipGetLastError(); (void)pmt_comm_destroy(c); return fail(PMT_HIP_ERROR, std::string("comm_init_rank: ") + hipGetErrorString(e)); }
-    if (nranks > 1) {
+    if (use_rccl) {
         UniqueId id;
         memcpy(&id, unique_id_128_bytes, sizeof id);
         int rc = R->comm_init_rank(&c->nccl, nranks, id, rank);
@@ -133,6 +138,8 @@ extern "C" int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_12
     *out_comm = c;
     return PMT_OK;
 }
+
+extern "C" int64_t pmt_comm_rccl_calls(void *comm) { return comm ? reinterpret_cast<Comm *>(comm)->rccl_calls : 0; }
 
 extern "C" int pmt_comm_destroy(void *comm) {
     Comm *c = reinterpret_cast<Comm *>(comm);
@@ -176,10 +183,21 @@ static int exchange_range(Comm *c, const double *local, double *gathered, int64_
     if (count == 0) return PMT_OK;
     double *mine = gathered + pmt_batch_gathered_offset(c->rank, per_rank, lo, stride);
     const double *src = local + lo * stride;
+    if (c->nranks == 1 && c->nccl) {
+        // one-rank RCCL communicator: this rank's own block travels through RCCL (send to self / receive from self in one group)
+        PMT_RCCL_READY();
+        PMT_RCCL_CHECK(R->group_start());
+        PMT_RCCL_CHECK(R->send(src, count, kNcclDouble, 0, c->nccl, stream));
+        PMT_RCCL_CHECK(R->recv(mine, count, kNcclDouble, 0, c->nccl, stream));
+        PMT_RCCL_CHECK(R->group_end());
+        c->rccl_calls += 2;
+        return PMT_OK;
+    }
     if (mine != src) PMT_HIP_CHECK(hipMemcpyAsync(mine, src, count * sizeof(double), hipMemcpyDeviceToDevice, stream));
     if (c->nranks == 1) return PMT_OK;
     PMT_RCCL_READY();
     PMT_RCCL_CHECK(R->group_start());
+    c->rccl_calls += 2 * (c->nranks - 1);
     for (int k = 1; k < c->nranks; ++k) {
         const int to = (c->rank + k) % c->nranks, from = (c->rank - k + c->nranks) % c->nranks;       // staggered: every link busy in every step
         PMT_RCCL_CHECK(R->send(src, count, kNcclDouble, to, c->nccl, stream));

@@ -26,7 +26,7 @@ struct CourierArgs {
     double *dst;                          // device address of the page-locked host array
     long long *ready;                     // per band group: 1 = in the making, 0 = complete (cleared by the one-thread kernel behind the group's stage)
     unsigned *done;                       // workgroups that have finished; the last one re-arms the flags for the next launch
-    int *error;                           // set to 1 on timeout
+    int *error;                           // set to 1 on timeout (page-locked host word, gram.hip SideStream::err_host)
     int ngroups;
     long long off[MAXGROUPS + 1];
 };
@@ -97,6 +97,16 @@ __global__ __launch_bounds__(256) void to_host_kernel(const unsigned long long *
     if (o < nb) *reinterpret_cast<unsigned long long *>(db + o) = *reinterpret_cast<const unsigned long long *>(sb + o);
 }
 
+// pitched: `height` rows of `wwords` 8-byte words; row r at src + r * spitch / dst + r * dpitch (pitches in words)
+__global__ __launch_bounds__(256) void to_host_2d_kernel(const unsigned long long *__restrict__ src, unsigned spitch, unsigned long long *__restrict__ dst,
+                                                         unsigned dpitch, unsigned wwords, unsigned height) {
+    const unsigned total = wwords * height;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned r = i / wwords, c = i - r * wwords;
+        dst[(size_t)r * dpitch + c] = src[(size_t)r * spitch + c];
+    }
+}
+
 // device-visible address of a page-locked host buffer, or null when it is not mapped (pageable memory: the runtime's copy is used)
 void *host_device_pointer(void *host) {
     void *d = nullptr;
@@ -125,6 +135,16 @@ int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s) 
                    reinterpret_cast<unsigned long long *>(static_cast<char *>(dst_dev) + o), n);
     }
     return check_launch("to_host_kernel");
+}
+
+int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t dst_pitch, size_t width_bytes, size_t height, hipStream_t s) {
+    PMT_REQUIRE(width_bytes / 8 * height < ((size_t)1 << 32) && src_pitch / 8 < ((size_t)1 << 32) && dst_pitch / 8 < ((size_t)1 << 32), PMT_DIMENSION_MISMATCH,
+                "host delivery: a pitched block of 2^32 words or more");
+    if (!width_bytes || !height) return PMT_OK;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, cdiv((int64_t)(width_bytes / 8 * height), 1024)));
+    PMT_LAUNCH(to_host_2d_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const unsigned long long *>(src), (unsigned)(src_pitch / 8),
+               static_cast<unsigned long long *>(dst_dev), (unsigned)(dst_pitch / 8), (unsigned)(width_bytes / 8), (unsigned)height);
+    return check_launch("to_host_2d_kernel");
 }
 
 }  // namespace pmt

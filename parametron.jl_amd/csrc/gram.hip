@@ -31,10 +31,11 @@ size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s);
 int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
+int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t dst_pitch, size_t width_bytes, size_t height, hipStream_t s);
 void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, hipStream_t s);
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
 constexpr int DELIVER_ORDER_W = 2; // a delivery computes the tiles in super-columns of two tile columns: the column bands finish in ascending order
@@ -116,13 +117,17 @@ namespace pmt {
 struct SideStream {
     hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr; int device = -1;
     void *counters = nullptr;
+    // error word of the kernels that wait on other workgroups with a bound (the courier, the pair fold of gram_sk.hip): page-locked host
+    // memory the kernels store to (system scope) and the host reads without a copy in fetch_synchronize.  0 = fine, ERR_* otherwise
+    int *err_host = nullptr, *err_dev = nullptr;
     hipStream_t fetch = nullptr; hipEvent_t fetch_done = nullptr; bool fetch_pending = false;
     std::vector<std::pair<dma::Engine *, dma::Signal>> dma_pending;     // completion signals of copy-engine transfers in flight
     std::vector<std::shared_ptr<void>> keepalive;                        // ... and the owners of their signals (an immediate call's go with the call)
     bool in_replay = false;                                              // a plan's tape is being replayed: P's transfers are submitted at its end
     std::vector<std::function<int()>> deferred;
 };
-// layout of `counters`: [MAXGROUPS x u64 unused][MAXGROUPS x i64 courier flags (armed = 1)][u32 courier done][i32 courier error]
+constexpr int ERR_COURIER = 1, ERR_PAIR_FOLD = 2;
+// layout of `counters`: [MAXGROUPS x u64 unused][MAXGROUPS x i64 courier flags (armed = 1)][u32 courier done][u32 unused]
 constexpr size_t PROGRESS_OFFSET = 0;
 constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
 constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
@@ -157,13 +162,25 @@ static SideStream *side_stream(hipStream_t s) {
               hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&ss.counters, COUNTER_BYTES) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void **>(&ss.err_host), 64, hipHostMallocDefault) == hipSuccess &&
               hipMemsetAsync(ss.counters, 0, COUNTER_BYTES, s) == hipSuccess;      // on the calling stream: ordered before its first kernel
+    if (ok) {
+        memset(ss.err_host, 0, 64);
+        ss.err_dev = static_cast<int *>(host_device_pointer(ss.err_host));
+        ok = ss.err_dev != nullptr;
+    }
     if (ok) {
         static const long long armed[MAXGROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         ok = hipMemcpyAsync(static_cast<char *>(ss.counters) + FLAGS_OFFSET, armed, sizeof armed, hipMemcpyHostToDevice, s) == hipSuccess;
     }
     if (prev != dev) (void)hipSetDevice(prev);
-    if (!ok) { (void)hipGetLastError(); g_side.erase(s); return nullptr; }
+    if (!ok) {
+        (void)hipGetLastError();
+        if (ss.err_host) (void)hipHostFree(ss.err_host);
+        if (ss.counters) (void)hipFree(ss.counters);
+        g_side.erase(s);
+        return nullptr;
+    }
     ss.device = dev;
     return &ss;
 }
@@ -203,6 +220,7 @@ void release_side_stream(hipStream_t s) {
     if (it->second.fetch_done) (void)hipEventDestroy(it->second.fetch_done);
     (void)wait_dma_pending(&it->second);
     if (it->second.counters) (void)hipFree(it->second.counters);
+    if (it->second.err_host) (void)hipHostFree(it->second.err_host);
     g_side.erase(it);
 }
 
@@ -227,18 +245,25 @@ FetchState::~FetchState() {
 
 // D2H copy ordered behind everything enqueued on `after` (the plan's stream or its side stream) so far.  Preferred: the copy engine, started
 // by a signal that a one-thread kernel on `after` sets (hsadma.hip) — nothing of it runs on a CU.  Otherwise a kernel copy / the runtime's
-// copy on the fetch stream of `s`.
-int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st) {
+// copy on the fetch stream of `s`.  r.height > 0: a PITCHED copy of r.height rows of `bytes` bytes each (a matrix block whose device copy
+// is padded, or that lands in a column range of a wider host matrix); the engine does those natively (hsa_amd_memory_async_copy_rect).
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st, FetchRect r) {
     SideStream *ss = side_stream(s);
     if (!ss) return fail(PMT_STATE_ERROR, "fetch_async: no auxiliary streams for this stream");
     // A fetch behind the plan's OWN stream inside a replay (its producer finishes with the objective's kernels, e.g. the constant, whose
     // serial chain is itself queued at the end of the replay) is issued at the end of the replay, behind that chain's join and behind the
     // band groups of a delivery (the copy engine's queue is first in, first out).
     if (ss->in_replay && after == s) {
-        ss->deferred.push_back([=]() -> int { return fetch_async(s, after, order_event, host_dst, device_src, bytes, st); });
+        ss->deferred.push_back([=]() -> int { return fetch_async(s, after, order_event, host_dst, device_src, bytes, st, r); });
         return PMT_OK;
     }
-    if (st && !st->created && !st->tried) {
+    const int mode = dma::delivery_mode();
+    // whichever way this entry's previous copy went, it has read the device buffer (and left the host one) before the next one is queued
+    if (st && st->pending) { if (int rc = dma::wait(st->eng, st->done, 10.0)) return rc; st->pending = false; }
+    // the engine is handed physical pages: only page-locked, device-mapped destinations qualify (a pageable numpy / Julia array takes the
+    // runtime's copy below, which stages it)
+    if (st && st->pinned < 0) st->pinned = host_device_pointer(host_dst) ? 1 : 0;
+    if (mode != 2 && st && st->pinned == 1 && !st->created && !st->tried) {
         st->tried = true;
         st->eng = dma::get(ss->device);
         if (st->eng) {
@@ -246,13 +271,17 @@ int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *
             else st->eng = nullptr;
         }
     }
-    if (st && st->created) {
-        if (st->pending) { if (int rc = dma::wait(st->eng, st->done, 10.0)) return rc; st->pending = false; }
+    const bool engine = mode != 2 && st && st->created;
+    if (mode == 1 && !engine)
+        return fail(PMT_STATE_ERROR, "host delivery: the copy engine was demanded (pmt_set_host_delivery(1)) but is not available for this transfer "
+                                     "(no HSA agent match, or a pageable destination)");
+    if (engine) {
         dma::signal_set(st->eng, st->dep, 1);
         dma::signal_set(st->eng, st->done, 1);
         if (int rc = dma::launch_signal_store(st->dep, after)) return rc;
         st->pending = true;
         ss->dma_pending.emplace_back(st->eng, st->done);
+        if (r.height) return dma::copy_rect_to_host(st->eng, host_dst, r.dst_pitch, device_src, r.src_pitch, bytes, r.height, &st->dep, st->done);
         return dma::copy_to_host(st->eng, host_dst, device_src, bytes, &st->dep, st->done);
     }
     if (int rc = ensure_fetch_stream(ss)) return rc;
@@ -260,8 +289,12 @@ int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *
     PMT_HIP_CHECK(hipStreamWaitEvent(ss->fetch, order_event, 0));
     // a <= 16-VGPR copy kernel that is co-resident with the contraction (deliver.hip) when the destination is page-locked, 8-byte words
     // and below 16 GiB; the runtime's copy otherwise
-    void *dst_dev = (bytes % 8 == 0 && bytes / 8 < (size_t)1 << 31) ? host_device_pointer(host_dst) : nullptr;
-    if (dst_dev) { if (int rc = launch_to_host(device_src, dst_dev, bytes, ss->fetch)) return rc; }
+    const size_t total = r.height ? r.height * r.dst_pitch : bytes;
+    const bool words = bytes % 8 == 0 && (!r.height || (r.dst_pitch % 8 == 0 && r.src_pitch % 8 == 0));
+    void *dst_dev = (words && total / 8 < (size_t)1 << 31) ? host_device_pointer(host_dst) : nullptr;
+    if (dst_dev && r.height) { if (int rc = launch_to_host_2d(device_src, r.src_pitch, dst_dev, r.dst_pitch, bytes, r.height, ss->fetch)) return rc; }
+    else if (dst_dev) { if (int rc = launch_to_host(device_src, dst_dev, bytes, ss->fetch)) return rc; }
+    else if (r.height) PMT_HIP_CHECK(hipMemcpy2DAsync(host_dst, r.dst_pitch, device_src, r.src_pitch, bytes, r.height, hipMemcpyDeviceToHost, ss->fetch));
     else PMT_HIP_CHECK(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ss->fetch));
     PMT_HIP_CHECK(hipEventRecord(ss->fetch_done, ss->fetch));
     ss->fetch_pending = true;
@@ -346,16 +379,22 @@ int fetch_synchronize(hipStream_t s) {
 #ifdef PMT_TUNING
     { const char *e = getenv("PMT_DMA_DEBUG"); if (e && e[0] == '2') trace_dma_pending(ss, s); }
 #endif
-    if (int rc = wait_dma_pending(ss)) return rc;
-    if (!f) return PMT_OK;
-    PMT_HIP_CHECK(hipStreamSynchronize(f));
-    int err = 0;
-    PMT_HIP_CHECK(hipMemcpy(&err, static_cast<char *>(counters) + DONE_OFFSET + sizeof(unsigned), sizeof(int), hipMemcpyDeviceToHost));
-    if (err) {
+    int rc = wait_dma_pending(ss);
+    if (!rc && f) PMT_HIP_CHECK(hipStreamSynchronize(f));
+    // the kernels' error word (page-locked, written with system-scope stores before the data the transfers above carried)
+    const int err = ss->err_host ? __atomic_exchange_n(ss->err_host, 0, __ATOMIC_ACQ_REL) : 0;
+    if (err == ERR_COURIER) {
+        // the courier left without re-arming: flags back to "in the making", completion count to zero
+        static const long long armed[MAXGROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
         PMT_HIP_CHECK(hipMemset(counters, 0, COUNTER_BYTES));
+        PMT_HIP_CHECK(hipMemcpy(static_cast<char *>(counters) + FLAGS_OFFSET, armed, sizeof armed, hipMemcpyHostToDevice));
         return fail(PMT_HIP_ERROR, "host delivery: the courier saw no progress of the contraction for 2 s and gave up; the host arrays are incomplete");
     }
-    return PMT_OK;
+    if (err == ERR_PAIR_FOLD)
+        return fail(PMT_HIP_ERROR, "host delivery: a split tile of the contraction never received its first half (pair fold); the tile was "
+                                   "written as NaN and the delivered quadratic coefficients are invalid");
+    if (err) return fail(PMT_HIP_ERROR, "host delivery: unknown device error " + std::to_string(err));
+    return rc;
 }
 
 hipStream_t side_stream_of(hipStream_t s) {
@@ -494,10 +533,16 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.
         SideStream *side = side_stream(s);
         const bool deliver = dplan.host != nullptr;
+        bool use_engine = false;
         if (deliver) {
             PMT_REQUIRE(side && side->counters, PMT_STATE_ERROR, "quad_gram_csc_deliver: no auxiliary streams for this stream");
             // Preferred: one copy-engine transfer per band group, each started by the signal set behind the group's stage (hsadma.hip)
-            if (!sig->tried) {
+            const int mode = dma::delivery_mode();
+            // the previous delivery of this entry must have read its array before this contraction overwrites it (whichever way it went)
+            if (sig->pending) { if (int rc = dma::wait(sig->eng, sig->done, 10.0)) return rc; sig->pending = false; }
+            // an immediate (unrecorded) call owns fresh signals: what earlier calls on this stream handed to the engine is awaited here
+            if (!side->in_replay) { if (int rc = wait_dma_pending(side)) return rc; }
+            if (mode != 2 && !sig->tried) {
                 sig->tried = true;
                 dma::Engine *eng = dma::get(side->device);
                 if (eng) {
@@ -506,9 +551,9 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     if (ok) sig->eng = eng;
                 }
             }
-            if (sig->eng) {
-                // the previous delivery must have read out_csc before this contraction overwrites it, and its signals are re-armed
-                if (sig->pending) { if (int rc = dma::wait(sig->eng, sig->done, 10.0)) return rc; sig->pending = false; }
+            use_engine = mode != 2 && sig->eng != nullptr;
+            PMT_REQUIRE(mode != 1 || use_engine, PMT_STATE_ERROR, "host delivery: the copy engine was demanded (pmt_set_host_delivery(1)) but is not available");
+            if (use_engine) {
                 for (int i = 0; i < dplan.ngroups; ++i) dma::signal_set(sig->eng, sig->dep[i], 1);
                 dma::signal_set(sig->eng, sig->done, dplan.ngroups);
             } else {
@@ -553,7 +598,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
             if (!deliver) {
-                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, nullptr, 0, s);
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, nullptr, 0, nullptr, s);
             } else {
                 // stage by stage; behind a stage that completes column bands, one thread stores 0 into the word the transfer of those bands waits
                 // for: the value of its dependency signal (copy engine, hsadma.hip) or the courier's flag (deliver.hip)
@@ -564,16 +609,16 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                 if (pair_flags) PMT_HIP_CHECK(hipMemsetAsync(pair_flags, 0, PAIR_FLAG_BYTES, s));
                 for (int st = 0; !rc && st < dplan.nstages; ++st) {
                     rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, deliver_order, dplan.seq_begin[st],
-                                        dplan.seq_count[st], pair_flags, (unsigned)(st + 1), s);
+                                        dplan.seq_count[st], pair_flags, (unsigned)(st + 1), side->err_dev, s);
                     const int grp = dplan.group_of[st];
                     if (!rc && grp >= 0) {
-                        dma::Signal word = sig->eng ? sig->dep[grp] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET) + grp};
+                        dma::Signal word = use_engine ? sig->dep[grp] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET) + grp};
                         rc = dma::launch_signal_store(word, s);
                     }
                 }
             }
             if (!rc && deliver) {
-                if (sig->eng) {
+                if (use_engine) {
                     // The engine works through its queue in submission order.  Inside a plan's replay the groups' transfers are therefore
                     // submitted at the END of the replay, behind the recorded fetches of the tape (q, A's values, bounds: ready within the
                     // first tenth of the contraction) — submitted here they would hold those back until the last band group has left.
@@ -593,7 +638,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     // band groups' flags and stores each finished group straight into the host array (deliver.hip)
                     char *cb = static_cast<char *>(side->counters);
                     rc = launch_courier(deliver_src, dplan.host_dev, reinterpret_cast<long long *>(cb + FLAGS_OFFSET), reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
-                                        reinterpret_cast<int *>(cb + DONE_OFFSET + sizeof(unsigned)), dplan.ngroups, dplan.off, side->fetch);
+                                        side->err_dev, dplan.ngroups, dplan.off, side->fetch);
                     if (rc) return rc;
                     PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
                     side->fetch_pending = true;

@@ -31,6 +31,9 @@ struct SKArgs {
     int seq_begin;    // this launch covers the tiles seq_begin .. seq_begin + T' - 1 of the sequence (a staged host delivery launches the
                       // contraction band range by band range; 0 and all tiles otherwise)
     unsigned *pair_flags; unsigned epoch;      // pair fold of a ranged launch (gram_sk.hip), or null
+    unsigned flag_value;                       // what a first half stores into its tile's flag: `epoch` (anything else only under fault injection)
+    int *error;                                // page-locked error word: a second half whose partner never showed up stores 2 here
+    long long pair_timeout;                    // bound of the pair wait in 100 MHz ticks
 };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)

@@ -22,6 +22,7 @@
 // with column group b, so the 16 (row group, column group) pairs of a 16x16 tile take 4 instructions whose B operand is read
 // from LDS with the column groups rotated by s = 0..3 (cbsz/abid broadcast is ignored for f64: tools/mfma_probe2.hip).
 // acc[tm][tn][s] of lane l = C[16tm + 4b + i][16tn + 4((b+s)&3) + j], i = l>>4, b = (l>>2)&3, j = l&3.
+#include "dma.h"
 #include "gram_common.h"
 
 // Codegen knobs.  The compiler's schedule of the stage loop moves by +-10 % with source changes that do not touch the loop.  Rounds 1-2
@@ -469,8 +470,10 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                     double late = 0.0;
                     while (__hip_atomic_load(&g.pair_flags[rtile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) {
                         __builtin_amdgcn_s_sleep(8);
-                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) { late = 1.0; break; }      // 2 s at 100 MHz
+                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > g.pair_timeout) { late = 1.0; break; }   // 2 s (100 MHz ticks)
                     }
+                    // reported, not only marked: pmt_plan_fetch_synchronize / pmt_fetch_synchronize return PMT_HIP_ERROR (gram.hip)
+                    if (late != 0.0 && g.error) __hip_atomic_store(g.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     lds[0][0][0] = late;                         // (the panels are idle between the stage loop and the epilogue)
                 }
                 __syncthreads();
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                     for (int r = 0; r < C::NACC; ++r) __hip_atomic_store(&w[r * C::NT], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __builtin_amdgcn_s_waitcnt(0);
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_store(&g.pair_flags[rtile], g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) __hip_atomic_store(&g.pair_flags[rtile], g.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
     #pragma unroll
                     for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
@@ -605,7 +608,7 @@ static int env_int(const char *name, int dflt) {
 // anything but `epoch`): tiles split exactly in two are summed inside the launch (see the kernel) instead of by the fix-up pass.
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, hipStream_t s) {
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s) {
     SKArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
@@ -637,10 +640,15 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.order_w = order_w;
     if (T <= 0) return PMT_OK;
     // pair fold: every tile of this ranged launch is split in exactly two halves held by neighbouring workgroups
-    g.pair_flags = nullptr; g.epoch = 0;
+    g.pair_flags = nullptr; g.epoch = 0; g.flag_value = 0; g.error = error_word; g.pair_timeout = 200000000LL;
     // (the flags live in the tail of the workspace, behind the partial-tile slots of a grid of at most MAXG / 2 workgroups: gram.hip)
     const bool fold = seq_count >= 0 && pair_flags && g.tfull == 0 && (g.nchunk & 1) == 0 && 2 * R == g.G && g.U == (int64_t)g.G * (g.nchunk / 2) && g.G <= MAXG / 2;
-    if (fold) { g.pair_flags = pair_flags; g.epoch = epoch; }
+    if (fold) {
+        g.pair_flags = pair_flags; g.epoch = g.flag_value = epoch;
+        // test hook (pmt_set_fault_injection(1)): the first halves announce a value nobody waits for and the wait is cut to 20 ms — the
+        // second halves run into their bound, write NaN tiles and raise the error word
+        if (dma::fault_injection() & 1) { g.flag_value = epoch + 0x40000000u; g.pair_timeout = 2000000LL; }
+    }
     if (g.nchunk > 1 && !workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     const dim3 grid((unsigned)g.G);
 #ifdef PMT_TUNING_ABLATE

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <link.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -43,6 +44,7 @@ struct Api {
     // optional (HSA 1.2+): a chosen SDMA engine per copy, so that two FIFO queues exist instead of one
     decltype(&hsa_amd_memory_async_copy_on_engine) memory_async_copy_on_engine = nullptr;
     decltype(&hsa_amd_memory_copy_engine_status) memory_copy_engine_status = nullptr;
+    decltype(&hsa_amd_memory_async_copy_rect) memory_async_copy_rect = nullptr;      // optional: pitched transfers on the engine
 };
 
 struct Engine {
@@ -52,6 +54,9 @@ struct Engine {
 };
 
 static std::mutex g_mu;
+static std::atomic<int> g_mode{0}, g_fault{0};
+int delivery_mode() { return g_mode.load(std::memory_order_relaxed); }
+int fault_injection() { return g_fault.load(std::memory_order_relaxed); }
 static bool g_tried = false;
 static void *g_lib = nullptr;
 static Api g_api;
@@ -91,6 +96,7 @@ static bool load_api() {
 #undef PMT_HSA_SYM
     g_api.memory_async_copy_on_engine = reinterpret_cast<decltype(g_api.memory_async_copy_on_engine)>(dlsym(lib, "hsa_amd_memory_async_copy_on_engine"));
     g_api.memory_copy_engine_status = reinterpret_cast<decltype(g_api.memory_copy_engine_status)>(dlsym(lib, "hsa_amd_memory_copy_engine_status"));
+    g_api.memory_async_copy_rect = reinterpret_cast<decltype(g_api.memory_async_copy_rect)>(dlsym(lib, "hsa_amd_memory_async_copy_rect"));
     if (g_api.init() != HSA_STATUS_SUCCESS) { dlclose(lib); return false; }     // reference-counted: HIP initialised it long ago
     g_lib = lib;
     return true;
@@ -106,7 +112,9 @@ static hsa_status_t collect_agent(hsa_agent_t a, void *data) {
     return HSA_STATUS_SUCCESS;
 }
 
-Engine *get(int device) {
+static Engine *engine_of(int device);
+Engine *get(int device) { return delivery_mode() == 2 ? nullptr : engine_of(device); }
+static Engine *engine_of(int device) {
     std::lock_guard<std::mutex> lock(g_mu);
     if (!load_api()) return nullptr;
     if (device < 0) return nullptr;
@@ -114,17 +122,25 @@ Engine *get(int device) {
     AgentList l;
     l.api = &g_api;
     if (g_api.iterate_agents(collect_agent, &l) != HSA_STATUS_SUCCESS || l.gpus.empty() || l.cpus.empty()) return nullptr;
-    // the HSA agent of HIP device `device`: same PCI bus / device (HIP_VISIBLE_DEVICES renumbers HIP devices only)
-    int bus = -1, dev = -1;
+    // the HSA agent of HIP device `device`: same PCI domain / bus / device (HIP_VISIBLE_DEVICES renumbers HIP devices only).  On a multi-socket
+    // node two GPUs may share bus:device in different domains, so the domain is part of the key; an ambiguous match means no engine (the
+    // kernel copies are used) rather than another GPU's.
+    int bus = -1, dev = -1, domain = -1;
     if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess ||
         hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipDeviceGetAttribute(&domain, hipDeviceAttributePciDomainID, device) != hipSuccess) { (void)hipGetLastError(); domain = -1; }
     hsa_agent_t gpu{};
-    bool found = false;
+    int matches = 0;
     for (hsa_agent_t a : l.gpus) {
-        uint32_t bdf = 0;
+        uint32_t bdf = 0, dom = 0;
         if (g_api.agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) != HSA_STATUS_SUCCESS) continue;
-        if ((int)((bdf >> 8) & 0xff) == bus && (int)((bdf >> 3) & 0x1f) == dev) { gpu = a; found = true; break; }
+        if ((int)((bdf >> 8) & 0xff) != bus || (int)((bdf >> 3) & 0x1f) != dev) continue;
+        const bool have_dom = g_api.agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) == HSA_STATUS_SUCCESS;
+        if (have_dom && domain >= 0 && (int)dom != domain) continue;
+        gpu = a;
+        ++matches;
     }
+    const bool found = matches == 1;
     if (!found) return nullptr;
     Engine *e = new Engine();
     e->api = g_api; e->gpu = gpu; e->cpu = l.cpus[0];
@@ -191,6 +207,27 @@ int copy_to_host(Engine *e, void *host_dst, const void *device_src, size_t bytes
     return PMT_OK;
 }
 
+// A pitched block.  The engine's rectangle copy where the runtime has it; otherwise (or when it refuses the shape) one linear copy per
+// row, all counted down on the same completion signal — the caller has set it to 1, so it is raised to `height` first.
+int copy_rect_to_host(Engine *e, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes, size_t height,
+                      const Signal *dep, Signal completion) {
+    hsa_signal_t d{};
+    if (dep) d.handle = dep->handle;
+    if (e->api.memory_async_copy_rect && width_bytes < ((size_t)1 << 32) && height < ((size_t)1 << 32) && (width_bytes & 3) == 0 &&
+        (dst_pitch & 3) == 0 && (src_pitch & 3) == 0) {
+        hsa_pitched_ptr_t dp{host_dst, dst_pitch, dst_pitch * height}, sp{const_cast<void *>(device_src), src_pitch, src_pitch * height};
+        hsa_dim3_t zero{0, 0, 0}, range{(uint32_t)width_bytes, (uint32_t)height, 1};
+        const hsa_status_t st = e->api.memory_async_copy_rect(&dp, &zero, &sp, &zero, &range, e->gpu, hsaDeviceToHost, dep ? 1 : 0, dep ? &d : nullptr,
+                                                              hsa_signal_t{completion.handle});
+        if (st == HSA_STATUS_SUCCESS) return PMT_OK;
+    }
+    signal_set(e, completion, (int64_t)height);
+    for (size_t r = 0; r < height; ++r)
+        if (int rc = copy_to_host(e, static_cast<char *>(host_dst) + r * dst_pitch, static_cast<const char *>(device_src) + r * src_pitch, width_bytes, dep, completion))
+            return rc;
+    return PMT_OK;
+}
+
 // host: until the completion signal has counted down to 0 (every copy that decrements it is done); a negative value is the runtime's error
 // report; `timeout_s` bounds the wait (a dependency that is never signalled must not hang the host for good)
 int wait(Engine *e, Signal completion, double timeout_s) {
@@ -237,3 +274,24 @@ int launch_signal_store(Signal s, hipStream_t stream) {
 
 }  // namespace dma
 }  // namespace pmt
+
+// Which way results leave for the host (recorded fetches, band-wise deliveries): takes effect from the next replay / call on.
+extern "C" int pmt_set_host_delivery(int mode) {
+    PMT_REQUIRE(mode >= 0 && mode <= 2, PMT_INVALID_ARGUMENT, "set_host_delivery: mode must be 0 (auto), 1 (copy engine) or 2 (kernel copies)");
+    pmt::dma::g_mode.store(mode);
+    return PMT_OK;
+}
+
+extern "C" int pmt_get_host_delivery(int device, int *out_mode, int *out_copy_engine) {
+    if (out_mode) *out_mode = pmt::dma::delivery_mode();
+    if (out_copy_engine) {
+        *out_copy_engine = pmt::dma::engine_of(device) ? 1 : 0;      // (whatever the mode says)
+    }
+    return PMT_OK;
+}
+
+extern "C" int pmt_set_fault_injection(int what) {
+    PMT_REQUIRE(what >= 0 && what <= 1, PMT_INVALID_ARGUMENT, "set_fault_injection: unknown fault");
+    pmt::dma::g_fault.store(what);
+    return PMT_OK;
+}

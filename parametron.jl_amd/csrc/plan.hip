@@ -230,7 +230,7 @@ namespace pmt {
 hipStream_t side_stream_of(hipStream_t s);
 void retain_side_stream(hipStream_t s);
 void release_side_stream(hipStream_t s);
-int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st);
+int fetch_async(hipStream_t s, hipStream_t after, hipEvent_t order_event, void *host_dst, const void *device_src, size_t bytes, FetchState *st, FetchRect r);
 int fetch_fence(hipStream_t s);
 void replay_begin(hipStream_t s);
 int replay_end(hipStream_t s);
@@ -267,6 +267,9 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     }
     (void)hipSetDevice(plan->device);
     (void)hipStreamSynchronize(plan->stream);
+    // copy-engine transfers of this plan's tape still in flight read its buffers and count on its signals: drained before either goes away,
+    // also when other plans keep the stream's auxiliary streams alive
+    (void)pmt::fetch_synchronize(plan->stream);
     pmt::release_side_stream(plan->stream);
     if (plan->copy_stream) { (void)hipStreamSynchronize(plan->copy_stream); (void)hipStreamDestroy(plan->copy_stream); }
     for (int i = 0; i < 2; ++i) {
@@ -580,7 +583,30 @@ extern "C" int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void 
     plan->fetch_events.push_back(ev);
     hipStream_t main = plan->stream;
     std::shared_ptr<pmt::FetchState> st = std::make_shared<pmt::FetchState>();     // the transfer's signals; goes with the tape entry
-    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes, st.get()); });
+    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes, st.get(), pmt::FetchRect{}); });
+    plan->lanes.push_back(plan->record_lane);
+    return PMT_OK;
+}
+
+// The pitched form: `height` rows of `width_bytes` (a dense matrix block whose device copy is padded, leaving for a column range of the
+// solver's stacked constraint matrix — the CSC values of a dense block ARE the Parameter matrix column by column, so they leave straight
+// out of the Parameter's buffer, with no kernel in between).
+extern "C" int pmt_plan_record_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
+                                        size_t height) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_record_fetch_2d: null plan");
+    PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan_record_fetch_2d: the plan is not recording");
+    if (width_bytes == 0 || height == 0) return PMT_OK;
+    PMT_REQUIRE(host_dst && device_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, PMT_INVALID_ARGUMENT, "plan_record_fetch_2d: bad argument");
+    if (dst_pitch == width_bytes && src_pitch == width_bytes) return pmt_plan_record_fetch(plan, host_dst, device_src, width_bytes * height);
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    hipEvent_t ev = nullptr;
+    PMT_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    plan->fetch_events.push_back(ev);
+    hipStream_t main = plan->stream;
+    std::shared_ptr<pmt::FetchState> st = std::make_shared<pmt::FetchState>();
+    pmt::FetchRect r;
+    r.dst_pitch = dst_pitch; r.src_pitch = src_pitch; r.height = height;
+    plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, width_bytes, st.get(), r); });
     plan->lanes.push_back(plan->record_lane);
     return PMT_OK;
 }

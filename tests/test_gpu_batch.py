@@ -169,3 +169,62 @@ def test_batch_step_through_the_library_communicator_single_rank():
             assert torch.equal(wl.gathered, ref.local) and torch.equal(wl.local, ref.local)
     finally:
         comm.close()
+
+
+def test_one_rank_rccl_communicator_exchanges_through_rccl():
+    """The library's RCCL binding (hand-declared prototypes resolved from librccl, ncclGetUniqueId, ncclCommInitRank, grouped ncclSend /
+    ncclRecv with ncclDouble, the communication stream and both events) on ONE GPU: a one-rank communicator built from a unique id sends
+    every chunk to itself.  pmt_batch_step_f64 with 4 uneven chunks: `gathered` is filled by RCCL alone, equals `local` bit for bit and
+    the single-launch slabs, and the instances' coefficient blocks equal the oracle's."""
+    import gpu_util as g
+    from parametron_jl_amd import batch, _lib
+    total, n, r, m = 103, 128, 96, 16                                  # chunks of 30, 30, 30, 13 instances
+    wl = batch.BatchLSQ(torch, total, n, r, m)
+    wl.compute()
+    torch.cuda.synchronize()
+    want = wl.local.clone()
+    comm = batch.Communicator(torch, None, 0, 1, torch.cuda.current_device(), rccl_single=True)
+    assert comm.rccl_calls() == 0
+    wl.gathered = torch.full((total, wl.L), float("nan"), dtype=torch.float64, device=g.DEV)       # a buffer of its own: only RCCL writes it
+    chunk = 30
+    assert batch.chunk_schedule(total, chunk) == [(0, 30), (30, 60), (60, 90), (90, 103)]
+    for epoch in range(2):
+        wl.local.fill_(float("nan"))
+        wl.step_pipelined(comm, chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(wl.gathered, wl.local) and torch.equal(wl.local, want)
+        assert comm.rccl_calls() == 8 * (epoch + 1)                     # one send + one receive per chunk
+    # exchange of slabs that already exist (pmt_batch_allgather_f64), default stream, one chunk and many
+    for chunk in (0, 7):
+        wl.gathered.fill_(float("nan"))
+        before = comm.rccl_calls()
+        _lib.call("pmt_batch_allgather_f64", comm.handle, g.ptr(wl.local), g.ptr(wl.gathered), total, wl.L, chunk, g.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(wl.gathered, want)
+        assert comm.rccl_calls() - before == 2 * len(batch.chunk_schedule(total, chunk))
+    # in place (gathered is local, the one-GPU bench layout): RCCL's self copy leaves the block as it is
+    _lib.call("pmt_batch_allgather_f64", comm.handle, g.ptr(wl.local), g.ptr(wl.local), total, wl.L, 30, g.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wl.local, want)
+    comm.close()
+    # and the gathered slabs against the oracle's builders for a few instances (constraint block and constants bit for bit, Q / q to 1e-12)
+    off, L = batch.slab_layout(n, m)
+    nq = n * (n + 1) // 2
+    got = wl.gathered.cpu().numpy()
+    for inst in (0, 29, 30, 102):
+        A = O.fill_uniform((inst + 1) * r * n, 101)[inst * r * n:].reshape(n, r).T
+        b = O.fill_uniform((inst + 1) * r, 102)[inst * r:]
+        Cm = O.fill_uniform((inst + 1) * m * n, 103)[inst * m * n:].reshape(n, m).T
+        d = O.fill_uniform((inst + 1) * m, 104, 2.0)[inst * m:]
+        w = O.LsqWorkspace(n, r, m)
+        xvar = np.arange(1, n + 1, dtype=np.int64)
+        w.eval_objective(np.ascontiguousarray(A.T).reshape(-1), b, xvar)
+        w.eval_constraint(np.ascontiguousarray(Cm.T).reshape(-1), d, xvar)
+        w.objective.canonicalize()
+        at, qt, const = w.objective.moi()
+        ct, cc = w.constraint.moi()
+        np.testing.assert_allclose(got[inst, :nq], qt["coeff"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got[inst, off["q"]:off["q"] + n], at["coeff"], rtol=1e-12, atol=0)
+        assert got[inst, off["const"]] == const
+        assert np.array_equal(got[inst, off["C"]:off["C"] + m * n], ct["coeff"])
+        assert np.array_equal(got[inst, off["dconst"]:], cc)

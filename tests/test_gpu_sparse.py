@@ -263,3 +263,122 @@ def test_block_form_is_the_one_the_config5_model_runs():
         csr.sort_indices()
         assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
         assert np.array_equal(t["out"], np.repeat(np.arange(1, m + 1), np.diff(csr.indptr)))
+
+
+class _PermutingMock(P.MockOptimizer):
+    """MockOptimizer whose index map permutes the variables and shifts them (MOI.copy_to may return any map, src/model.jl:100-118)"""
+
+    def __init__(self, variable_offset, seed):
+        super().__init__(variable_offset)
+        self.seed = seed
+
+    def copy_to(self, backend):
+        out = super().copy_to(backend)
+        out["variables"] = np.random.default_rng(self.seed).permutation(backend.nvars).astype(np.int64) + 1 + self.variable_offset
+        return out
+
+
+def _oracle_sparse_rows(Cs, xidx, dvec, sign):
+    """the reference's dense builders on the densified matrix (matvecmul!, src/functions.jl:775-798; vecsubtract!/vecadd!, :840-858)"""
+    m = Cs.shape[0]
+    mv = O.AffVec(m).matvecmul_vars(Cs.toarray(), xidx)
+    return O.AffVec(m).vecaddsub(mv, dvec, sign < 0) if dvec is not None else mv
+
+
+@pytest.mark.parametrize("m,n,density,kw", [
+    (300, 3000, 0.05, {}),                                                           # three row blocks, the last ragged; 1024-wide bands
+    (513, 2049, 0.03, {"dense_cols": (0, 700, 2048), "empty_rows": (0, 17, 512)}),
+])
+def test_block_form_model_against_the_oracle(m, n, density, kw):
+    """the kernel config 5 runs (sparse_block_kernel) against the ORACLE — the reference's dense matvecmul!/vecsubtract! output and its
+    update!(::MOI.VectorAffineFunction) (src/moi_interop.jl:64-81) minus the structural zeros — through a permuting, shifted index map,
+    as MOI triplets (VAT) and as native terms (LT), solve after solve with new values; the profile shows which kernel ran"""
+    rng = np.random.default_rng(m + n)
+    Cs = _pattern(m, n, density, 31, **kw)
+    model = P.Model(_PermutingMock(variable_offset=9, seed=4))
+    xs = [Variable(model) for _ in range(n + 3)]
+    x = [xs[i] for i in rng.permutation(n + 3)[:n]]                                    # the columns' variables in no particular order
+    def upd(Cm):
+        Cm.data[:] = rng.random(Cm.nnz) + 0.1
+    Cp = P.Parameter(upd, Cs, model)
+    d = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(m) - 0.5), np.zeros(m), model)
+    expr = Cp * x - d
+    P.constraint(model, Cp * x == d)
+    xidx = [v.index for v in x]
+    P.solve(model)
+    assert not np.array_equal(np.sort(model.model_var_to_optimizer), model.model_var_to_optimizer)      # the map does permute
+    for it in range(3):
+        P.profile_enable(True)
+        P.solve(model)
+        rep = P.profile_report()
+        P.profile_enable(False)
+        assert "sparse_block_kernel<VAT>" in rep and "sparse_slab_kernel" not in rep
+        f = list(model.constraints)[0].f
+        terms, consts = _oracle_sparse_rows(Cp(), xidx, d(), -1).moi(model.model_var_to_optimizer)
+        want = terms[terms["coeff"] != 0.0]
+        assert len(want) == Cs.nnz
+        assert np.array_equal(f.terms.view(np.int64), want.view(np.int64))
+        assert np.array_equal(f.constants.view(np.int64), consts.view(np.int64))
+    # native (LinearTerm) form of the same node: the LT instantiation of the block kernel
+    P.profile_enable(True)
+    got = expr()
+    rep = P.profile_report()
+    P.profile_enable(False)
+    assert "sparse_block_kernel<LT>" in rep
+    rows = _oracle_sparse_rows(Cp(), xidx, d(), -1).as_tuples()
+    assert len(got) == m
+    for g_, (t, c) in zip(got, rows):
+        assert [(tt.coeff, tt.var.index) for tt in g_.linear] == [p for p in t if p[0] != 0.0] and g_.constant == c
+
+
+def test_block_kernel_with_varmap_gather_and_row_offset_against_the_oracle():
+    """the block kernels' own varmap gather and row offset (a block stacked under another one, vcat!, src/functions.jl:870-885) against the
+    oracle's vcat + update!(::MOI.VectorAffineFunction): the second block's triplets are the rows m1+1.. of the stacked function"""
+    import ctypes as C
+    from parametron_jl_amd import _lib
+    m1, m, n = 11, 300, 3000
+    csc = _pattern(m, n, 0.05, 41)
+    nnz = csc.nnz
+    rng = np.random.default_rng(6)
+    colptr, rowval = csc.indptr.astype(np.int64) + 1, csc.indices.astype(np.int64) + 1
+    perm, trow, tcol = (np.empty(nnz, dtype=np.int64) for _ in range(3))
+    rptr = np.empty(m + 1, dtype=np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.call("pmt_sparse_rowmajor_order", m, n, vp(colptr), vp(rowval), vp(perm), vp(trow), vp(tcol), vp(rptr))
+    cw = C.c_int(0)
+    _lib.call("pmt_sparse_blocks_width", m, n, vp(colptr), vp(rowval), C.byref(cw))
+    cw = cw.value
+    nrb, ncb = -(-m // 128), -(-n // cw)
+    desc, idx, band = np.zeros(nrb * n, dtype=np.uint64), np.zeros(nnz, dtype=np.uint32), np.zeros(m * (ncb + 1), dtype=np.int64)
+    _lib.call("pmt_sparse_blocks_build", m, n, vp(colptr), vp(rowval), vp(perm), vp(tcol), vp(rptr), cw, vp(desc), vp(idx), vp(band))
+    xvar = rng.permutation(np.arange(1, n + 1)).astype(np.int64) + 3
+    varmap = rng.permutation(np.arange(1, n + 4)).astype(np.int64) + 100
+    top = O.AffVec(m1).matvecmul_vars(rng.random((m1, 5)), [1, 2, 3, 4, 5])               # the block above: m1 rows of anything
+    dev = torch.device("cuda:0")
+    dp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64) if a.dtype == np.uint64 else np.ascontiguousarray(a)).to(dev)
+    ddesc, dband, dxvar, dvarmap = t(desc), t(band), t(xvar), t(varmap)
+    didx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    got = torch.zeros(nnz * 3, dtype=torch.int64, device=dev)
+    got_lt = torch.zeros(nnz * 2, dtype=torch.int64, device=dev)
+    gconst = torch.full((m,), 7.0, dtype=torch.float64, device=dev)
+    gconst_lt = torch.full((m,), 7.0, dtype=torch.float64, device=dev)
+    for sign in (-1, 1):
+        csc.data[:] = rng.random(nnz) + 0.1
+        dvec = rng.random(m) - 0.5
+        nz, dd = torch.from_numpy(csc.data.copy()).to(dev), torch.from_numpy(dvec).to(dev)
+        _lib.call("pmt_sparse_pack_vector_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(dvarmap), m1, dp(dd), sign,
+                  dp(got), dp(gconst), stream)
+        _lib.call("pmt_sparse_assemble_blocks_f64", dp(nz), dp(ddesc), dp(didx), dp(dband), dp(dxvar), m, n, nnz, cw, dp(dd), sign, dp(got_lt), dp(gconst_lt), stream)
+        torch.cuda.synchronize()
+        block = _oracle_sparse_rows(csc, xvar, dvec, sign)
+        terms, consts = O.AffVec(m1 + m).vcat(top, block).moi(varmap)
+        want = terms[(terms["out"] > m1) & (terms["coeff"] != 0.0)]
+        assert len(want) == nnz
+        assert np.array_equal(got.cpu().numpy(), want.view(np.int64).reshape(-1))
+        assert np.array_equal(gconst.cpu().numpy().view(np.int64), consts[m1:].view(np.int64))
+        lt, _, lc = block.flat()
+        lt = lt[lt["coeff"] != 0.0]
+        assert np.array_equal(got_lt.cpu().numpy(), lt.view(np.int64).reshape(-1))
+        assert np.array_equal(gconst_lt.cpu().numpy().view(np.int64), lc.view(np.int64))
