@@ -318,6 +318,12 @@ int pmt_qp_bounds_f64(const double *consts, int64_t rows, int set_kind, double s
  *   pmt_qp_bounds_rows_f64: row i reads its constant through const_ptr[i] and has its own set kind / value. */
 int pmt_csc_values_gather_f64(const double *const *term_ptr, int64_t nnz_in, const int64_t *seg_ptr, int64_t nnz_out, double alpha,
                               const int64_t *dst_index, double *dst_values, void *stream);
+/* A DENSE block of a solver matrix: column j of dst (dst + j*dst_pitch doubles) takes the `rows` doubles of column j of src
+ * (src + j*src_pitch) — the CSC values of a dense constraint block C*x (+|-) d are the Parameter matrix C itself, column by column,
+ * placed at the block's row range of every column of the stacked matrix.  dst_offset != NULL: column j goes to dst + dst_offset[j]
+ * instead (the other blocks do not have the same height in every column).  No term structs are read. */
+int pmt_copy_2d_f64(const double *src, int64_t src_pitch, double *dst, int64_t dst_pitch, const int64_t *dst_offset, int64_t rows,
+                    int64_t cols, void *stream);
 int pmt_qp_bounds_rows_f64(const double *const *const_ptr, const int *set_kind, const double *set_value, int64_t rows, double infty,
                            double *l, double *u, void *stream);
 
@@ -538,7 +544,10 @@ int pmt_plan_end_record(pmt_plan *plan);
  * src/moi_interop.jl:168-175, is independent of every other record).  At replay these entries fork from the plan's stream at the
  * top of the tape and join at its end; they are queued on the stream's side stream BEHIND the two small reductions of a canonical
  * least-squares objective, so they are dispatched when the contraction's workgroups are already placed and run while those drain and
- * while the fix-up pass runs, instead of adding their own kernels and in-stream gaps behind it. */
+ * while the fix-up pass runs, instead of adding their own kernels and in-stream gaps behind it.
+ * Lane 2 is the FRONT of the side lane: the same stream, but replayed before every other entry of the tape whatever its position in the
+ * recording — for an entry that needs nothing of this re-evaluation, e.g. the recorded fetch of a dense constraint block's CSC values
+ * straight out of its Parameter buffer (pmt_plan_record_fetch_2d): PCIe is busy from the first microseconds of the solve. */
 int pmt_plan_set_lane(pmt_plan *plan, int lane);
 void *pmt_plan_recording_stream(pmt_plan *plan);
 int64_t pmt_plan_tape_length(const pmt_plan *plan);

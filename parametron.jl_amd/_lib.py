@@ -87,6 +87,7 @@ SIGNATURES = {
     "pmt_csc_values_f64": (_ci, [_vp, _i64, _i64, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "pmt_qp_bounds_f64": (_ci, [_vp, _i64, _ci, _f64, _f64, _vp, _vp, _vp]),
     "pmt_csc_values_gather_f64": (_ci, [_vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp]),
+    "pmt_copy_2d_f64": (_ci, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "pmt_qp_bounds_rows_f64": (_ci, [_vp, _vp, _vp, _i64, _f64, _vp, _vp, _vp]),
     "pmt_sparse_rowmajor_order": (_ci, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_sparse_assemble_f64": (_ci, [_vp, _vp, _vp, _i64, _vp, _vp]),

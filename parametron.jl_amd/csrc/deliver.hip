@@ -28,7 +28,7 @@ struct CourierArgs {
     unsigned *done;                       // workgroups that have finished; the last one re-arms the flags for the next launch
     int *error;                           // set to 1 on timeout (page-locked host word, gram.hip SideStream::err_host)
     int ngroups;
-    long long off[MAXGROUPS + 1];
+    long long gbeg[MAXGROUPS], gend[MAXGROUPS];      // the groups' ranges of the array (doubles)
 };
 
 constexpr long long COURIER_TIMEOUT_TICKS = 200000000LL;      // wall_clock64 runs at 100 MHz: 2 s
@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256) void courier_kernel(CourierArgs a) {
             if (tid == 0) __hip_atomic_store(a.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
-        const long long n = a.off[g + 1] - a.off[g];
-        const double *src = a.src + a.off[g];
-        double *dst = a.dst + a.off[g];
+        const long long n = a.gend[g] - a.gbeg[g];
+        const double *src = a.src + a.gbeg[g];
+        double *dst = a.dst + a.gbeg[g];
         // (32-bit offsets from uniform bases, two loads in flight: the kernel has to stay within 16 VGPRs)
         // BYTE offsets (a group is below 4 GiB: checked by the launcher) so that every access is uniform base + 32-bit lane offset
         const char *sb = reinterpret_cast<const char *>(src);
@@ -114,12 +114,13 @@ void *host_device_pointer(void *host) {
     return d;
 }
 
-int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s) {
+int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *gbeg, const int64_t *gend,
+                   hipStream_t s) {
     for (int g = 0; g < ngroups; ++g)
-        PMT_REQUIRE((off[g + 1] - off[g]) * 8 < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH, "host delivery: a band group of 2 GiB or more (use more groups)");
+        PMT_REQUIRE((gend[g] - gbeg[g]) * 8 < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH, "host delivery: a band group of 2 GiB or more (use more groups)");
     CourierArgs a;
     a.src = src; a.dst = dst_dev; a.ready = ready; a.done = done; a.error = error; a.ngroups = ngroups;
-    for (int g = 0; g <= MAXGROUPS; ++g) a.off[g] = g <= ngroups ? off[g] : 0;
+    for (int g = 0; g < MAXGROUPS; ++g) { a.gbeg[g] = g < ngroups ? gbeg[g] : 0; a.gend[g] = g < ngroups ? gend[g] : 0; }
     // 64 workgroups: page-locked stores saturate PCIe from 64 workgroups on (tools/deliver_probe.hip: 53.6 GB/s), and at most one courier
     // wave sits beside the contraction's two on a quarter of the SIMDs
     PMT_LAUNCH(courier_kernel, dim3(64), dim3(256), 0, s, a);

@@ -29,7 +29,7 @@ void mark_no_graph(void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
-int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *off, hipStream_t s);
+int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *gbeg, const int64_t *gend, hipStream_t s);
 int launch_to_host(const void *src, void *dst_dev, size_t bytes, hipStream_t s);
 int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t dst_pitch, size_t width_bytes, size_t height, hipStream_t s);
 void *host_device_pointer(void *host);
@@ -38,7 +38,12 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
                    unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
-constexpr int DELIVER_ORDER_W = 2; // a delivery computes the tiles in super-columns of two tile columns: the column bands finish in ascending order
+// a CSC delivery computes the tiles column band by column band (super-columns of ONE tile column: a band's completion is never held back by
+// its neighbour's, so the stages complete nearly equal byte counts — 1.73 vs 1.77 ms per solve with super-columns of two at n = 4096,
+// profiles/r04_host_delivery.txt), walked from the LAST band to the first (order_w < 0): the column bands finish in descending order.  Band kb holds (kb + 1) tiles' worth of values, so the long bands leave while the contraction is
+// still busy and what is left to ship when it ends — the tail nothing overlaps — is the short ones (ascending order, round 3, left 8.1 MB
+// = 0.15 ms of PCIe behind the last stage at n = 4096; descending leaves 1 MB).
+constexpr int DELIVER_ORDER_W = 1;
 
 // out_lin[j] = (2 * sum_i c_i * A[i,j], vm[xvar[j]]),  c_i = 0.0 (+|-) b[i]; one wave per column (coalesced along i)
 __global__ __launch_bounds__(256) void gram_linear_kernel(const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
@@ -436,7 +441,7 @@ struct DeliverPlan {
     int64_t seq_begin[MAXGROUPS], seq_count[MAXGROUPS];
     int group_of[MAXGROUPS];                // index of the band group the stage completes, or -1
     int ngroups = 0;
-    int64_t off[MAXGROUPS + 1];             // CSC offsets (doubles) of the groups' first columns
+    int64_t gbeg[MAXGROUPS], gend[MAXGROUPS];      // the groups' ranges of the delivered array (doubles)
 };
 
 // Stage size.  With the persistent grid all workgroups finish a round of whole tiles together, so one launch of everything delivers in two
@@ -458,42 +463,52 @@ static DeliverPlan deliver_plan(int64_t rows, int64_t cols, int nstages_hint, in
     int64_t per = nchunk >= 2 ? std::max<int64_t>(1, G / 2) : G;           // tiles per stage: half a grid's worth (whole tiles if there is nothing to split)
     if (nstages_hint > 0) per = std::max<int64_t>(1, cdiv(T, std::min(nstages_hint, MAXGROUPS)));
     if (cdiv(T, per) > MAXGROUPS) per = cdiv(T, MAXGROUPS);
-    // tiles up to the end of each super-column, i.e. where its bands are complete
-    std::vector<int64_t> seq_end_of_band((size_t)nt), endoff((size_t)nt);
+    // position in the walk after which each band is complete, and the band's range of the delivered array
+    std::vector<int64_t> seq_end_of_band((size_t)nt), bandbeg((size_t)nt), bandend((size_t)nt);
     int64_t seq_end = 0;
     if (quad) {
+        // row bands, ascending (row band jb holds nt - jb tiles: the short ones come last by themselves)
         for (int j0 = 0; j0 < nt; j0 += 4) {
             const int h = std::min(4, nt - j0), W = nt - j0;
             seq_end += (int64_t)h * (h + 1) / 2 + (int64_t)(W - h) * h;    // (sk_seq_unrank)
             for (int jb = j0; jb < j0 + h; ++jb) seq_end_of_band[(size_t)jb] = seq_end;
         }
         for (int jb = 0; jb < nt; ++jb) {
-            const int64_t J = std::min<int64_t>(cols, (int64_t)(jb + 1) * GT);
-            endoff[(size_t)jb] = 3 * (J * cols - J * (J - 1) / 2);         // rows 0 .. J-1 of the row-major upper triangle, 3 doubles per term
+            const int64_t J0 = (int64_t)jb * GT, J = std::min<int64_t>(cols, (int64_t)(jb + 1) * GT);
+            bandbeg[(size_t)jb] = 3 * (J0 * cols - J0 * (J0 - 1) / 2);      // rows 0 .. J-1 of the row-major upper triangle, 3 doubles per term
+            bandend[(size_t)jb] = 3 * (J * cols - J * (J - 1) / 2);
         }
     } else {
+        // column bands, DESCENDING: the walk starts at the end of the column-band-major sequence (sk_colseq_unrank, launch_gram_sk order_w < 0)
+        std::vector<int64_t> start_of_super((size_t)nt);
+        int64_t pos = 0;
         for (int c0 = 0; c0 < nt; c0 += order_w) {
             const int h = std::min(order_w, nt - c0);
-            seq_end += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;         // (sk_colseq_unrank)
-            for (int kb = c0; kb < c0 + h; ++kb) seq_end_of_band[(size_t)kb] = seq_end;
+            for (int kb = c0; kb < c0 + h; ++kb) start_of_super[(size_t)kb] = pos;
+            pos += (int64_t)c0 * h + (int64_t)h * (h + 1) / 2;
         }
         for (int kb = 0; kb < nt; ++kb) {
-            const int64_t cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
-            endoff[(size_t)kb] = cend * (cend + 1) / 2;
+            seq_end_of_band[(size_t)kb] = T - start_of_super[(size_t)kb];     // the walk has passed the band's whole super-column
+            const int64_t c0 = (int64_t)kb * GT, cend = std::min<int64_t>(cols, (int64_t)(kb + 1) * GT);
+            bandbeg[(size_t)kb] = c0 * (c0 + 1) / 2;
+            bandend[(size_t)kb] = cend * (cend + 1) / 2;
         }
     }
-    d.off[0] = 0;
+    // bands in completion order: 0, 1, .. (quad) or nt-1, nt-2, .. (CSC)
+    auto band_at = [&](int i) { return quad ? i : nt - 1 - i; };
     int done_bands = 0;
     for (int64_t t0 = 0; t0 < T; t0 += per) {
         const int st = d.nstages++;
         d.seq_begin[st] = t0;
         d.seq_count[st] = std::min<int64_t>(per, T - t0);
         int nb = done_bands;
-        while (nb < nt && seq_end_of_band[(size_t)nb] <= t0 + d.seq_count[st]) ++nb;
+        while (nb < nt && seq_end_of_band[(size_t)band_at(nb)] <= t0 + d.seq_count[st]) ++nb;
         d.group_of[st] = -1;
         if (nb > done_bands) {
             d.group_of[st] = d.ngroups;
-            d.off[d.ngroups + 1] = endoff[(size_t)nb - 1];
+            const int first = band_at(done_bands), last = band_at(nb - 1);
+            d.gbeg[d.ngroups] = bandbeg[(size_t)std::min(first, last)];
+            d.gend[d.ngroups] = bandend[(size_t)std::max(first, last)];
             ++d.ngroups;
             done_bands = nb;
         }
@@ -521,9 +536,14 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     // the array a delivery ships, as doubles: out_csc, or out_quad (three doubles per term)
     double *deliver_host = host_quad ? reinterpret_cast<double *>(host_quad) : host_csc;
     const double *deliver_src = host_quad ? reinterpret_cast<const double *>(out_quad) : out_csc;
-    const int deliver_order = host_quad ? 0 : DELIVER_ORDER_W;
+#ifdef PMT_TUNING
+    static const int deliver_w = [] { const char *e = getenv("PMT_DELIVER_ORDER_W"); return e ? atoi(e) : DELIVER_ORDER_W; }();
+#else
+    constexpr int deliver_w = DELIVER_ORDER_W;
+#endif
+    const int deliver_order = host_quad ? 0 : -deliver_w;
     if (deliver_host && cols > 0) {
-        dplan = deliver_plan(rows, cols, ngroups, DELIVER_ORDER_W, deliver_host, host_quad != nullptr);
+        dplan = deliver_plan(rows, cols, ngroups, deliver_w, deliver_host, host_quad != nullptr);
         dplan.host_dev = static_cast<double *>(host_device_pointer(deliver_host));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
         mark_no_graph(stream);
@@ -624,8 +644,8 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     // first tenth of the contraction) — submitted here they would hold those back until the last band group has left.
                     auto submit = [=]() -> int {
                         for (int i = 0; i < dplan.ngroups; ++i)
-                            if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.off[i], deliver_src + dplan.off[i],
-                                                            sizeof(double) * (size_t)(dplan.off[i + 1] - dplan.off[i]), &sig->dep[i], sig->done, 1)) return rc2;
+                            if (int rc2 = dma::copy_to_host(sig->eng, dplan.host + dplan.gbeg[i], deliver_src + dplan.gbeg[i],
+                                                            sizeof(double) * (size_t)(dplan.gend[i] - dplan.gbeg[i]), &sig->dep[i], sig->done, 1)) return rc2;
                         return PMT_OK;
                     };
                     sig->pending = true;
@@ -638,7 +658,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                     // band groups' flags and stores each finished group straight into the host array (deliver.hip)
                     char *cb = static_cast<char *>(side->counters);
                     rc = launch_courier(deliver_src, dplan.host_dev, reinterpret_cast<long long *>(cb + FLAGS_OFFSET), reinterpret_cast<unsigned *>(cb + DONE_OFFSET),
-                                        side->err_dev, dplan.ngroups, dplan.off, side->fetch);
+                                        side->err_dev, dplan.ngroups, dplan.gbeg, dplan.gend, side->fetch);
                     if (rc) return rc;
                     PMT_HIP_CHECK(hipEventRecord(side->fetch_done, side->fetch));
                     side->fetch_pending = true;

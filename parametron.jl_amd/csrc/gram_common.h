@@ -28,8 +28,9 @@ struct SKArgs {
     // Tile order: 0 = super-rows of 4 tile rows (sk_seq_unrank); w > 0 = super-columns of w tile columns (sk_colseq_unrank): the column
     // bands of the output complete in ascending order, which is what a solver hand-off in CSC order wants to ship first.
     int order_w;
-    int seq_begin;    // this launch covers the tiles seq_begin .. seq_begin + T' - 1 of the sequence (a staged host delivery launches the
-                      // contraction band range by band range; 0 and all tiles otherwise)
+    int seq_begin;    // this launch covers the tiles seq_begin, seq_begin + seq_step, .. (T' of them) of the sequence (a staged host delivery
+                      // launches the contraction band range by band range; 0 and all tiles otherwise)
+    int seq_step;     // +1, or -1: the sequence is walked from its end (column bands complete in DESCENDING order: the small ones last)
     unsigned *pair_flags; unsigned epoch;      // pair fold of a ranged launch (gram_sk.hip), or null
     unsigned flag_value;                       // what a first half stores into its tile's flag: `epoch` (anything else only under fault injection)
     int *error;                                // page-locked error word: a second half whose partner never showed up stores 2 here

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
             const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
             const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
             int jb, kb;
-            sk_tile_unrank(g, tile + (RANGED ? g.seq_begin : 0), jb, kb);
+            sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * tile : tile, jb, kb);
             const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
             const bool diag = (jb == kb);
             const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
-        sk_tile_unrank(g, sk_phase_a_index(g, bid, t) + (RANGED ? g.seq_begin : 0), jb, kb);
+        sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * sk_phase_a_index(g, bid, t) : sk_phase_a_index(g, bid, t), jb, kb);
         double acc[C::NACC];
         sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
         sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         for (int r = 0; r < APB; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
-    sk_tile_unrank(g, tile + g.seq_begin, jb, kb);
+    sk_tile_unrank(g, g.seq_begin + g.seq_step * tile, jb, kb);
 #pragma unroll
     for (int r = 0; r < APB; ++r) {
         int row, col;
@@ -615,7 +615,12 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.ntiles = (int)cdiv(cols, ST);
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
     const int64_t T = seq_count >= 0 ? seq_count : (int64_t)g.ntiles * (g.ntiles + 1) / 2;      // tiles of this launch
-    g.seq_begin = (int)seq_begin;
+    g.seq_begin = (int)seq_begin; g.seq_step = 1;
+    if (order_w < 0) {                                // walked from the end: position p of the walk is tile T_all - 1 - p of the sequence
+        order_w = -order_w;
+        g.seq_begin = (int)((int64_t)g.ntiles * (g.ntiles + 1) / 2 - 1 - seq_begin);
+        g.seq_step = -1;
+    }
     // variant: 0 = wg256 (two 4-wave workgroups per CU, 64x64 wave tiles), 1 = wg512 (one 8-wave workgroup per CU, 64x32), BK 16
 #ifdef PMT_TUNING
 #ifdef PMT_TUNING_ABLATE

@@ -57,6 +57,22 @@ __global__ __launch_bounds__(256) void csc_values_wave_kernel(const char *__rest
     if (lane == 0) dst[dst_index ? dst_index[s] : s] = alpha * acc;
 }
 
+// The CSC values of a DENSE constraint block are its Parameter matrix column by column (update!(::MOI.VectorAffineFunction) writes one term
+// per entry, src/moi_interop.jl:64-81): column j of the block = `rows` consecutive doubles at src + j * spitch, going to the block's row range
+// of column j of the stacked matrix, dst + j * dpitch.  One wave per column, lanes along it (coalesced both ways); 16.8 MB read for 16.8 MB
+// written at config 2, where the per-term pointer gather this replaces read 248 MB (profiles/r03_pmc_traffic.json).
+// dst_offset != null: column j goes to dst + dst_offset[j] (the other blocks of the stacked matrix are not the same height in every column).
+__global__ __launch_bounds__(256) void copy_2d_kernel(const double *__restrict__ src, int64_t spitch, double *__restrict__ dst, int64_t dpitch,
+                                                      const int64_t *__restrict__ dst_offset, int rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t j = wave0; j < cols; j += nwaves) {
+        const double *s = src + j * spitch;
+        double *d = dst + (dst_offset ? dst_offset[j] : j * dpitch);
+        for (int i = lane; i < rows; i += 64) d[i] = s[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void qp_bounds_kernel(const double *__restrict__ consts, int64_t rows, int kind, double value, double infty,
                                                         double *__restrict__ l, double *__restrict__ u) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +174,18 @@ extern "C" int pmt_csc_values_gather_f64(const double *const *term_ptr, int64_t 
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(csc_values_gather_kernel, dim3((unsigned)cdiv(nseg, 256)), dim3(256), 0, s, term_ptr, seg_ptr, nseg, alpha, dst_index, dst_values);
         return check_launch("csc_values_gather_kernel");
+    });
+}
+
+extern "C" int pmt_copy_2d_f64(const double *src, int64_t src_pitch, double *dst, int64_t dst_pitch, const int64_t *dst_offset, int64_t rows,
+                               int64_t cols, void *stream) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0 && rows < ((int64_t)1 << 31), PMT_DIMENSION_MISMATCH, "copy_2d: bad size");
+    PMT_REQUIRE(src_pitch >= rows && (dst_offset || dst_pitch >= rows), PMT_DIMENSION_MISMATCH, "copy_2d: pitch smaller than the column");
+    if (rows == 0 || cols == 0) return PMT_OK;
+    PMT_REQUIRE(src && dst, PMT_INVALID_ARGUMENT, "copy_2d: null pointer");
+    return dispatch(stream, [=](hipStream_t s) {
+        PMT_LAUNCH(copy_2d_kernel, dim3((unsigned)std::min<int64_t>(cdiv(cols, 4), 4096)), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, dst_offset, (int)rows, cols);
+        return check_launch("copy_2d_kernel");
     });
 }
 

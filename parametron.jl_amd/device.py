@@ -89,6 +89,24 @@ class DeviceContext:
             return
         _lib.call("pmt_plan_record_fetch", self.plan, host.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), int(nbytes))
 
+    def fetch_ptr(self, host_ptr, dptr, nbytes):
+        if nbytes:
+            _lib.call("pmt_plan_fetch", self.plan, C.c_void_p(host_ptr), C.c_void_p(dptr), int(nbytes))
+
+    def fetch_2d_ptr(self, host_ptr, dst_pitch, dptr, src_pitch, width_bytes, height):
+        if width_bytes and height:
+            _lib.call("pmt_plan_fetch_2d", self.plan, C.c_void_p(host_ptr), int(dst_pitch), C.c_void_p(dptr), int(src_pitch), int(width_bytes), int(height))
+
+    def record_fetch_ptr(self, host_ptr, dptr, nbytes):
+        if nbytes:
+            _lib.call("pmt_plan_record_fetch", self.plan, C.c_void_p(host_ptr), C.c_void_p(dptr), int(nbytes))
+
+    def record_fetch_2d(self, host_ptr, dst_pitch, dptr, src_pitch, width_bytes, height):
+        """while recording: the pitched form of record_fetch (pmt_plan_record_fetch_2d) — `height` rows of `width_bytes`"""
+        if width_bytes and height:
+            _lib.call("pmt_plan_record_fetch_2d", self.plan, C.c_void_p(host_ptr), int(dst_pitch), C.c_void_p(dptr), int(src_pitch), int(width_bytes),
+                      int(height))
+
     def fetch_synchronize(self):
         """host: every copy on the plan's fetch stream (recorded fetches, delivered CSC values) has landed"""
         _lib.call("pmt_plan_fetch_synchronize", self.plan)

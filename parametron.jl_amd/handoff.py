@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib, moi
 from ._lib import ArgumentError, ErrorException
-from .device import DSparseAff, P
+from .device import DDenseAff, DSparseAff, DVarsAff, P
 
 _SET_KIND = {moi.EqualTo: 0, moi.Zeros: 0, moi.GreaterThan: 1, moi.Nonnegatives: 1, moi.LessThan: 2, moi.Nonpositives: 2}
 DEFAULT_INFTY = 1e20
@@ -41,16 +41,47 @@ def _csc_order(rows, cols, nrows, ncols, upper):
 class _Block:
     """One source of matrix entries: a device term buffer (or host values for constant functions) and where its runs go."""
 
-    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None, source_perm=None):
+    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None, source_perm=None, dense=None):
         self.rows, self.cols, self.coeff_ptr, self.stride, self.host_coeff = rows, cols, coeff_ptr, stride, host_coeff
         self.source_perm = source_perm            # entry i's coefficient sits at coeff_ptr + source_perm[i] * stride (None: i * stride)
+        self.dense = dense                        # DMat of a dense block A*x (+|-) b whose terms are row-major (row*cols + col): its values ARE the matrix
+
+
+class _Rect:
+    """A dense block inside a solver matrix's CSC values: column j of the Parameter matrix (rows doubles at mat + j*lda) sits at
+    values[first + j*pitch ...] — a pitched copy, no term is read."""
+
+    def __init__(self, first, pitch, mat, offsets=None):
+        self.first, self.pitch, self.mat = int(first), int(pitch), mat
+        self.offsets = offsets              # per-column positions when they are not a constant pitch apart (then pitch is 0)
 
 
 class CSC:
-    def __init__(self, nrows, ncols, col_ptr, row_idx, values_ptr):
+    def __init__(self, nrows, ncols, col_ptr, row_idx, values_ptr, rects=(), only_rects=False):
         self.shape = (nrows, ncols)
         self.col_ptr, self.row_idx, self.values_ptr = col_ptr, row_idx, values_ptr
         self.nnz = len(row_idx)
+        self.rects = list(rects)            # dense blocks that are pitched copies of Parameter matrices
+        self.only_rects = only_rects        # every value that changes per re-evaluation belongs to one of them (the rest is static)
+
+
+class _Transfer:
+    """one device -> host copy of a re-evaluation: `nbytes` linear, or `height` rows of `nbytes` with the given pitches"""
+
+    def __init__(self, host_ptr, dev_ptr, nbytes, dst_pitch=0, src_pitch=0, height=0):
+        self.host_ptr, self.dev_ptr, self.nbytes, self.dst_pitch, self.src_pitch, self.height = int(host_ptr), int(dev_ptr), int(nbytes), dst_pitch, src_pitch, height
+
+    def record(self, ctx):
+        if self.height:
+            ctx.record_fetch_2d(self.host_ptr, self.dst_pitch, self.dev_ptr, self.src_pitch, self.nbytes, self.height)
+        else:
+            ctx.record_fetch_ptr(self.host_ptr, self.dev_ptr, self.nbytes)
+
+    def fetch(self, ctx):
+        if self.height:
+            ctx.fetch_2d_ptr(self.host_ptr, self.dst_pitch, self.dev_ptr, self.src_pitch, self.nbytes, self.height)
+        else:
+            ctx.fetch_ptr(self.host_ptr, self.dev_ptr, self.nbytes)
 
 
 class HostQP:
@@ -79,18 +110,24 @@ class HostQP:
         return self._qp.sign * float(self._r[0])
 
     def transfers(self, late=None):
-        """(host array, device pointer) pairs of one re-evaluation; P is absent when the contraction delivers it itself.
-        late=False: what the hand-off launches produce (A's values, q | l | u); late=True: what only the objective's own kernels finish —
-        its constant (the node's serial c'c chain) and P when it is not delivered band by band; None: all."""
+        """the device -> host copies of one re-evaluation; P is absent when the contraction delivers it itself.
+        late=False: what is ready early — A's values (dense blocks: pitched copies straight out of their Parameter buffers, ready when the
+        re-evaluation starts; otherwise the hand-off's gather output) and q | l | u; late=True: what only the objective's own kernels
+        finish — its constant (the node's serial c'c chain) and P when it is not delivered band by band; None: all."""
         qp = self._qp
-        early = [(self.Ax, qp.A.values_ptr), (self._small[:qp._small_len], qp._small_ptr)]
+        if qp.A.only_rects:
+            # A's static entries (bounds rows: 1.0) were fetched once at set-up; per solve only the dense blocks travel
+            early = [_Transfer(self.Ax.ctypes.data + 8 * r.first, r.mat.buf, 8 * r.mat.rows, 8 * r.pitch, 8 * r.mat.lda, r.mat.cols) for r in qp.A.rects]
+        else:
+            early = [_Transfer(self.Ax.ctypes.data, qp.A.values_ptr, self.Ax.nbytes)]
+        early.append(_Transfer(self._small.ctypes.data, qp._small_ptr, 8 * qp._small_len))
         tail = []
         if qp._obj_const[0]:
-            tail.append((self._r, qp._obj_const[0]))
+            tail.append(_Transfer(self._r.ctypes.data, qp._obj_const[0], 8))
         if not self.P_delivered_by_contraction:
-            tail.append((self.Px, qp.P.values_ptr))
+            tail.append(_Transfer(self.Px.ctypes.data, qp.P.values_ptr, self.Px.nbytes))
         t = early + tail if late is None else (tail if late else early)
-        return [(a, ptr) for a, ptr in t if a.nbytes]
+        return [x for x in t if x.nbytes]
 
     def nbytes(self):
         return self.Px.nbytes + self.q.nbytes + self.Ax.nbytes + self.l.nbytes + self.u.nbytes + 8
@@ -122,6 +159,8 @@ class DeviceQP:
         self.nvars = n = int(vm.max()) if len(vm) else 0
         self.sign = -1.0 if model.sense == "Maximize" else 1.0
         self._launches = []
+        self._lazy_launches = []                  # device copies only an inspection (fetch()) reads
+        self._host_mode = host
 
         # ---- objective: P (upper triangular), q, r
         obj = model.objective
@@ -189,7 +228,14 @@ class DeviceQP:
                     bounds.append((row0, c.nrows, kind, value, None, np.asarray(c.f.constants, dtype=np.float64).copy()))
                 else:
                     out = c.expr.out
-                    if isinstance(out, DSparseAff) and not out.need_terms:
+                    if isinstance(out, DDenseAff) and not out.need_terms:
+                        # a dense block's coefficients are the Parameter matrix itself (terms row-major: row*cols + col)
+                        # (host_csc: the record packs no terms at all — moi._Record.compile — and the structure in c.f.terms is static)
+                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8 if "terms" in c.dev else None, 24, dense=out.mat))
+                    elif isinstance(out, DVarsAff) and not out.need_terms:
+                        # x (+|-) v: the coefficient of every row is the 1.0 of copyto!(f, ::Variable) (src/functions.jl:421) — static
+                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), host_coeff=t["coeff"].copy()))
+                    elif isinstance(out, DSparseAff) and not out.need_terms:
                         # a sparse block's coefficients are read where they already are — the Parameter's nzval (CSC order) — not out of
                         # the 24-byte terms the scatter kernel wrote for the MOI side
                         ablocks.append(_Block(t["out"] + row0, t["var"].copy(), out.spmat.buf, 8, source_perm=out.spmat.perm))
@@ -218,7 +264,13 @@ class DeviceQP:
         ctx.synchronize()
         self._in_tape = False
         self.host = HostQP(self) if host else None
-        self._host_mode = host
+        model._fetches_read_parameters = self.host is not None and self.A.only_rects
+        if self.host is not None and self.A.only_rects and self.A.nnz:
+            # A's static entries, once: the per-solve transfers rewrite the dense blocks only
+            for name, args in self._lazy_launches:
+                ctx.call(name, *args)
+            ctx.fetch_ptr(self.host.Ax.ctypes.data, self.A.values_ptr, self.host.Ax.nbytes)
+            ctx.synchronize()
         if host == "overlap" and not in_tape:
             in_tape = "main"                        # the fetches are tape entries, so their producers have to be too
         if in_tape and (self._launches or host == "overlap") and model._records:
@@ -230,12 +282,14 @@ class DeviceQP:
                 for name, args in self._launches:
                     ctx.call(name, *args)
                 if host == "overlap":
-                    for arr, ptr in self.host.transfers(late=False):
-                        ctx.record_fetch(arr, ptr, arr.nbytes)
+                    for t in self.host.transfers(late=False):
+                        # a dense block straight out of its Parameter buffer depends on nothing of this re-evaluation: front of the side lane
+                        ctx.set_lane(2 if (t.height and in_tape == "side") else (1 if in_tape == "side" else 0))
+                        t.record(ctx)
                 ctx.set_lane(0)
                 if host == "overlap":                       # behind the objective's own kernels on the plan's stream
-                    for arr, ptr in self.host.transfers(late=True):
-                        ctx.record_fetch(arr, ptr, arr.nbytes)
+                    for t in self.host.transfers(late=True):
+                        t.record(ctx)
             finally:
                 ctx.end_record()
             self._in_tape = True
@@ -272,31 +326,65 @@ class DeviceQP:
             src = perm if b.source_perm is None else b.source_perm[perm]
             if b.stride == 8 and len(seg) == len(perm) + 1 and np.array_equal(src, np.arange(len(src))):
                 return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), b.coeff_ptr)
-        values = ctx.alloc(8 * max(len(ukey), 1))
+        values = None
         static = np.zeros(max(len(ukey), 1))
         pos = 0
         addr, segs, dsts, nterms = [], [], [], 0            # the device blocks, folded into ONE gather launch (term addresses are static)
+        rects = []
         for (b, perm, seg, cols, row_idx) in local:
             k = len(row_idx)
             dst = np.ascontiguousarray(inverse[pos:pos + k], dtype=np.int64)
             pos += k
+            rect = self._dense_rect(b, perm, seg, dst, alpha) if k else None
             if b.host_coeff is not None:
                 sums = np.add.reduceat(b.host_coeff[perm], seg[:-1]) if k else np.zeros(0)
                 static[dst] = alpha * sums
+            elif rect is not None:
+                rects.append(rect)
+            elif k and b.coeff_ptr is None:
+                raise ErrorException("DeviceQP: a dense block without MOI terms must leave as a copy of its Parameter matrix")
             elif k:
                 src = perm if b.source_perm is None else b.source_perm[perm]
                 addr.append(np.uint64(b.coeff_ptr) + src.astype(np.uint64) * np.uint64(b.stride))
                 segs.append(seg[:-1] + nterms)
                 dsts.append(dst)
                 nterms += len(perm)
+        pitched = all(r.offsets is None for r in rects)
+        if len(rects) == 1 and pitched and not addr and rects[0].pitch == rects[0].mat.lda and len(ukey) == rects[0].mat.rows * rects[0].mat.cols:
+            # the matrix IS one dense Parameter whose device copy is not padded: nothing to launch, nothing to copy
+            return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), rects[0].mat.buf, rects, only_rects=True)
+        values = ctx.alloc(8 * max(len(ukey), 1))
         ctx.upload(values, static)
+        for r in rects:
+            off = None if r.offsets is None else P(ctx.upload_new(r.offsets))
+            launch = ("pmt_copy_2d_f64", (P(r.mat.buf), r.mat.lda, P(values + 8 * r.first), r.pitch, off, r.mat.rows, r.mat.cols))
+            # a host hand-off whose dense blocks leave straight from their Parameters needs the device copy only for inspection (fetch())
+            (self._lazy_launches if (self._host_mode and not addr and pitched) else self._launches).append(launch)
         if addr:
             seg_all = np.concatenate(segs + [np.array([nterms], dtype=np.int64)]).astype(np.int64)
             dst_all = np.concatenate(dsts)
             identity = len(dst_all) == len(ukey) and np.array_equal(dst_all, np.arange(len(dst_all)))
             self._launches.append(("pmt_csc_values_gather_f64", (P(ctx.upload_new(np.concatenate(addr))), nterms, P(ctx.upload_new(seg_all)), len(dst_all),
                                                                  alpha, None if identity else P(ctx.upload_new(dst_all)), P(values))))
-        return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), values)
+        return CSC(nrows, ncols, col_ptr, urows.astype(np.int64), values, rects, only_rects=bool(rects) and not addr and pitched)
+
+    @staticmethod
+    def _dense_rect(b, perm, seg, dst, alpha):
+        """the block as a pitched copy of its Parameter matrix, or None: its columns must meet the matrix's columns in ascending order (the
+        optimizer's indices of x ascending, the usual case) so that column j's values are a contiguous run, the runs a constant pitch apart"""
+        mat = b.dense
+        if mat is None or alpha != 1.0 or len(seg) != len(perm) + 1 or mat.rows == 0 or mat.cols == 0 or len(perm) != mat.rows * mat.cols:
+            return None
+        want = (np.arange(mat.rows, dtype=np.int64)[None, :] * mat.cols + np.arange(mat.cols, dtype=np.int64)[:, None]).reshape(-1)
+        if not np.array_equal(perm, want):
+            return None
+        d = dst.reshape(mat.cols, mat.rows)
+        if not np.array_equal(d, d[:, :1] + np.arange(mat.rows, dtype=np.int64)[None, :]):
+            return None
+        pitch = int(d[1, 0] - d[0, 0]) if mat.cols > 1 else mat.rows
+        if pitch < mat.rows or not np.array_equal(d[:, 0], d[0, 0] + pitch * np.arange(mat.cols, dtype=np.int64)):
+            return _Rect(0, 0, mat, offsets=np.ascontiguousarray(d[:, 0], dtype=np.int64))      # the other blocks' heights vary from column to column
+        return _Rect(d[0, 0], pitch, mat)
 
     def _add_vector_block(self, b, n, q_ptr, alpha):
         ctx = self.ctx
@@ -318,8 +406,8 @@ class DeviceQP:
             for name, args in self._launches:
                 self.ctx.call(name, *args)
         if self.host is not None and not (self._in_tape and self._host_mode == "overlap"):
-            for arr, ptr in self.host.transfers():  # behind everything on the plan's stream (serial mode)
-                self.ctx.fetch(arr, ptr, arr.nbytes)
+            for t in self.host.transfers():         # behind everything on the plan's stream (serial mode)
+                t.fetch(self.ctx)
 
     # ---- host views (tests, host solvers)
     def _f64(self, ptr, n):
@@ -330,6 +418,8 @@ class DeviceQP:
 
     def fetch(self):
         """dict(P=(x, i, p), q, r, A=(x, i, p), l, u) on the host; r is the objective constant."""
+        for name, args in self._lazy_launches:
+            self.ctx.call(name, *args)
         cptr, cval = self._obj_const
         r = float(self._f64(cptr, 1)[0]) if cptr else cval
         return {

@@ -396,6 +396,10 @@ class Model:
 
     def _run_tape(self, fetch=True):
         ctx = self.device()
+        if getattr(self, "_fetches_read_parameters", False):
+            # host_csc: dense constraint blocks leave straight out of their Parameter buffers (handoff.py): the previous solve's transfers
+            # have read them before this solve's callbacks / commits rewrite them (a no-op when the caller has synchronised, as solve! does)
+            ctx.fetch_synchronize()
         self._refresh_parameters()
         ctx.replay()
         if not fetch:

@@ -245,6 +245,30 @@ class _Record:
                 c.call("pmt_pack_scalar_affine_f64", P(out.lin), out.nl, P(varmap_buf), P(dl))
             return emit
         # Vector{AffineFunction}
+        # handoff="host_csc": the deliverable is the solver's CSC arrays on the host and the index map is fixed (Model.initialize), so the MOI
+        # terms of a dense block A*x (+|-) b or of x (+|-) v would be an intermediate nobody reads: A's CSC values are the Parameter matrix
+        # column by column (they leave straight out of its buffer, handoff.py) and the coefficients of x (+|-) v are the constant 1.0.
+        # Only the constants 0 (+|-) b are rebuilt per re-evaluation; the term STRUCTURE (rows, optimizer variables) is static host data.
+        if handoff_varmap is not None and getattr(self.model, "handoff", None) == "host_csc" and isinstance(out, (DDenseAff, DVarsAff)) and not out.need_terms:
+            xv = np.asarray(handoff_varmap, dtype=np.int64)[out.xvars.vars - 1]
+            dense = isinstance(out, DDenseAff)
+            if not dense or (len(xv) and np.all(np.diff(xv) > 0)):            # (a dense block whose columns are permuted or repeated keeps its terms)
+                self.f = VectorAffineFunction(out.nterms, out.rows)
+                t = self.f.terms
+                if dense:
+                    t["out"], t["var"], t["coeff"] = np.repeat(np.arange(1, out.rows + 1), out.mat.cols), np.tile(xv, out.rows), np.nan
+                else:
+                    t["out"], t["var"], t["coeff"] = np.arange(1, out.rows + 1), xv, 1.0
+                dc = ctx.alloc(8 * max(out.rows, 1))
+                ctx.zero(dc, 8 * max(out.rows, 1))
+                self.dev = {"consts": dc}
+                self.side_lane_ok = True
+                self.terms_static = True
+
+                def emit(c):
+                    if out.vec is not None and out.rows:
+                        c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
+                return emit
         self.f = VectorAffineFunction(out.nterms, out.rows, alloc=ctx.pinned_array)
         dt = ctx.alloc(24 * max(out.nterms, 1))
         if isinstance(out, DDenseAff) and not out.need_terms:
@@ -350,7 +374,8 @@ class _Record:
             ctx.fetch(f.affine_terms, d["lin"], f.affine_terms.nbytes)
             self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
         else:
-            ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
+            if "terms" in d:                                              # absent for a host_csc record whose terms are static (compile)
+                ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
             ctx.fetch(f.constants, d["consts"], f.constants.nbytes)
 
     def finish_fetch(self):

@@ -387,3 +387,57 @@ def test_side_lane_commits_of_staged_parameters(handoff):
             assert np.array_equal(got["l"][:n], bufs["l"]) and np.array_equal(got["u"][n:], bufs["h"])
     model.wait_staged()
     model.close()
+
+
+@pytest.mark.parametrize("case", ["dense_and_bounds", "dense_over_sparse"])
+def test_dense_blocks_leave_without_terms_or_gather(case):
+    """handoff="host_csc": the CSC values of a dense constraint block are its Parameter matrix column by column — they leave as pitched
+    copies straight out of the Parameter buffer (pmt_plan_record_fetch_2d), the bounds rows' coefficients are the static 1.0, and no MOI
+    term is packed or gathered per solve (the profile shows neither the pack kernels nor csc_values_gather_kernel).  Stacked over a sparse
+    block the other block's height varies per column: the dense block is placed by per-column offsets on the device (pmt_copy_2d_f64) and A
+    leaves as one array.  Either way A, l, u on the host follow the Parameters solve after solve and equal the device hand-off."""
+    import scipy.sparse as sp
+    n, r, mi, ms = 200, 256, 70, 31
+    rng = np.random.default_rng(17)
+    model = P.Model(P.MockOptimizer(variable_offset=3), quadratic_mode="canonical", handoff="host_csc")
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model)
+    b = P.DeviceUniformParameter((r,), 2, model)
+    residual = A * x - b
+    P.objective(model, P.Minimize, P.dot(residual, residual))
+    G = P.Parameter(model, val=rng.random((mi, n)))
+    h = P.Parameter(model, val=rng.random(mi))
+    P.constraint(model, G * x, "<=", h)
+    if case == "dense_and_bounds":
+        lo = P.Parameter(model, val=-rng.random(n))
+        P.constraint(model, x, ">=", lo)
+    else:
+        Ss = sp.random(ms, n, density=0.15, format="csc", random_state=rng, data_rvs=lambda k: rng.random(k) + 0.1)
+        Ss.sort_indices()
+        S = P.Parameter(model, val=Ss.copy())
+        e = P.Parameter(model, val=rng.random(ms))
+        P.constraint(model, S * x, "<=", e)
+    P.solve(model)
+    qp = model.device_qp
+    assert qp.A.rects and qp.A.only_rects == (case == "dense_and_bounds")
+    off = 3
+    for it in range(3):
+        G.val[...] = rng.random((mi, n)); h.val[...] = rng.random(mi)
+        P.profile_enable(True)
+        P.solve(model)
+        rep = P.profile_report()
+        P.profile_enable(False)
+        banned = ("affine_tile_kernel", "affine_pack", "vars_addsub") + (("csc_values_gather",) if case == "dense_and_bounds" else ())   # (the sparse block is gathered out of its nzval)
+        assert not any(k.startswith(banned) for k in rep), sorted(rep)
+        assert "consts_kernel" in rep
+        host = assert_host_equals_device(model)
+        rows = qp.nrows
+        Ad = sp.csc_matrix(host["A"], shape=(rows, n + off)).toarray()
+        assert np.all(Ad[:, :off] == 0)
+        if case == "dense_and_bounds":                     # update order: Nonnegatives (x >= lo) before Nonpositives (G x <= h)
+            assert np.array_equal(Ad[:n, off:], np.eye(n)) and np.array_equal(Ad[n:, off:], G.val)
+            assert np.array_equal(host["l"][:n], lo.val) and np.array_equal(host["u"][n:], h.val)
+        else:
+            assert np.array_equal(Ad[:mi, off:], G.val) and np.array_equal(Ad[mi:, off:], S.val.toarray())
+            assert np.array_equal(host["u"][:mi], h.val) and np.array_equal(host["u"][mi:], e.val)
+    model.close()
