@@ -18,8 +18,10 @@
 #     scale!(dest, s::Parameter{<:Number}, <DenseAffine>)               -> the affine block times a scalar Parameter (:284-290)
 #     vcat!(dest, <DenseAffine | bounds>...)                            -> one MOI function, the pieces stacked (:276-278)
 #     bilinearmul!(dest, Q, x', y)                                      -> transpose(x) * Q * y objectives (:219-226)
-# Anything else makes `HIPModel` keep the reference's own CPU `update!` for that record (it says so once): the device path is an
-# accelerator for the shapes it knows, never a silent approximation.
+# Anything else is an ERROR by default: `HIPModel(model)` (strict = true) throws an ArgumentError that names the record and the builder the
+# analysis does not know — a model either runs on the device path or it does not start.  `HIPModel(model; strict = false)` keeps the
+# reference's own CPU `update!` for such a record instead (logged once); `on_device(hm)` says which record runs where.  Never a silent
+# approximation, and with strict = true never a silent CPU solve either.
 #
 # Zero allocation in steady state, as the reference promises (`@allocated solve!(model) == 0`, README.md:8,138, test/model.jl:116-124):
 # update! below touches preallocated buffers only — Parameter values are copied into PAGE-LOCKED staging arrays (pmt_host_alloc) and
@@ -30,14 +32,15 @@
 # `HIPModel(model; handoff = :host_csc, solver_update = f)`: instead of 252 MB of MOI terms (config 2) the HOST solver is handed what its
 # own update takes — P's and A's CSC values, q, l, u (84 MB) in page-locked arrays that are filled WHILE the contraction runs (recorded
 # fetches + pmt_quad_gram_csc_deliver_f64): `f(Px, Ax, q, l, u)` is e.g. `(a...) -> OSQP.update!(osqp; Px = a[1], Ax = a[2], q = a[3],
-# l = a[4], u = a[5])`.  5.9 -> 1.96 ms per solve! through the Python host of this repository (DESIGN.md §8).
+# l = a[4], u = a[5])`.  5.9 -> 1.73 ms per solve! at config 2 through the Python host of this repository (DESIGN.md §8.1; the link's floor
+# for 84 MB is 1.55 ms).
 #
 # NOT EXECUTED in this repository's CI (no julia in the build image; tests/test_gpu_julia.py runs julia/example1_parity.jl when a julia
 # binary is present on the GPU box).  tests/test_cabi_exports.py checks every ccall of julia/*.jl against include/parametron_hip.h —
 # symbol, argument count and argument type classes.
 module ParametronHIPBackend
 
-export HIPModel, solve!
+export HIPModel, solve!, on_device
 
 import Parametron
 import Parametron: Model, Parameter, Variable, LazyExpression, setdirty!
@@ -315,7 +318,18 @@ mutable struct HIPModel
     handoff::Symbol                   # :moi (the reference's boundary) or :host_csc
     host::Union{Nothing, HostQP}
     solver_update::Any                # f(Px, Ax, q, l, u), called by update! in the host_csc hand-off
+    strict::Bool                      # true: every non-constant record runs on the device (HIPModel throws otherwise); false: unknown shapes keep the CPU update!
 end
+
+"""on_device(hm) -> (objective = :device | :cpu | :constant, constraints = [:device | :cpu | :constant ...] in the reference's update order).
+A record is :constant when the reference never updates it (src/moi_interop.jl:132,169), :cpu only under `strict = false`."""
+function on_device(hm::HIPModel)
+    where_is(r) = r.isconstant ? :constant : (any(x -> x === r, hm.cpu_records) ? :cpu : :device)
+    (objective = where_is(hm.model.objective), constraints = Symbol[where_is(c) for c in constraint_records(hm.model)])
+end
+
+unsupported_record(what::AbstractString, reason) =
+    ArgumentError("ParametronHIP: $what is not a shape the device path knows ($reason). HIPModel(model; strict = false) keeps the reference's CPU update! for it.")
 
 function device_param!(hm::HIPModel, p::Parameter)
     for d in hm.params
@@ -511,11 +525,21 @@ function record_host_handoff!(hm::HIPModel, rec)
         row0 += c.rows
     end
     H.record_fetch!(hm.plan, h.small, h.small_dev)
+    # A's values: recorded pitched fetches straight out of the Parameter buffers, at the FRONT of the side lane (lane 2): they need nothing of the
+    # re-evaluation, so the copy engine starts on them in the first microseconds of the solve (pmt_plan_record_fetch_2d, pmt_plan_set_lane)
+    H.set_lane!(hm.plan, 2)
+    row0 = 0
+    for c in hm.constraints
+        buf, lda, r, ncol = c.dense
+        H.record_fetch_matrix!(hm.plan, pointer(h.Ax) + 8 * row0, 8 * m, buf, lda, r, ncol)
+        row0 += r
+    end
     H.set_lane!(hm.plan, 0)
     nothing
 end
 
-"A's values in the serial part of update!: one pitched copy per dense block straight out of its Parameter buffer (column j of A = the blocks' columns j, stacked)"
+"A's values behind the re-evaluation instead (the serial form of the recorded fetches above; kept for hosts that do not record them): one pitched copy per
+dense block straight out of its Parameter buffer (column j of A = the blocks' columns j, stacked)"
 function fetch_A!(hm::HIPModel)
     h = hm.host
     row0 = 0
@@ -527,14 +551,14 @@ function fetch_A!(hm::HIPModel)
     nothing
 end
 
-function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 << 24, handoff::Symbol = :moi, solver_update = nothing)
+function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 << 24, handoff::Symbol = :moi, solver_update = nothing, strict::Bool = true)
     handoff in (:moi, :host_csc) || throw(ArgumentError("handoff must be :moi or :host_csc"))
     model.initialized || Parametron.initialize!(model)              # copy_to + mapindices! first: the index map is then final (src/model.jl:117-122)
     plan = H.Plan(device)
     nvars = length(model.model_var_to_optimizer)
     varmap = upload_indices(plan, Int64[vi.value for vi in model.model_var_to_optimizer])          # src/model.jl:100-107
     host = handoff === :host_csc ? HostQP(Float64[], Float64[], Float64[], nvars, 0, DevPtr(C_NULL)) : nothing
-    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit, 0, handoff, host, solver_update)
+    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit, 0, handoff, host, solver_update, strict)
     rec = H.recording_stream(plan)
     H.begin_record!(plan)
     try
@@ -547,7 +571,8 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
             catch err
                 err isa Unsupported || rethrow()
                 handoff === :host_csc && rethrow()                   # the host_csc hand-off has no CPU fallback for a record: say so
-                @info "ParametronHIP: the objective stays on the CPU path" reason = err.what
+                strict && throw(unsupported_record("the objective", err.what))
+                @info "ParametronHIP: the objective stays on the CPU path (strict = false)" reason = err.what
                 push!(hm.cpu_records, obj)
             end
         end
@@ -558,7 +583,8 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
             catch err
                 err isa Unsupported || rethrow()
                 handoff === :host_csc && rethrow()
-                @info "ParametronHIP: a constraint stays on the CPU path" reason = err.what
+                strict && throw(unsupported_record("constraint $(length(hm.constraints) + length(hm.cpu_records) + 1) ($(typeof(c.set)))", err.what))
+                @info "ParametronHIP: a constraint stays on the CPU path (strict = false)" reason = err.what
                 push!(hm.cpu_records, c)
             end
         end
@@ -625,8 +651,7 @@ function Parametron.update!(hm::HIPModel)
     H.update!(hm.plan)                                               # every device node of the model (+ the recorded fetches / the delivery of P)
     if hm.handoff === :host_csc
         h = hm.host
-        fetch_A!(hm)                                                 # pitched copies out of the Parameter buffers, behind the commits
-        H.fetch_synchronize(hm.plan)                                 # q | l | u and P's band groups have landed
+        H.fetch_synchronize(hm.plan)                                 # A's blocks (recorded pitched fetches), q | l | u and P's band groups have landed
         H.synchronize(hm.plan)
         hm.solver_update === nothing || hm.solver_update(h.Px, h.Ax, q_of(h), l_of(h), u_of(h))
         return nothing
@@ -635,7 +660,14 @@ function Parametron.update!(hm::HIPModel)
     for c in hm.constraints
         Parametron.update!(c, hm, m.optimizer)
     end
-    for r in hm.cpu_records                                          # shapes the device path does not know: the reference's own update!
+    hm.strict || cpu_update!(hm)
+    nothing
+end
+
+"strict = false only: the records whose shape the device path does not know run the reference's own update! (src/moi_interop.jl:131-137,168-175)"
+function cpu_update!(hm::HIPModel)
+    m = hm.model
+    for r in hm.cpu_records
         Parametron.update!(r, m.optimizer, m.model_var_to_optimizer)
     end
     nothing

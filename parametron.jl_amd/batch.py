@@ -241,8 +241,33 @@ def measure(torch, dist, rank, world, steps, warmup):
         dist.all_reduce(one)
         ranks_seen = int(one.item())
     nchunks = len(chunk_schedule(wl.B, chunk))
+    rccl_calls = comm.rccl_calls()
     comm.close()
-    return sharded_report(world, ranks_seen, steps, warmup, t_pipe, t_mono, t_compute, nchunks) if rank == 0 else None
+    rep = sharded_report(world, ranks_seen, steps, warmup, t_pipe, t_mono, t_compute, nchunks) if rank == 0 else None
+    if world == 1:
+        # One GPU: the value above loads no RCCL (a single rank has nothing to exchange).  The library's RCCL binding is exercised all the
+        # same: a real ONE-RANK communicator (ncclGetUniqueId / ncclCommInitRank) whose chunks travel to itself through grouped ncclSend /
+        # ncclRecv on the communication stream — the N-rank code path on this GPU, checked against the plain result and timed beside it.
+        try:
+            want = wl.local.clone()
+            c1 = Communicator(torch, None, 0, 1, torch.cuda.current_device(), rccl_single=True)
+            wl.gathered = torch.full_like(wl.local, float("nan"))
+            ch = max(256, wl.B // 8)
+            for _ in range(3):
+                wl.step_pipelined(c1, ch)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(wl.gathered, want) and torch.equal(wl.local, want))
+            t_self = timed(lambda: wl.step_pipelined(c1, ch))
+            rccl_calls = c1.rccl_calls()
+            c1.close()
+            rep["rccl_self_exchange"] = {"ms_per_step": t_self / steps * 1e3, "chunks": len(chunk_schedule(wl.B, ch)), "gathered_equals_local": ok,
+                                         "what": "one-rank RCCL communicator: every chunk sent to / received from this rank through RCCL while the next is computed"}
+        except Exception as e:
+            rep["rccl_self_exchange"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rep is not None:
+        rep["rccl_calls_made"] = rccl_calls > 0
+        rep["rccl_calls"] = rccl_calls
+    return rep
 
 
 def bench(args, torch, dist, lib_mod, rank, world):

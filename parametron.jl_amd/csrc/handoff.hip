@@ -11,6 +11,7 @@
 // l = v - c, u = +infty;  Nonpositives/LessThan(v): l = -infty, u = v - c.
 #include <algorithm>
 #include <numeric>
+#include <new>
 #include <vector>
 
 #include "common.h"
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void qp_bounds_rows_kernel(const double *const
 using namespace pmt;
 
 extern "C" int pmt_csc_order(int64_t nnz_in, const int64_t *rows, const int64_t *cols, int64_t nrows, int64_t ncols, int upper,
-                             int64_t *perm, int64_t *seg_ptr, int64_t *col_ptr, int64_t *row_idx, int64_t *nnz_out) {
+                             int64_t *perm, int64_t *seg_ptr, int64_t *col_ptr, int64_t *row_idx, int64_t *nnz_out) try {
     PMT_REQUIRE(nnz_in >= 0 && nrows >= 0 && ncols >= 0, PMT_DIMENSION_MISMATCH, "csc_order: negative size");
     PMT_REQUIRE(nnz_out && seg_ptr && col_ptr && (nnz_in == 0 || (rows && cols && perm && row_idx)), PMT_INVALID_ARGUMENT, "csc_order: null pointer");
     auto r_of = [&](int64_t i) { return (upper ? std::min(rows[i], cols[i]) : rows[i]) - 1; };
@@ -132,6 +133,8 @@ extern "C" int pmt_csc_order(int64_t nnz_in, const int64_t *rows, const int64_t 
     seg_ptr[nseg] = nnz_in;
     *nnz_out = nseg;
     return PMT_OK;
+} catch (const std::bad_alloc &) {
+    return pmt::fail(PMT_OUT_OF_MEMORY, "csc_order: out of host memory");
 }
 
 extern "C" int pmt_csc_values_f64(const void *src_coeff, int64_t src_stride_bytes, int64_t nnz_in, const int64_t *perm, const int64_t *seg_ptr,

@@ -6,6 +6,7 @@
 // non-zeros is computed once on the host at plan time (the sparsity pattern is fixed across re-evaluations);
 // each re-evaluation is one gather + coalesced 24-byte AoS write: 8 (nzval) + 8 (perm) + 8 (row) + 8 (var) read,
 // 24 written per non-zero.
+#include <new>
 #include <vector>
 
 #include "common.h"
@@ -298,7 +299,7 @@ extern "C" int pmt_sparse_assemble_f64(const double *nzval, const int64_t *perm,
 }
 
 extern "C" int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int64_t *perm,
-                                         int64_t *rows_out, int64_t *cols_out, int64_t *row_ptr) {
+                                         int64_t *rows_out, int64_t *cols_out, int64_t *row_ptr) try {
     PMT_REQUIRE(m >= 0 && n >= 0, PMT_DIMENSION_MISMATCH, "sparse_rowmajor_order: negative dimension");
     PMT_REQUIRE(colptr && row_ptr, PMT_INVALID_ARGUMENT, "sparse_rowmajor_order: null pointer");
     PMT_REQUIRE(colptr[0] == 1, PMT_INVALID_ARGUMENT, "sparse_rowmajor_order: colptr must be 1-based");
@@ -323,6 +324,8 @@ extern "C" int pmt_sparse_rowmajor_order(int64_t m, int64_t n, const int64_t *co
             cols_out[t] = c + 1;
         }
     return PMT_OK;
+} catch (const std::bad_alloc &) {
+    return pmt::fail(PMT_OUT_OF_MEMORY, "sparse_rowmajor_order: out of host memory");
 }
 
 extern "C" int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *perm, const int64_t *term_row, const int64_t *term_var,
@@ -338,7 +341,7 @@ extern "C" int pmt_sparse_pack_vector_f64(const double *nzval, const int64_t *pe
     });
 }
 
-extern "C" int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const int64_t *row_ptr, const int64_t *term_col, int64_t *slab_ptr) {
+extern "C" int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const int64_t *row_ptr, const int64_t *term_col, int64_t *slab_ptr) try {
     PMT_REQUIRE(rows >= 0 && cols >= 0 && nslab >= 1, PMT_DIMENSION_MISMATCH, "sparse_slab_ptr: bad dimensions");
     PMT_REQUIRE(row_ptr && slab_ptr, PMT_INVALID_ARGUMENT, "sparse_slab_ptr: null pointer");
     for (int64_t r = 0; r < rows; ++r) {
@@ -351,6 +354,8 @@ extern "C" int pmt_sparse_slab_ptr(int64_t rows, int64_t cols, int nslab, const 
         }
     }
     return PMT_OK;
+} catch (const std::bad_alloc &) {
+    return pmt::fail(PMT_OUT_OF_MEMORY, "sparse_slab_ptr: out of host memory");
 }
 
 template <typename IDX>
@@ -393,7 +398,7 @@ extern "C" int pmt_sparse_assemble_slabs_u32_f64(const double *nzval, const uint
 }
 
 // ---- block form: host-side structure (once per pattern) and launchers
-extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int *out_cw) {
+extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, int *out_cw) try {
     PMT_REQUIRE(m >= 0 && n >= 0, PMT_DIMENSION_MISMATCH, "sparse_blocks_width: negative dimension");
     PMT_REQUIRE(colptr && out_cw, PMT_INVALID_ARGUMENT, "sparse_blocks_width: null pointer");
     *out_cw = 0;
@@ -403,9 +408,19 @@ extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colp
     if (nnz == 0 || nnz >= ((int64_t)1 << 32)) return PMT_OK;           // nothing to do / positions do not fit the 32-bit descriptors
     PMT_REQUIRE(rowval, PMT_INVALID_ARGUMENT, "sparse_blocks_width: null pointer");
     const int64_t nrb = cdiv(m, SB_RB);
+    // The block form pays when a row's part of a column band is a run worth writing: >= 16 terms on average, i.e. nnz >= 16 * m * (number
+    // of bands).  Checked with the widest band BEFORE anything is sized by m * n: a hypersparse pattern (1e6 x 1e6 with a few entries per
+    // column) must not allocate its (row block, strip) table — about 1 GB there — only to be turned down; it keeps the slab form (cw = 0).
+    if (nnz < 16 * m * cdiv(n, SB_MAXCW)) {
+        for (int64_t p = 0; p < nnz; ++p)
+            if (rowval[p] < 1 || rowval[p] > m) return fail(PMT_DIMENSION_MISMATCH, "sparse_blocks_width: row index out of range");
+        return PMT_OK;
+    }
     // non-zeros per (row block, 32-column strip); rows must ascend within a column (they do in a SparseMatrixCSC)
     const int64_t nstrip = cdiv(n, 32);
-    std::vector<int32_t> cnt((size_t)(nrb * nstrip), 0);
+    std::vector<int32_t> cnt;
+    try { cnt.assign((size_t)(nrb * nstrip), 0); }
+    catch (const std::bad_alloc &) { return fail(PMT_OUT_OF_MEMORY, "sparse_blocks_width: out of host memory for the block table"); }
     for (int64_t c = 0; c < n; ++c) {
         int64_t prev = 0;
         for (int64_t p = colptr[c] - 1; p < colptr[c + 1] - 1; ++p) {
@@ -425,13 +440,18 @@ extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colp
                 for (int64_t k = s0; k < std::min(nstrip, s0 + per); ++k) tot += cnt[(size_t)(rb * nstrip + k)];
                 worst = std::max(worst, tot);
             }
-        if (worst <= SB_CAP) { *out_cw = cw; return PMT_OK; }
+        if (worst <= SB_CAP) {
+            if (nnz >= 16 * m * cdiv(n, cw)) *out_cw = cw;               // (the same gate with the band width that fits)
+            return PMT_OK;
+        }
     }
     return PMT_OK;
+} catch (const std::bad_alloc &) {
+    return pmt::fail(PMT_OUT_OF_MEMORY, "sparse_blocks_width: out of host memory");
 }
 
 extern "C" int pmt_sparse_blocks_build(int64_t m, int64_t n, const int64_t *colptr, const int64_t *rowval, const int64_t *perm,
-                                       const int64_t *term_col, const int64_t *row_ptr, int cw, uint64_t *desc, uint32_t *idx, int64_t *band_ptr) {
+                                       const int64_t *term_col, const int64_t *row_ptr, int cw, uint64_t *desc, uint32_t *idx, int64_t *band_ptr) try {
     PMT_REQUIRE(m > 0 && n > 0, PMT_DIMENSION_MISMATCH, "sparse_blocks_build: empty matrix");
     PMT_REQUIRE(cw >= 32 && cw <= SB_MAXCW && (cw & (cw - 1)) == 0, PMT_INVALID_ARGUMENT, "sparse_blocks_build: bad band width");
     PMT_REQUIRE(colptr && rowval && perm && term_col && row_ptr && desc && idx && band_ptr, PMT_INVALID_ARGUMENT, "sparse_blocks_build: null pointer");
@@ -468,6 +488,8 @@ extern "C" int pmt_sparse_blocks_build(int64_t m, int64_t n, const int64_t *colp
         for (int64_t u = row_ptr[r]; u < tend; ++u) idx[u] = slot[(size_t)perm[u]] | ((uint32_t)((term_col[u] - 1) % cw) << 16);
     }
     return PMT_OK;
+} catch (const std::bad_alloc &) {
+    return pmt::fail(PMT_OUT_OF_MEMORY, "sparse_blocks_build: out of host memory");
 }
 
 static int launch_sparse_blocks(bool vat, const double *nzval, const uint64_t *desc, const uint32_t *idx, const int64_t *band_ptr,

@@ -59,3 +59,29 @@ def test_sharded_c4_report_contract():
 
 def test_default_line_documents_the_sharded_config():
     assert "C4_sharded" in bench.__doc__ and "ranks_seen" in bench.__doc__
+
+
+def test_line_ends_with_the_contract_objects_and_a_compact_summary():
+    """a log that keeps only the tail of stdout must still show what matters: the bulky sections come first, then the contract fields,
+    `roofline`, `cpu_baseline`, and `summary` — last and short"""
+    out = {"metric": "m", "value": 800.0, "unit": "re-evaluations/s", "ms_per_step": 1.25, "n_gpus": 1,
+           "config": {"workload": "C2"}, "roofline": {"frac": 0.74, "avg_ms": 1.18}, "kernels": {"k": {"avg_ms": 1.0, "what": "x" * 4000}},
+           "configs": {"C3": {"ms_per_step": 1.27, "workload": "y" * 3000}, "C4": {"ms_per_step": 0.44, "roofline": {"frac": 0.54}},
+                       "C5": {"ms_per_step": 0.03, "roofline": {"frac": 0.55}}, "C4_sharded": {"ms_per_step": 0.45, "rccl_calls_made": True}},
+           "host_api": {"handoff_device": {"ms_per_solve": 1.29}, "handoff_host_csc": {"ms_per_solve": 1.73}, "handoff_moi": {"ms_per_solve": 4.7},
+                        "c3_host_csc": {"ms_per_solve": 1.97}},
+           "roofline_constraint_pack": {"frac": 0.63, "in_step": {"frac": 0.44, "rocprofv3": {"frac": 0.55}}},
+           "roofline_affine": {"frac": 0.8, "cold": {"frac": 0.6}}, "cpu_baseline": {"value": 0.004, "sample": "z" * 500}, "ranks_seen": 1}
+    res = bench.ordered_for_the_tail(out)
+    assert set(res) == set(out) | {"summary"}
+    keys = list(res)
+    assert keys[-1] == "summary" and keys[-3:-1] == ["roofline", "cpu_baseline"] and keys.index("kernels") < keys.index("metric") < keys.index("roofline")
+    s = res["summary"]
+    for k in ("C3_ms", "C4_ms", "C4_frac", "C5_ms", "C5_frac", "host_csc_ms", "moi_ms", "device_ms", "pack_in_step_frac", "affine_warm_frac", "affine_cold_frac",
+              "ranks_seen", "rccl_calls_made", "gram_frac", "value", "ms_per_step"):
+        assert k in s, k
+    assert s["pack_in_step_frac"] == 0.55 and s["C4_frac"] == 0.54 and s["host_csc_ms"] == 1.73 and s["rccl_calls_made"] is True
+    text = json.dumps(res)
+    tail = text[-2000:]
+    assert '"summary"' in tail and '"roofline"' in tail and len(json.dumps(s)) < 1200
+    assert bench.summary_of({})["value"] is None                 # sections may be missing (N > 1, --no-configs): no exception

@@ -205,3 +205,37 @@ def test_julia_update_path_has_no_allocating_constructors():
             assert not hit, "%s allocates in the per-solve path: %r" % (head, hit.group(0))
         checked += 1
     assert checked == len(per_solve)
+
+
+def test_julia_backend_is_strict_by_default():
+    """A record whose shape the analysis does not know must not silently run the reference's CPU update! (a Julia user could not tell a GPU
+    solve from a CPU solve): HIPModel(model) throws an ArgumentError by default, `strict = false` is the explicit opt-out, on_device(hm)
+    reports which record runs where, and update!(hm) reaches the reference's update!(record, optimizer, varmap) only through cpu_update!,
+    which it calls only when the model is not strict.  (Static: no julia in this image.)"""
+    src = open(os.path.join(ROOT, "julia", "ParametronHIPBackend.jl")).read()
+    assert re.search(r"function HIPModel\(model::Model;[^)]*strict::Bool = true", src)
+    assert "export HIPModel, solve!, on_device" in src and re.search(r"function on_device\(hm::HIPModel\)", src)
+    # both catch sites of an Unsupported record throw when strict, before the @info fallback
+    sites = re.findall(r"err isa Unsupported \|\| rethrow\(\)(.*?)push!\(hm\.cpu_records", src, flags=re.S)
+    assert len(sites) == 2
+    for body in sites:
+        assert body.index("strict && throw(unsupported_record(") < body.index("@info")
+    assert "ArgumentError(" in src[src.index("unsupported_record(what"):src.index("unsupported_record(what") + 400]
+
+    def body_of(head):
+        m = re.search(head, src)
+        assert m, head
+        out, depth = [], 0
+        for line in src[m.start():].splitlines():
+            code = line.split("#")[0]
+            depth += len(re.findall(r"\b(function|if|for|while|try|let|do|begin)\b", code)) - len(re.findall(r"\bend\b", code))
+            out.append(code)
+            if depth <= 0 and len(out) > 1:
+                break
+        return "\n".join(out)
+    upd = body_of(r"function Parametron\.update!\(hm::HIPModel\)")
+    assert "m.model_var_to_optimizer)" not in upd, "update!(hm) calls the reference's CPU update! directly"
+    assert re.search(r"hm\.strict \|\| cpu_update!\(hm\)", upd)
+    cpu = body_of(r"function cpu_update!\(hm::HIPModel\)")
+    assert "Parametron.update!(r, m.optimizer, m.model_var_to_optimizer)" in cpu
+    assert len(re.findall(r"cpu_update!\(hm\)", src)) == 1          # the one guarded call

@@ -39,6 +39,11 @@ for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
     reg = d[first:first + bu["steps"]]
     lines.append("%-28s %3d launches in the process; timed region: avg %.1f us, min %.1f, max %.1f; spin-up + warm-up before it: avg %.1f us" %
                  (name, len(d), sum(reg) / len(reg), min(reg), max(reg), sum(d[:first]) / max(1, first)))
+json.dump({name: {"avg_us": sum(d[first:first + bu["steps"]]) / bu["steps"], "launches": bu["steps"],
+                  "source": "rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline`, launches of the timed region; tag " + out}
+           for name, key in (("gram_sk_kernel", "gram_sk_kernel<"), ("gram_sk_fixup_kernel", "gram_sk_fixup_kernel"), ("affine_tile_kernel<VAT>", "affine_tile_kernel<1"))
+           for d in [[(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if key in r["Kernel_Name"]]] if len(d) >= first + bu["steps"]},
+          open(out + "/rocprof_in_step.json", "w"), indent=1)
 lines.append("bench.py's HIP-event average for the dominant kernel in the same run: %.1f us" % (bu["roofline"]["avg_ms"] * 1e3))
 open(out + "/rocprofv3_timed_region.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
