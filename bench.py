@@ -574,7 +574,7 @@ def cpu_canonical_blas(wl):
 
 def run_batch(args, torch, dist, _lib, rank, world):
     from parametron_jl_amd import batch
-    return batch.bench(args, torch, dist, _lib, rank, world)
+    return batch.bench(args, torch, dist, _lib, rank, world, emit=emit_line)
 
 
 def guarded(fn, *a):
@@ -584,8 +584,31 @@ def guarded(fn, *a):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries underneath write there too (RCCL prints a five-line version banner through C
+    stdio when its first communicator is built — flushed at exit, i.e. BEHIND the JSON line): file descriptor 1 is pointed at stderr for
+    the life of the process and the line goes to a duplicate of the original descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
     args = parse_args()
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -733,7 +756,7 @@ def main():
             if rank == 0:
                 out.setdefault("configs", {})["C4_sharded"] = {"error": "timeout: the sharded section did not finish within 150 s"}
                 out["ranks_seen"] = None
-                print(json.dumps(ordered_for_the_tail(out)), flush=True)
+                emit_line(ordered_for_the_tail(out))
             os._exit(0)
         watchdog = threading.Timer(150.0, give_up)
         watchdog.daemon = True
@@ -747,7 +770,7 @@ def main():
             out.setdefault("configs", {})["C4_sharded"] = sharded
             out["ranks_seen"] = sharded.get("ranks_seen") if isinstance(sharded, dict) else None
     if rank == 0:
-        print(json.dumps(ordered_for_the_tail(out)), flush=True)
+        emit_line(ordered_for_the_tail(out))
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -270,13 +270,13 @@ def measure(torch, dist, rank, world, steps, warmup):
     return rep
 
 
-def bench(args, torch, dist, lib_mod, rank, world):
+def bench(args, torch, dist, lib_mod, rank, world, emit=None):
     """bench.py --workload batch: 8192 x (n = r = 128, m = 16) instances, strong scaling over ranks.  Reports the re-evaluation rate
     compute-only, with one monolithic all-gather behind the computation (torch.distributed), and with the library's chunked exchange
     overlapped with the computation (pmt_batch_step_f64) — BASELINE.md §3 asks for the gather included and excluded."""
     out = measure(torch, dist, rank, world, args.steps, args.warmup)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        (emit or (lambda o: print(json.dumps(o), flush=True)))(out)        # (bench.py passes the writer that owns the real stdout)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

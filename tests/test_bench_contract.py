@@ -85,3 +85,20 @@ def test_line_ends_with_the_contract_objects_and_a_compact_summary():
     tail = text[-2000:]
     assert '"summary"' in tail and '"roofline"' in tail and len(json.dumps(s)) < 1200
     assert bench.summary_of({})["value"] is None                 # sections may be missing (N > 1, --no-configs): no exception
+
+
+def test_stdout_carries_the_json_line_only(tmp_path):
+    """Libraries underneath (RCCL's version banner, C stdio) must not add lines to stdout: bench.py points descriptor 1 at stderr and writes
+    its line to a duplicate of the original one.  Checked in a child process that prints through C stdio behind the line, as RCCL does."""
+    import subprocess
+    code = ("import bench, ctypes, sys\n"
+            "bench.claim_stdout()\n"
+            "libc = ctypes.CDLL(None)\n"
+            "libc.printf(b'RCCL version : banner\\n')\n"                     # buffered C stdio, flushed at exit
+            "print('a python print somewhere')\n"
+            "bench.emit_line({'metric': 'm', 'value': 1})\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(__import__("pathlib").Path(bench.__file__).parent))
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "m", "value": 1}
+    assert "banner" in r.stderr and "a python print somewhere" in r.stderr
