@@ -15,6 +15,10 @@
 
 namespace pmt {
 
+#ifndef PMT_AFFINE_NT_LOAD
+#define PMT_AFFINE_NT_LOAD 0      // 1: the matrix is read with the nontemporal policy (a stream read once per re-evaluation)
+#endif
+
 constexpr int TILE = 64;
 constexpr int PITCH = TILE + 1;
 
@@ -64,7 +68,8 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
         const double *base = A + (c0 + cg) * lda + r0 + lr;
 #pragma unroll
         for (int it = 0; it < TILE / CPI; ++it) {
-            f64x2 v = *reinterpret_cast<const f64x2 *>(base + (int64_t)it * CPI * lda);
+            const f64x2 *src = reinterpret_cast<const f64x2 *>(base + (int64_t)it * CPI * lda);
+            f64x2 v = PMT_AFFINE_NT_LOAD ? __builtin_nontemporal_load(src) : *src;
             const int c = it * CPI + cg;
             tile[lr * PITCH + c] = v.x;
             tile[(lr + 1) * PITCH + c] = v.y;

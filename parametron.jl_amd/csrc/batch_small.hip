@@ -43,6 +43,16 @@
 #define PMT_BS_FENCE 1     // operand reads are hoisted at most one k-step ahead of their MFMAs (unfenced the scheduler hoists several k-steps and spills)
 #endif
 
+#ifndef PMT_BS_GLDS
+#define PMT_BS_GLDS 0      // 1: the FAST path's A chunks go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write)
+#endif
+
+#ifndef PMT_BS_NT
+#define PMT_BS_NT 3        // bit 0 = the A stream is loaded with the nt policy, bit 1 = the slab copy-out stores are nontemporal
+#endif
+// (measured, profiles/r04_batch_small.txt: A is read once and the slab written once — with both marked nontemporal the step takes 0.430 instead
+// of 0.443 ms; either alone is within noise)
+
 #ifndef PMT_BS_TRACE
 #define PMT_BS_TRACE 0     // tuning builds: s_memtime stamps of workgroup 0's matrix wave 0, read back with pmt_debug_bs_trace (the loader waves must not
                            // be instrumented: a stamp is a global store, and their hand-counted s_waitcnt assumes they issue loads only)
@@ -72,6 +82,16 @@ constexpr int CREG = 16;                // constraint-block entries prefetched p
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// LDS-DMA panel layout (GL): a global_load_lds_dwordx4 writes 64 lanes x 16 bytes LINEARLY from a wave-uniform base, so the image cannot be
+// padded per column.  One instruction fills a GROUP of four columns (4 x 256 bytes; lane L = column L >> 4, 16-byte slot L & 15); groups
+// are 1088 bytes apart (64 bytes of padding: the panel is exactly as large as the padded one) and inside a group slot s of column cg holds
+// the row pair s ^ cg (the lane reads that pair from HBM: the swizzle is on the SOURCE address, a quarter wave still reads one whole 256-byte
+// column piece).  16 lanes reading the same row pair of 16 consecutive columns then touch 16 distinct 16-byte slots: (group & 3) * 64 +
+// ((pair ^ cg) & 3) * 16 + ... covers every bank once — conflict-free like the 34-double pitch, for 8- and 16-byte reads alike.
+constexpr int GLG = 136;                // doubles per column group (1088 bytes)
+// doubles offset of (column c, row r) in a GL panel
+__device__ __forceinline__ int gl_off(int c, int r) { return (c >> 2) * GLG + (c & 3) * 32 + ((((r >> 1) ^ (c & 3)) << 1) | (r & 1)); }
+
 struct SmallArgs {
     const double *A; int64_t lda, rows, cols, strideA;
     const double *b; int64_t strideb; int sign;
@@ -89,7 +109,7 @@ __device__ __forceinline__ void phase_barrier() { __syncthreads(); }
 
 // ---- matrix wave W (0..3): column strips 7 - W (tm = 0 .. 7 - W) and W (tm = 0 .. W)
 // ALLCOLS: n == 128 (no column predicate on the staging stores)
-template <int W, bool ALLCOLS>
+template <int W, bool ALLCOLS, bool GL>
 __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh, int lane, int n, int nchunk) {
     constexpr int KA = 8 - W, KB = W + 1, TNA = 7 - W, TNB = W;
     const int lm = lane & 15, lk = lane >> 4;
@@ -118,6 +138,18 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
     if (PMT_BS_PRIO) __builtin_amdgcn_s_setprio(PMT_BS_PRIO);                                                           // the matrix pipe's wave outranks the helper on its SIMD
     const int a0 = lm * SGP + lk;                                                            // sub-tile tm: + tm * 16 * SGP
     const int bA0 = (TNA * 16) * SGP + lk, bB0 = (TNB * 16) * SGP + lk;
+    // GL panels: (column 16 t + c', row 4 ks + lk) sits at gl_off; the row pair 2 ks + (lk >> 1) is XORed with the column's cg = c' & 3, whose
+    // bit 1 meets the parity of ks: one base for even and one for odd k-steps, everything else is an immediate (t * 544, (ks >> 1) * 8 doubles)
+    const int cgl = lm & 3;
+    const int glane = cgl * 32 + ((((lk >> 1) ^ (cgl & 1)) << 1) | (lk & 1));
+    const int gaE = (lm >> 2) * GLG + glane + (cgl >> 1) * 4, gaO = (lm >> 2) * GLG + glane + (1 - (cgl >> 1)) * 4;
+    int gbE[4], gbO[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int grp = ((lm >> 2) + r) & 3;
+        gbE[r] = grp * GLG + glane + (cgl >> 1) * 4;
+        gbO[r] = grp * GLG + glane + (1 - (cgl >> 1)) * 4;
+    }
     const int64_t G = gridDim.x;
     int cur = 0;
     int tphase = 0; (void)tphase;
@@ -137,6 +169,18 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
                         for (int i = 0; i < KA; ++i) a[s_][i] = (double)(lane + i + ks);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { bA[s_][r] = (double)(lane + r); bB[s_][r] = (double)(lane - r); }
+                        return;
+                    }
+                    if (GL) {
+                        const int hi = (ks >> 1) * 8;
+#pragma unroll
+                        for (int i = 0; i < KA; ++i) a[s_][i] = pan[((ks & 1) ? gaO : gaE) + i * 4 * GLG + hi];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int b0 = (ks & 1) ? gbO[r] : gbE[r];
+                            bA[s_][r] = pan[b0 + TNA * 4 * GLG + hi];
+                            bB[s_][r] = pan[b0 + TNB * 4 * GLG + hi];
+                        }
                         return;
                     }
 #pragma unroll
@@ -193,6 +237,102 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
 }
 
 // ---- loader waves 4, 5 (lt = 0..127): chunk loads -> LDS panels, and q from the LDS chunk
+// ---- loader waves 4, 5, LDS-DMA form (FAST shapes only): in phase g the 16 global_load_lds_dwordx4 of chunk g + 1 go straight into the panel
+// chunk g - 1 has just left (no staging registers, no ds_write pass), q is accumulated from panel g while they fly, and the wave waits for
+// them (vmcnt(0), by hand: the compiler does not count asm loads) just before the phase's barrier — the matrix waves read the panel one
+// phase after that wait.
+__device__ __forceinline__ void loader_waves_glds(const SmallArgs &p, const Shared &sh, int lt, int n, int nchunk) {
+    const int lane = lt & 63, lw = __builtin_amdgcn_readfirstlane(lt >> 6);
+    const int lm = lane & 15;
+    const int nq = n * (n + 1) / 2;
+    const int64_t G = gridDim.x;
+    const bool has_c = p.b && p.sign;
+    const double *csrc = has_c ? p.b : p.A;
+    const int64_t cstride = has_c ? p.strideb : p.strideA;
+    const int csign = has_c ? p.sign : 0;
+    // instruction q of this wave fills column group 16 lw + q; lane L of it: column 4 (16 lw + q) + (L >> 4), row pair (L & 15) ^ (L >> 4)
+    const int64_t lane_src = (int64_t)(lane >> 4) * p.lda + 2 * ((lane & 15) ^ (lane >> 4));
+    const unsigned pan_lds = (unsigned)reinterpret_cast<uintptr_t>(sh.panel) + (unsigned)(lw * 16 * GLG * 8);       // LDS byte address (low half of the generic one)
+    double cval = 0.0;
+    auto issue_chunk = [&](int64_t inst, int ch, int buf) {
+        const double *src0 = p.A + inst * p.strideA + (int64_t)(lw * 64) * p.lda + (int64_t)ch * CK + lane_src;
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(pan_lds + (unsigned)(buf * PANEL * 8));
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const double *src = src0 + (int64_t)(4 * q) * p.lda;
+            const unsigned dst = dst0 + (unsigned)(q * GLG * 8);
+            unsigned keep;
+            if (PMT_BS_NT & 1)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+        const double *cs = csrc + inst * cstride + (int64_t)ch * CK + (lt & (CK - 1));
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(cval) : "v"(cs) : "memory");
+    };
+    auto land_chunk = [&](int buf) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cval) : : "memory");
+        sh.cvec[buf * CK + (lt & (CK - 1))] = signed_const(cval, csign);                      // four threads write the same value: benign
+    };
+    // q as in the register form; (column c, rows 4 u + 2 lkp, + 1) is one aligned 16-byte read at gl_off(c, 4 u + 2 lkp): the pair index
+    // 2 u + lkp meets cg = c & 3, whose bit 1 meets the parity of u
+    double qpart[4] = {0.0, 0.0, 0.0, 0.0};
+    const int lkp = (lane >> 4) & 1, cg = lane >> 5;
+    const int c0 = 64 * lw + 16 * cg + lm, cgl = c0 & 3;
+    const int qbase = (c0 >> 2) * GLG + cgl * 32 + ((lkp ^ (cgl & 1)) << 1);
+    const int qE = qbase + (cgl >> 1) * 4, qO = qbase + (1 - (cgl >> 1)) * 4;
+    auto next_of = [&](int64_t i, int c, int64_t &ni, int &nc) { nc = c + 1; ni = i; if (nc == nchunk) { nc = 0; ni = i + G; } };
+
+    int64_t inst = blockIdx.x;
+    int ch = 0;
+    if (inst < p.B) {
+        issue_chunk(inst, 0, 0);
+        land_chunk(0);
+    }
+    phase_barrier();
+    int par = 0;
+    while (inst < p.B) {
+        const double *pan = sh.panel + par * PANEL;
+        int64_t n1i; int n1c;
+        next_of(inst, ch, n1i, n1c);
+        const bool more = n1i < p.B;
+        const bool last = (ch == nchunk - 1);
+        issue_chunk(more ? n1i : inst, more ? n1c : ch, par ^ 1);          // (past the end: a valid chunk again, never used)
+        if (!(PMT_BS_SKIP & 2)) {
+#pragma unroll
+            for (int u = 0; u < CK / 4; ++u) {
+                const f64x2 c2 = *reinterpret_cast<const f64x2 *>(sh.cvec + par * CK + 4 * u + 2 * lkp);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f64x2 a2 = *reinterpret_cast<const f64x2 *>(pan + ((u & 1) ? qO : qE) + j * 8 * GLG + (u >> 1) * 8);
+                    const double p0 = c2.x * a2.x, p1 = c2.y * a2.y;
+                    qpart[2 * j] = qpart[2 * j] + p0;
+                    qpart[2 * j + 1] = qpart[2 * j + 1] + p1;
+                }
+            }
+        }
+        if (last) {
+            phase_barrier();                                  // the previous slab has left the staging buffer
+            double *outp = p.out + inst * p.out_stride;
+            double *st = sh.stage + (int)((reinterpret_cast<uintptr_t>(outp) >> 3) & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double p2 = __shfl(qpart[2 * j], lane + 16, 64), p3 = __shfl(qpart[2 * j + 1], lane + 16, 64);
+                const int col = 64 * lw + 32 * j + 16 * cg + lm;
+                if (lkp == 0 && col < n) st[nq + col] = 2 * (((qpart[2 * j] + qpart[2 * j + 1]) + p2) + p3);
+                qpart[2 * j] = 0.0;
+                qpart[2 * j + 1] = 0.0;
+            }
+        }
+        land_chunk(par ^ 1);
+        phase_barrier();
+        inst = n1i; ch = n1c;
+        par ^= 1;
+    }
+}
+
 template <bool FAST>
 __device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &sh, int lt, int n, int nchunk) {
     const int lane = lt & 63, lw = lt >> 6;
@@ -228,7 +368,8 @@ __device__ __forceinline__ void loader_waves(const SmallArgs &p, const Shared &s
             for (int q = 0; q < NPL; ++q) {
                 const double *src = A + (int64_t)(cc0 + 8 * q) * p.lda + row;
                 f64x2 &dst = R[S][q];
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
+                if (PMT_BS_NT & 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(src) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(src) : "memory");
             }
             // every thread reads c of row lt & 31 (no branch); without a b (sign 0) the read goes to A and signed_const(., 0) = 0
             const double *src = csrc + inst * cstride + (int64_t)ch * CK + (lt & (CK - 1));
@@ -385,7 +526,10 @@ __device__ __forceinline__ void storer_waves(const SmallArgs &p, const Shared &s
             v[k] = *reinterpret_cast<const f64x2 *>(sh.stage + cp_head + pos[k]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<f64x2 *>(cp_out + pos[k]) = v[k];
+        for (int k = 0; k < 4; ++k) {
+            if (PMT_BS_NT & 2) __builtin_nontemporal_store(v[k], reinterpret_cast<f64x2 *>(cp_out + pos[k]));
+            else *reinterpret_cast<f64x2 *>(cp_out + pos[k]) = v[k];
+        }
         cp_u += 4;
     };
     auto copy_begin = [&](int64_t inst) {
@@ -478,8 +622,9 @@ __device__ __forceinline__ void storer_waves(const SmallArgs &p, const Shared &s
 }  // namespace
 
 // FAST: cols == 128, rows a multiple of 32, 16-byte aligned columns — aligned 16-byte loads without bounds checks.
-template <bool FAST>
+template <bool FAST, bool GL = false>
 __global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
+    static_assert(!GL || FAST, "the LDS-DMA panels serve the FAST shapes only");
     __shared__ __attribute__((aligned(16))) double panel[2 * PANEL];
     __shared__ __attribute__((aligned(16))) double stage[STAGE_CAP + 2];
     __shared__ __attribute__((aligned(16))) double cvec[2 * CK];
@@ -488,11 +633,11 @@ __global__ __launch_bounds__(NT, 2) void batch_small_kernel(SmallArgs p) {
     const int nchunk = (int)max((int64_t)1, (p.rows + CK - 1) / CK);
     Shared sh{panel, stage, cvec};
     // every wave executes the same number of barriers: one to start, one per phase, one more in the last phase of every instance
-    if (wave == 0) matrix_wave<0, FAST>(p, sh, tid & 63, n, nchunk);
-    else if (wave == 1) matrix_wave<1, FAST>(p, sh, tid & 63, n, nchunk);
-    else if (wave == 2) matrix_wave<2, FAST>(p, sh, tid & 63, n, nchunk);
-    else if (wave == 3) matrix_wave<3, FAST>(p, sh, tid & 63, n, nchunk);
-    else if (wave < 6) loader_waves<FAST>(p, sh, tid - NH, n, nchunk);
+    if (wave == 0) matrix_wave<0, FAST, GL>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 1) matrix_wave<1, FAST, GL>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 2) matrix_wave<2, FAST, GL>(p, sh, tid & 63, n, nchunk);
+    else if (wave == 3) matrix_wave<3, FAST, GL>(p, sh, tid & 63, n, nchunk);
+    else if (wave < 6) { if (GL) loader_waves_glds(p, sh, tid - NH, n, nchunk); else loader_waves<FAST>(p, sh, tid - NH, n, nchunk); }
     else storer_waves(p, sh, tid - NH - NL, n, nchunk);
 }
 
@@ -520,7 +665,7 @@ int launch_batch_small(const double *A, int64_t lda, int64_t rows, int64_t cols,
     const bool fast = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (strideA & 1) == 0 && cols == SN && rows > 0 && (rows % CK) == 0;
     // one workgroup per CU (LDS-limited), each walks instances blockIdx.x, blockIdx.x + G, ...
     const dim3 grid((unsigned)std::min<int64_t>(B, cu_count()));
-    if (fast) PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<true>, grid, dim3(NT), 0, s, p);
+    if (fast) PMT_LAUNCH_NAMED("batch_small_kernel", (batch_small_kernel<true, PMT_BS_GLDS != 0>), grid, dim3(NT), 0, s, p);
     else PMT_LAUNCH_NAMED("batch_small_kernel", batch_small_kernel<false>, grid, dim3(NT), 0, s, p);
     return check_launch("batch_small_kernel");
 }
