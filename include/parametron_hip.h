@@ -549,6 +549,11 @@ int pmt_plan_end_record(pmt_plan *plan);
  * recording — for an entry that needs nothing of this re-evaluation, e.g. the recorded fetch of a dense constraint block's CSC values
  * straight out of its Parameter buffer (pmt_plan_record_fetch_2d): PCIe is busy from the first microseconds of the solve. */
 int pmt_plan_set_lane(pmt_plan *plan, int lane);
+/* The HIP stream the entries of a lane are replayed on (0: pmt_plan_stream; 1, 2: the side stream).  A device-side Parameter callback whose
+ * value only side-lane entries read may run THERE (in front of pmt_plan_update): a transfer at the front of the side lane then does not
+ * wait for the callbacks of the objective's Parameters on the plan's stream.  Work issued on it is ordered before the side-lane entries
+ * of the next update and joined into the plan's stream at that update's end. */
+int pmt_plan_lane_stream(pmt_plan *plan, int lane, void **out_stream);
 void *pmt_plan_recording_stream(pmt_plan *plan);
 int64_t pmt_plan_tape_length(const pmt_plan *plan);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls

@@ -144,6 +144,7 @@ SIGNATURES = {
     "pmt_plan_end_record": (_ci, [_vp]),
     "pmt_plan_commit_lane": (_ci, [_vp, _ci]),
     "pmt_plan_set_lane": (_ci, [_vp, _ci]),
+    "pmt_plan_lane_stream": (_ci, [_vp, _ci, C.POINTER(_vp)]),
     "pmt_plan_recording_stream": (_vp, [_vp]),
     "pmt_plan_tape_length": (_i64, [_vp]),
     "pmt_plan_update": (_ci, [_vp]),

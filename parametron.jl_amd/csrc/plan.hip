@@ -635,6 +635,17 @@ extern "C" int pmt_plan_set_lane(pmt_plan *plan, int lane) {
     return PMT_OK;
 }
 
+// the HIP stream a lane's entries are replayed on: 0 the plan's stream, 1 / 2 its side stream (created on first use)
+extern "C" int pmt_plan_lane_stream(pmt_plan *plan, int lane, void **out_stream) {
+    PMT_REQUIRE(plan && out_stream, PMT_INVALID_ARGUMENT, "plan_lane_stream: null pointer");
+    PMT_REQUIRE(lane >= 0 && lane <= 2, PMT_INVALID_ARGUMENT, "plan_lane_stream: lane must be 0, 1 or 2");
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    hipStream_t s = lane == 0 ? plan->stream : pmt::side_stream_of(plan->stream);
+    PMT_REQUIRE(s || lane == 0, PMT_STATE_ERROR, "plan_lane_stream: the plan's stream has no side stream");
+    *out_stream = s;
+    return PMT_OK;
+}
+
 extern "C" int pmt_plan_update(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_update: null plan");
     PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan is still recording");

@@ -408,10 +408,11 @@ extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colp
     if (nnz == 0 || nnz >= ((int64_t)1 << 32)) return PMT_OK;           // nothing to do / positions do not fit the 32-bit descriptors
     PMT_REQUIRE(rowval, PMT_INVALID_ARGUMENT, "sparse_blocks_width: null pointer");
     const int64_t nrb = cdiv(m, SB_RB);
-    // The block form pays when a row's part of a column band is a run worth writing: >= 16 terms on average, i.e. nnz >= 16 * m * (number
-    // of bands).  Checked with the widest band BEFORE anything is sized by m * n: a hypersparse pattern (1e6 x 1e6 with a few entries per
-    // column) must not allocate its (row block, strip) table — about 1 GB there — only to be turned down; it keeps the slab form (cw = 0).
-    if (nnz < 16 * m * cdiv(n, SB_MAXCW)) {
+    // The block form pays when a row's part of a column band is a run worth writing (>= 16 terms on average: the hosts' gate).  For a LARGE
+    // table that necessary condition is checked with the widest band BEFORE anything is sized by m * n: a hypersparse pattern (1e6 x 1e6 with
+    // a few entries per column) must not allocate its (row block, strip) table — about 1 GB there — only to be turned down; it keeps the
+    // slab form (cw = 0).  Small tables are simply built: the width is a property of the pattern, the gate is the caller's.
+    if (nrb * cdiv(n, 32) > ((int64_t)1 << 22) && nnz < 16 * m * cdiv(n, SB_MAXCW)) {
         for (int64_t p = 0; p < nnz; ++p)
             if (rowval[p] < 1 || rowval[p] > m) return fail(PMT_DIMENSION_MISMATCH, "sparse_blocks_width: row index out of range");
         return PMT_OK;
@@ -440,10 +441,7 @@ extern "C" int pmt_sparse_blocks_width(int64_t m, int64_t n, const int64_t *colp
                 for (int64_t k = s0; k < std::min(nstrip, s0 + per); ++k) tot += cnt[(size_t)(rb * nstrip + k)];
                 worst = std::max(worst, tot);
             }
-        if (worst <= SB_CAP) {
-            if (nnz >= 16 * m * cdiv(n, cw)) *out_cw = cw;               // (the same gate with the band width that fits)
-            return PMT_OK;
-        }
+        if (worst <= SB_CAP) { *out_cw = cw; return PMT_OK; }
     }
     return PMT_OK;
 } catch (const std::bad_alloc &) {

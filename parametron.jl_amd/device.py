@@ -157,6 +157,17 @@ class DeviceContext:
     def call(self, name, *args):
         _lib.call(name, *args, self.launch_stream())
 
+    def call_on_lane(self, lane, name, *args):
+        """an immediate call on the stream a lane's entries are replayed on (pmt_plan_lane_stream): device-side Parameter callbacks of values
+        only side-lane entries read"""
+        if not hasattr(self, "_lane_streams"):
+            self._lane_streams = {}
+        if lane not in self._lane_streams:
+            st = C.c_void_p()
+            _lib.call("pmt_plan_lane_stream", self.plan, int(lane), C.byref(st))
+            self._lane_streams[lane] = st
+        _lib.call(name, *args, self._lane_streams[lane])
+
     def call_now(self, name, *args):
         """setup-time call on the plan's stream even while recording (e.g. the one-off device ordering of canonicalize!)"""
         _lib.call(name, *args, self.stream)

@@ -147,13 +147,17 @@ def device_value_of(x, ctx=None):
                 x._dev = _alloc_like(ctx, val)
         if x._dev_version != x.version:
             if getattr(x, "device_resident", False):
+                # a value only side-lane records read is regenerated on the side stream (inside update! only: there the replay joins the
+                # side stream back): a transfer at the front of the side lane does not wait for the objective's callbacks on the plan's stream
+                side = getattr(x, "_commit_on_side_lane", False) and getattr(ctx, "_refreshing", False) and not ctx.recording
+                call = (lambda *a: ctx.call_on_lane(1, *a)) if side else ctx.call
                 if isinstance(x._dev, DSpMat):
-                    ctx.call("pmt_fill_uniform_f64", P(x._dev.buf), int(x._dev.nnz), C.c_uint64(x.current_seed()), x.scale)
+                    call("pmt_fill_uniform_f64", P(x._dev.buf), int(x._dev.nnz), C.c_uint64(x.current_seed()), x.scale)
                 elif isinstance(x._dev, DMat):
-                    ctx.call("pmt_fill_uniform_matrix_f64", P(x._dev.buf), x._dev.rows, x._dev.cols, x._dev.lda,
-                             C.c_uint64(x.current_seed()), x.scale)
+                    call("pmt_fill_uniform_matrix_f64", P(x._dev.buf), x._dev.rows, x._dev.cols, x._dev.lda,
+                         C.c_uint64(x.current_seed()), x.scale)
                 else:
-                    ctx.call("pmt_fill_uniform_f64", P(x._dev.buf), int(x.shape[0]), C.c_uint64(x.current_seed()), x.scale)
+                    call("pmt_fill_uniform_f64", P(x._dev.buf), int(x.shape[0]), C.c_uint64(x.current_seed()), x.scale)
             else:
                 _upload_value(ctx, x._dev, val)
             x._dev_version = x.version

@@ -387,9 +387,13 @@ class Model:
         ctx._staging_dirty = False
         if ctx._stage_slot != ctx._pending_slot:
             ctx.set_stage_slot(ctx._pending_slot)   # wait / commit / consumed act on the slot the pending values were staged into
-        for x in self._order:
-            if isinstance(x, Parameter):
-                device_value_of(x, ctx)
+        ctx._refreshing = True
+        try:
+            for x in self._order:
+                if isinstance(x, Parameter):
+                    device_value_of(x, ctx)
+        finally:
+            ctx._refreshing = False
         if ctx._staging_dirty:
             ctx.staging_consumed()               # behind the commits: the staging buffers may be overwritten by the next stage_parameters()
             ctx._staging_dirty = False

@@ -88,3 +88,17 @@ def test_block_form_is_declined_where_it_does_not_apply():
         colptr = np.array([1, 2, 3], dtype=np.int64)
         rowval = np.array([1, 9], dtype=np.int64)
         _lib.call("pmt_sparse_blocks_width", 2, 2, vp(colptr), vp(rowval), C.byref(cw))
+
+
+def test_hypersparse_pattern_is_declined_before_its_table_is_sized():
+    """a 3e6 x 3e6 pattern with two entries per column: the (row block, 32-column strip) table alone would be ~2.2e9 counters (9 GB); the width
+    function must answer 0 (slab form) without allocating it — and without throwing across the C boundary"""
+    n = 3_000_000
+    colptr = np.arange(1, 2 * n + 2, 2, dtype=np.int64)
+    rowval = np.empty(2 * n, dtype=np.int64)
+    rowval[0::2] = np.arange(1, n + 1)
+    rowval[1::2] = np.minimum(np.arange(1, n + 1) + 7, n)
+    rowval[-1] = n; rowval[-2] = n - 1
+    cw = C.c_int(7)
+    _lib.call("pmt_sparse_blocks_width", n, n, vp(colptr), vp(rowval), C.byref(cw))
+    assert cw.value == 0
