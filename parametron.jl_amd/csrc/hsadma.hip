@@ -61,6 +61,9 @@ static bool g_tried = false;
 static void *g_lib = nullptr;
 static Api g_api;
 static std::vector<Engine *> g_engines;        // per HIP device (null: no match)
+static std::vector<int> g_failed;              // devices whose engine did not pass its self-test
+__global__ void signal_store_kernel(int64_t *value);
+static bool self_test(Engine *e, int device);
 
 static int find_hsa(struct dl_phdr_info *info, size_t, void *data) {
     if (info->dlpi_name && strstr(info->dlpi_name, "libhsa-runtime64")) {
@@ -118,6 +121,7 @@ static Engine *engine_of(int device) {
     std::lock_guard<std::mutex> lock(g_mu);
     if (!load_api()) return nullptr;
     if (device < 0) return nullptr;
+    for (int d : g_failed) if (d == device) return nullptr;          // matched before and failed its self-test
     if ((size_t)device < g_engines.size() && g_engines[(size_t)device]) return g_engines[(size_t)device];
     AgentList l;
     l.api = &g_api;
@@ -160,8 +164,12 @@ static Engine *engine_of(int device) {
             if (n < 2) e->queue_engine[0] = e->queue_engine[1] = 0;
         }
     }
+    // The delivery rests on two things the HSA API does not promise: a signal's value word may be written by a KERNEL, and the copy engine
+    // notices that write.  Checked here, once per device, with a real transfer: if it does not behave, there is no engine (kernel copies).
+    if (!self_test(e, device)) { delete e; e = nullptr; }
     if (g_engines.size() <= (size_t)device) g_engines.resize((size_t)device + 1, nullptr);
     g_engines[(size_t)device] = e;
+    if (!e) g_failed.push_back(device);
     return e;
 }
 
@@ -265,6 +273,46 @@ int wait(Engine *e, Signal completion, double timeout_s) {
 // one thread: the producers enqueued before this launch on `s` are done -> the copy that depends on `value` may start
 __global__ void signal_store_kernel(int64_t *value) {
     __hip_atomic_store(value, (int64_t)0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One 64-byte transfer gated the way every delivery is: submitted with a dependency signal at 1, it must NOT have run after a millisecond; a
+// one-thread kernel then stores 0 into the signal's value word and the data must arrive.  false: the engine is not used on this device.
+static bool self_test(Engine *e, int device) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    unsigned long long *dsrc = nullptr, *hdst = nullptr;
+    hipStream_t st = nullptr;
+    Signal dep, done;
+    bool ok = hipMalloc(reinterpret_cast<void **>(&dsrc), 64) == hipSuccess && hipHostMalloc(reinterpret_cast<void **>(&hdst), 64, hipHostMallocDefault) == hipSuccess &&
+              hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    bool sig = false;
+    if (ok) {
+        const unsigned long long pattern[8] = {0x70617261ull, 0x6d657472ull, 0x6f6eull, 4, 5, 6, 7, 0x5e1f7e57ull};
+        for (int i = 0; i < 8; ++i) hdst[i] = 0;
+        ok = hipMemcpy(dsrc, pattern, 64, hipMemcpyHostToDevice) == hipSuccess;
+        sig = ok && signal_create(e, 1, &dep) == PMT_OK && signal_create(e, 1, &done) == PMT_OK;
+        ok = sig && copy_to_host(e, hdst, dsrc, 64, &dep, done) == PMT_OK;
+        if (ok) {
+            timespec nap{0, 1000000};
+            nanosleep(&nap, nullptr);
+            ok = __atomic_load_n(done.value, __ATOMIC_ACQUIRE) == 1 && hdst[7] == 0;      // held back by its dependency
+            hipLaunchKernelGGL(signal_store_kernel, dim3(1), dim3(1), 0, st, dep.value);
+            const bool launched = hipGetLastError() == hipSuccess;
+            // (wait for the transfer in any case: the signals and buffers must not go away under it)
+            const bool landed = launched && wait(e, done, 0.5) == PMT_OK;
+            if (!launched) signal_set(e, dep, 0), (void)wait(e, done, 0.5);
+            ok = ok && landed;
+            for (int i = 0; ok && i < 8; ++i) ok = hdst[i] == pattern[i];
+        }
+    }
+    if (sig) { signal_destroy(e, dep); signal_destroy(e, done); }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (dsrc) (void)hipFree(dsrc);
+    if (hdst) (void)hipHostFree(hdst);
+    (void)hipGetLastError();
+    (void)hipSetDevice(prev);
+    return ok;
 }
 
 int launch_signal_store(Signal s, hipStream_t stream) {
