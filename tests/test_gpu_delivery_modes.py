@@ -194,3 +194,42 @@ def test_pair_fold_timeout_surfaces_from_solve(delivery):
     P.solve(model)
     H.assert_host_equals_device(model)
     model.close()
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_back_to_back_immediate_deliveries_do_not_overtake_each_other(delivery, mode):
+    """two unrecorded pmt_quad_gram_csc_deliver_f64 calls on one stream with no synchronisation in between, different inputs, the same device
+    and host arrays: the second call waits by itself until the first delivery has read out_P_values (the header's promise — on the copy-engine
+    path the signals of an immediate call are fresh, so it must wait for what earlier calls handed to the engine); afterwards the host array
+    holds the SECOND result, bit for bit the device array"""
+    delivery(mode)
+    L = lib()
+    s = stream()
+    rows, cols = 2048, 1408
+    nnz = cols * (cols + 1) // 2
+    A1 = torch.empty(rows * cols, dtype=torch.float64, device=DEV)
+    A2 = torch.empty(rows * cols, dtype=torch.float64, device=DEV)
+    b = torch.empty(rows, dtype=torch.float64, device=DEV)
+    _lib.call("pmt_fill_uniform_f64", ptr(A1), rows * cols, 31, 1.0, s)
+    _lib.call("pmt_fill_uniform_f64", ptr(A2), rows * cols, 32, 3.0, s)
+    _lib.call("pmt_fill_uniform_f64", ptr(b), rows, 33, 1.0, s)
+    xvar = torch.arange(1, cols + 1, dtype=torch.int64, device=DEV)
+    ws = torch.empty(max(1, L.pmt_quad_gram_workspace_bytes(rows, cols) // 8), dtype=torch.float64, device=DEV)
+    Pv, lin, c = empty_f64(nnz), torch.empty(2 * cols, dtype=torch.int64, device=DEV), empty_f64(1)
+    ref = empty_f64(nnz)
+    _lib.call("pmt_quad_gram_csc_f64", ptr(A2), rows, rows, cols, ptr(xvar), ptr(b), -1, None, 1.0, ptr(ref), None, ptr(lin), ptr(c), ptr(ws), s)
+    torch.cuda.synchronize()
+    want = ref.cpu().numpy()
+    hp = C.c_void_p()
+    _lib.call("pmt_host_alloc", 8 * nnz, C.byref(hp))
+    host = np.frombuffer((C.c_char * (8 * nnz)).from_address(hp.value), dtype=np.float64)
+    for rep in range(3):
+        host[:] = -1.0
+        for A in (A1, A2):
+            _lib.call("pmt_quad_gram_csc_deliver_f64", ptr(A), rows, rows, cols, ptr(xvar), ptr(b), -1, None, 1.0, ptr(Pv), hp, 0, ptr(lin), ptr(c), ptr(ws), s)
+        _lib.call("pmt_fetch_synchronize", s)
+        torch.cuda.synchronize()
+        dev = Pv.cpu().numpy()
+        assert np.array_equal(host, dev)
+        np.testing.assert_allclose(host, want, rtol=1e-13, atol=0)          # (staged: split tiles are two half sums)
+    _lib.call("pmt_host_free", hp)
