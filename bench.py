@@ -465,8 +465,11 @@ def host_api_c2(torch, P, steps):
         c3_solve()
     dt = (time.perf_counter() - t0) / k
     model.wait_staged()
-    out["c3_host_csc"] = {"ms_per_solve": dt * 1e3, "solves_per_s": 1.0 / dt, "bytes_to_host": model.device_qp.host.nbytes(),
-                          "what": "config 3 (inequalities + bounds) with host-updated val= Parameters (17 MB staged up) and the host_csc delivery (84 MB down)"}
+    host = model.device_qp.host
+    out["c3_host_csc"] = {"ms_per_solve": dt * 1e3, "solves_per_s": 1.0 / dt, "bytes_to_host": host.bytes_over_pcie(),
+                          "bytes_copied_on_host": host.nbytes() - host.bytes_over_pcie(),
+                          "what": "config 3 (inequalities + bounds) with host-updated val= Parameters (17 MB staged up) and the host_csc delivery: P, q, l, u "
+                                  "(67 MB) down; A's dense block is G itself, which the host wrote: copied on the host (pmt_host_copy_2d), not shipped back"}
     model.close()
     return out
 

@@ -246,6 +246,11 @@ the CSC values of a dense constraint block leave straight out of its Parameter b
 record_fetch_matrix!(plan::Plan, dst::Ptr{Float64}, dst_pitch_bytes, src::DevPtr, lds, rows, cols) =
     check(ccall((:pmt_plan_record_fetch_2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, DevPtr, Csize_t, Csize_t, Csize_t),
                 plan.handle, dst, dst_pitch_bytes, src, 8 * lds, 8 * rows, cols))
+"host -> host: `cols` columns of `rows` doubles, `src_pitch_bytes` apart in the source, `dst_pitch_bytes` apart in the destination, on the library's
+worker threads (pmt_host_copy_2d) — the dense blocks of a host solver's A whose Parameter values are already on the host"
+host_copy_matrix!(dst::Ptr{Float64}, dst_pitch_bytes, src::Ptr{Float64}, src_pitch_bytes, rows, cols; threads::Integer = 0) =
+    check(ccall((:pmt_host_copy_2d, lib), Cint, (Ptr{Cvoid}, Csize_t, Ptr{Cvoid}, Csize_t, Csize_t, Csize_t, Cint),
+                dst, dst_pitch_bytes, src, src_pitch_bytes, 8 * rows, cols, threads))
 "how results leave for the host: 0 automatic, 1 copy engine or an error, 2 kernel copies (include/parametron_hip.h)"
 set_host_delivery(mode::Integer) = check(ccall((:pmt_set_host_delivery, lib), Cint, (Cint,), mode))
 "(mode, copy engine usable on `device`)"

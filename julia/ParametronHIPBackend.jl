@@ -289,7 +289,7 @@ struct HIPConstraint
     constants::DevPtr      # Float64[rows]
     nterms::Int
     rows::Int
-    dense::Union{Nothing, Tuple{DevPtr, Int, Int, Int}}     # (C buffer, lda, rows, cols) when the function is ONE unscaled dense block
+    dense::Union{Nothing, Tuple{DevPtr, Int, Int, Int, Vector{Float64}}}     # (C buffer, lda, rows, cols, the Parameter's page-locked host copy) when the function is ONE unscaled dense block
 end
 
 "what a host solver's update takes, in page-locked arrays the device fills (handoff = :host_csc)"
@@ -486,7 +486,7 @@ function record_constraint!(hm::HIPModel, constraint, rec)
     dense = nothing
     if length(pieces) == 1 && pieces[1] isa DenseAffine && !pieces[1].transposed
         d = device_param!(hm, pieces[1].A)
-        dense = (d.buf, d.ld, d.rows, d.cols)
+        dense = (d.buf, d.ld, d.rows, d.cols, d.host)
     end
     HIPConstraint(constraint, terms, constants, nterms, rows, dense)
 end
@@ -525,26 +525,33 @@ function record_host_handoff!(hm::HIPModel, rec)
         row0 += c.rows
     end
     H.record_fetch!(hm.plan, h.small, h.small_dev)
-    # A's values: recorded pitched fetches straight out of the Parameter buffers, at the FRONT of the side lane (lane 2): they need nothing of the
-    # re-evaluation, so the copy engine starts on them in the first microseconds of the solve (pmt_plan_record_fetch_2d, pmt_plan_set_lane)
-    H.set_lane!(hm.plan, 2)
-    row0 = 0
-    for c in hm.constraints
-        buf, lda, r, ncol = c.dense
-        H.record_fetch_matrix!(hm.plan, pointer(h.Ax) + 8 * row0, 8 * m, buf, lda, r, ncol)
-        row0 += r
-    end
-    H.set_lane!(hm.plan, 0)
+    # A's values are NOT fetched: every Parameter of this host is evaluated on the host (refresh! leaves its value in the page-locked staging
+    # array d.host), so a dense block's CSC values are already here — copy_A! copies them on the host while the device works.  (A host whose
+    # Parameter values live on the device records pitched fetches out of the Parameter buffers instead: pmt_plan_record_fetch_2d at the front
+    # of the side lane, ParametronHIP.record_fetch_matrix!; the Python host of this repository does both.)
     nothing
 end
 
-"A's values behind the re-evaluation instead (the serial form of the recorded fetches above; kept for hosts that do not record them): one pitched copy per
-dense block straight out of its Parameter buffer (column j of A = the blocks' columns j, stacked)"
+"A's values: one host-side pitched copy per dense block, from the Parameter's page-locked host copy into the block's row range of every column
+(column j of A = the blocks' columns j, stacked) on a few worker threads — pmt_host_copy_2d — while the device re-evaluates the objective"
+function copy_A!(hm::HIPModel)
+    h = hm.host
+    row0 = 0
+    for c in hm.constraints
+        buf, lda, r, n, src = c.dense
+        H.host_copy_matrix!(pointer(h.Ax) + 8 * row0, 8 * h.m, pointer(src), 8 * r, r, n)
+        row0 += r
+    end
+    nothing
+end
+
+"A's values out of the DEVICE copies instead, behind the re-evaluation (kept for hosts whose Parameter values are not on the host): one pitched copy per
+dense block straight out of its Parameter buffer"
 function fetch_A!(hm::HIPModel)
     h = hm.host
     row0 = 0
     for c in hm.constraints
-        buf, lda, r, n = c.dense
+        buf, lda, r, n, _ = c.dense
         H.fetch_matrix!(hm.plan, pointer(h.Ax) + 8 * row0, 8 * h.m, buf, lda, r, n)
         row0 += r
     end
@@ -651,7 +658,8 @@ function Parametron.update!(hm::HIPModel)
     H.update!(hm.plan)                                               # every device node of the model (+ the recorded fetches / the delivery of P)
     if hm.handoff === :host_csc
         h = hm.host
-        H.fetch_synchronize(hm.plan)                                 # A's blocks (recorded pitched fetches), q | l | u and P's band groups have landed
+        copy_A!(hm)                                                  # A's blocks: host -> host, while the device works (no allocation: worker threads of the library)
+        H.fetch_synchronize(hm.plan)                                 # q | l | u and P's band groups have landed
         H.synchronize(hm.plan)
         hm.solver_update === nothing || hm.solver_update(h.Px, h.Ax, q_of(h), l_of(h), u_of(h))
         return nothing

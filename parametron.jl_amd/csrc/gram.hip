@@ -574,6 +574,8 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             use_engine = mode != 2 && sig->eng != nullptr;
             PMT_REQUIRE(mode != 1 || use_engine, PMT_STATE_ERROR, "host delivery: the copy engine was demanded (pmt_set_host_delivery(1)) but is not available");
             if (use_engine) {
+                // (a previous delivery that went through the courier — the mode was switched in between — is ordered by its event)
+                if (side->fetch_pending) { PMT_HIP_CHECK(hipStreamWaitEvent(s, side->fetch_done, 0)); side->fetch_pending = false; }
                 for (int i = 0; i < dplan.ngroups; ++i) dma::signal_set(sig->eng, sig->dep[i], 1);
                 dma::signal_set(sig->eng, sig->done, dplan.ngroups);
             } else {

@@ -41,19 +41,26 @@ def _csc_order(rows, cols, nrows, ncols, upper):
 class _Block:
     """One source of matrix entries: a device term buffer (or host values for constant functions) and where its runs go."""
 
-    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None, source_perm=None, dense=None):
+    def __init__(self, rows, cols, coeff_ptr=None, stride=0, host_coeff=None, source_perm=None, dense=None, param=None):
         self.rows, self.cols, self.coeff_ptr, self.stride, self.host_coeff = rows, cols, coeff_ptr, stride, host_coeff
         self.source_perm = source_perm            # entry i's coefficient sits at coeff_ptr + source_perm[i] * stride (None: i * stride)
         self.dense = dense                        # DMat of a dense block A*x (+|-) b whose terms are row-major (row*cols + col): its values ARE the matrix
+        self.param = param                        # ... and the Parameter it mirrors
 
 
 class _Rect:
     """A dense block inside a solver matrix's CSC values: column j of the Parameter matrix (rows doubles at mat + j*lda) sits at
     values[first + j*pitch ...] — a pitched copy, no term is read."""
 
-    def __init__(self, first, pitch, mat, offsets=None):
+    def __init__(self, first, pitch, mat, offsets=None, param=None):
         self.first, self.pitch, self.mat = int(first), int(pitch), mat
         self.offsets = offsets              # per-column positions when they are not a constant pitch apart (then pitch is 0)
+        self.param = param
+
+    def host_resident(self):
+        """the block's Parameter is updated by the HOST (val= buffer or callback, src/parameter.jl:88,101-102): its values are already
+        there and need not come back from the device"""
+        return self.param is not None and not getattr(self.param, "device_resident", False) and self.offsets is None
 
 
 class CSC:
@@ -63,6 +70,16 @@ class CSC:
         self.nnz = len(row_idx)
         self.rects = list(rects)            # dense blocks that are pitched copies of Parameter matrices
         self.only_rects = only_rects        # every value that changes per re-evaluation belongs to one of them (the rest is static)
+
+
+def _parameter_of(expr, dmat):
+    """the Parameter whose device mirror `dmat` is, among the arguments of the record's expression"""
+    from .lazyexpression import schedule
+    from .parameter import Parameter
+    for x in schedule([expr]):
+        if isinstance(x, Parameter) and getattr(x, "_dev", None) is dmat:
+            return x
+    return None
 
 
 class _Transfer:
@@ -117,7 +134,9 @@ class HostQP:
         qp = self._qp
         if qp.A.only_rects:
             # A's static entries (bounds rows: 1.0) were fetched once at set-up; per solve only the dense blocks travel
-            early = [_Transfer(self.Ax.ctypes.data + 8 * r.first, r.mat.buf, 8 * r.mat.rows, 8 * r.pitch, 8 * r.mat.lda, r.mat.cols) for r in qp.A.rects]
+            # (blocks of host-updated Parameters do not travel at all: host_copies())
+            early = [_Transfer(self.Ax.ctypes.data + 8 * r.first, r.mat.buf, 8 * r.mat.rows, 8 * r.pitch, 8 * r.mat.lda, r.mat.cols)
+                     for r in qp.A.rects if not r.host_resident()]
         else:
             early = [_Transfer(self.Ax.ctypes.data, qp.A.values_ptr, self.Ax.nbytes)]
         early.append(_Transfer(self._small.ctypes.data, qp._small_ptr, 8 * qp._small_len))
@@ -128,6 +147,32 @@ class HostQP:
             tail.append(_Transfer(self.Px.ctypes.data, qp.P.values_ptr, self.Px.nbytes))
         t = early + tail if late is None else (tail if late else early)
         return [x for x in t if x.nbytes]
+
+    def host_copies(self):
+        """The dense blocks of A whose Parameter the HOST updates: copied on the host, from the Parameter's buffer into the block's row range
+        of every column of Ax (pmt_host_copy_2d, a few worker threads), while the device re-evaluates the rest — they do not cross PCIe a
+        second time.  Called by Model.update() once the re-evaluation has been enqueued."""
+        qp = self._qp
+        if not qp.A.only_rects:
+            return
+        for r in qp.A.rects:
+            if not r.host_resident():
+                continue
+            val = r.param()                               # this solve's value (evaluated when the Parameters were refreshed)
+            m, n = r.mat.rows, r.mat.cols
+            dst = self.Ax.ctypes.data + 8 * r.first
+            if isinstance(val, np.ndarray) and val.dtype == np.float64 and val.shape == (m, n) and (m == 1 or val.strides[0] == 8) and \
+                    (n == 1 or val.strides[1] >= 8 * m):
+                _lib.call("pmt_host_copy_2d", C.c_void_p(dst), 8 * r.pitch, C.c_void_p(val.ctypes.data), int(val.strides[1]) if n > 1 else 8 * m, 8 * m, n, 0)
+            else:                                         # row-major / other layouts: numpy's strided copy (slow; column-major buffers avoid it)
+                view = np.lib.stride_tricks.as_strided(self.Ax[r.first:], shape=(n, m), strides=(8 * r.pitch, 8))
+                view[...] = np.asarray(val, dtype=np.float64).T
+
+    def bytes_over_pcie(self):
+        """what crosses PCIe per solve: everything except the blocks the host copies itself"""
+        qp = self._qp
+        kept = sum(8 * r.mat.rows * r.mat.cols for r in qp.A.rects if r.host_resident()) if qp.A.only_rects else 0
+        return self.nbytes() - kept
 
     def nbytes(self):
         return self.Px.nbytes + self.q.nbytes + self.Ax.nbytes + self.l.nbytes + self.u.nbytes + 8
@@ -231,7 +276,8 @@ class DeviceQP:
                     if isinstance(out, DDenseAff) and not out.need_terms:
                         # a dense block's coefficients are the Parameter matrix itself (terms row-major: row*cols + col)
                         # (host_csc: the record packs no terms at all — moi._Record.compile — and the structure in c.f.terms is static)
-                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8 if "terms" in c.dev else None, 24, dense=out.mat))
+                        ablocks.append(_Block(t["out"] + row0, t["var"].copy(), c.dev["terms"] + 8 if "terms" in c.dev else None, 24, dense=out.mat,
+                                              param=_parameter_of(c.expr, out.mat)))
                     elif isinstance(out, DVarsAff) and not out.need_terms:
                         # x (+|-) v: the coefficient of every row is the 1.0 of copyto!(f, ::Variable) (src/functions.jl:421) — static
                         ablocks.append(_Block(t["out"] + row0, t["var"].copy(), host_coeff=t["coeff"].copy()))
@@ -336,6 +382,8 @@ class DeviceQP:
             dst = np.ascontiguousarray(inverse[pos:pos + k], dtype=np.int64)
             pos += k
             rect = self._dense_rect(b, perm, seg, dst, alpha) if k else None
+            if rect is not None:
+                rect.param = b.param
             if b.host_coeff is not None:
                 sums = np.add.reduceat(b.host_coeff[perm], seg[:-1]) if k else np.zeros(0)
                 static[dst] = alpha * sums

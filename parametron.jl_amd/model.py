@@ -425,6 +425,8 @@ class Model:
             if self._records:
                 self._run_tape(fetch=False)
             self.device_qp.refresh()
+            if self.device_qp.host is not None:
+                self.device_qp.host.host_copies()                      # blocks the host already has: copied here while the device works
             if synchronize:                                            # synchronize=False: the caller overlaps the next stage_parameters()
                 if self.device_qp.host is not None:                    # with this re-evaluation and synchronises later
                     self.device_qp.host.wait()                         # host_csc: the solver's arrays have landed

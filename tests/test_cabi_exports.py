@@ -184,7 +184,7 @@ def test_julia_update_path_has_no_allocating_constructors():
     here, so its per-solve functions are scanned for constructs that allocate: array constructors, comprehensions, copies, conversions.
     (Setup functions — HIPModel, record_*, DeviceParameter — may allocate: they run once.)"""
     src = open(os.path.join(ROOT, "julia", "ParametronHIPBackend.jl")).read()
-    per_solve = [r"function refresh!\(", r"function commit!\(", r"function fetch_A!\(", r"function Parametron\.update!\(o::HIPObjective",
+    per_solve = [r"function refresh!\(", r"function commit!\(", r"function fetch_A!\(", r"function copy_A!\(", r"function Parametron\.update!\(o::HIPObjective",
                  r"function Parametron\.update!\(c::HIPConstraint", r"function Parametron\.update!\(hm::HIPModel\)", r"function solve!\(hm::HIPModel\)"]
     banned = [r"\bVector\{[^}]*\}\(", r"\bMatrix\{[^}]*\}\(", r"\bArray\{", r"\bzeros\(", r"\bones\(", r"\bcollect\(", r"\bcopy\(", r"\bsimilar\(",
               r"\b(?:Int64|Float64|Any)\[", r"\[[^\]\n]*\bfor\b[^\]\n]*\]", r"\bpush!\(", r"\bvcat\(", r"\bhcat\(", r"\bconvert\(", r"\bstring\("]

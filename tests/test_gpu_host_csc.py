@@ -441,3 +441,41 @@ def test_dense_blocks_leave_without_terms_or_gather(case):
             assert np.array_equal(Ad[:mi, off:], G.val) and np.array_equal(Ad[mi:, off:], S.val.toarray())
             assert np.array_equal(host["u"][:mi], h.val) and np.array_equal(host["u"][mi:], e.val)
     model.close()
+
+
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_host_updated_dense_block_is_copied_on_the_host_not_shipped_back(order):
+    """handoff="host_csc", a dense block whose Parameter the HOST updates (`Parameter(model, val=buf)`, src/parameter.jl:88): its values are
+    already on the host, so A's block is copied there (pmt_host_copy_2d; numpy's strided copy for a row-major buffer) while the device
+    re-evaluates the objective — only P, q, l, u cross PCIe.  The host arrays follow the buffer solve after solve, with and without staged
+    uploads, and equal the device hand-off (whose copy of the block comes from the uploaded device mirror)."""
+    n, r, mi = 160, 200, 48
+    rng = np.random.default_rng(5)
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", handoff="host_csc")
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model)
+    b = P.DeviceUniformParameter((r,), 2, model)
+    residual = A * x - b
+    P.objective(model, P.Minimize, P.dot(residual, residual))
+    Gbuf = model.parameter_array(mi, n) if order == "F" else np.zeros((mi, n), order="C")
+    G = P.Parameter(model, val=Gbuf)
+    h = P.Parameter(model, val=rng.random(mi))
+    Cd = P.DeviceUniformParameter((7, n), 3, model)                       # a device-resident block beside it: that one does travel
+    dd = P.DeviceUniformParameter((7,), 4, model)
+    P.constraint(model, G * x, "<=", h)
+    P.constraint(model, Cd * x, "<=", dd)
+    P.solve(model)
+    qp = model.device_qp
+    kinds = sorted(rr.host_resident() for rr in qp.A.rects)
+    assert kinds == [False, True]
+    assert qp.host.nbytes() - qp.host.bytes_over_pcie() == 8 * mi * n
+    import scipy.sparse as sp
+    for it in range(4):
+        Gbuf[...] = rng.random((mi, n)); h.val[...] = rng.random(mi)
+        if it == 2:
+            model.stage_parameters()
+        P.solve(model)
+        host = assert_host_equals_device(model)
+        Ad = sp.csc_matrix(host["A"], shape=(mi + 7, n)).toarray()
+        assert np.array_equal(Ad[:mi], Gbuf) and np.array_equal(Ad[mi:], Cd())
+    model.close()

@@ -40,3 +40,24 @@ def test_csc_order_empty_and_errors():
         _csc_order(np.array([0], dtype=np.int64), np.array([1], dtype=np.int64), 2, 2, False)    # indices are 1-based
     with pytest.raises(P.DimensionMismatch):
         _csc_order(np.array([1], dtype=np.int64), np.array([3], dtype=np.int64), 2, 2, False)
+
+
+def test_host_copy_2d_matches_numpy():
+    """pmt_host_copy_2d (host -> host, pitched, worker threads): the dense blocks of a host solver's A whose Parameter the host itself updates
+    are copied on the host instead of coming back over PCIe.  No device involved: checked here against numpy for every pitch combination,
+    thread counts from 1 to 64, sizes from one word to beyond the per-thread minimum."""
+    import ctypes as C
+    from parametron_jl_amd import _lib
+    rng = np.random.default_rng(3)
+    for (rows, cols, spad, dpad, top) in [(1, 1, 0, 0, 0), (512, 4096, 64, 8704 - 512, 4096), (40, 33, 8, 24, 7), (1000, 300, 0, 0, 0), (7, 5000, 1, 2, 1)]:
+        for threads in (0, 1, 3, 64):
+            src = rng.random((cols, rows + spad))
+            dst = np.full((cols, top + rows + dpad), -1.0)
+            want = dst.copy()
+            want[:, top:top + rows] = src[:, :rows]
+            _lib.call("pmt_host_copy_2d", C.c_void_p(dst.ctypes.data + 8 * top), 8 * dst.shape[1], C.c_void_p(src.ctypes.data), 8 * src.shape[1], 8 * rows, cols, threads)
+            assert np.array_equal(dst, want), (rows, cols, threads)
+    with pytest.raises(_lib.ArgumentError):
+        _lib.call("pmt_host_copy_2d", C.c_void_p(dst.ctypes.data), 8, C.c_void_p(src.ctypes.data), 8, 16, 2, 0)      # pitch smaller than a row
+    with pytest.raises(_lib.ArgumentError):
+        _lib.call("pmt_host_copy_2d", C.c_void_p(dst.ctypes.data), 16, C.c_void_p(src.ctypes.data), 16, 16, 2, 65)
