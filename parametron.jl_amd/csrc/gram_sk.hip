@@ -163,7 +163,11 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
 #if defined(PMT_SK_EPI_ABL) && PMT_SK_EPI_ABL == 2
                     if (v.x == 0x7ff8dead7ff8deadull) seg[q0] = v.y;          // ablation: (practically) no global stores
 #else
+#if defined(PMT_SK_EPI_NT) && PMT_SK_EPI_NT
+                    __builtin_nontemporal_store(v, reinterpret_cast<u64x2 *>(seg + q0));      // tuning: the term array is written once and never re-read here
+#else
                     *reinterpret_cast<u64x2 *>(seg + q0) = v;
+#endif
 #endif
                 } else {
                     seg[q0] = word(q0);
