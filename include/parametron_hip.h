@@ -504,7 +504,8 @@ int pmt_plan_record_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, c
 /* HOST -> HOST pitched copy on `threads` worker threads (0: eight; small copies use fewer): `height` rows of `width_bytes`.  For the dense
  * blocks of a host solver's A whose Parameter the HOST updates (`Parameter(model, val=buf)`, src/parameter.jl:88): their values are already
  * on the host and are copied there — from the Parameter's buffer into the block's row range of every column of the solver's array — while
- * the device re-evaluates the rest, instead of coming back over PCIe.  Synchronous; no device work. */
+ * the device re-evaluates the rest, instead of coming back over PCIe.  Synchronous; no device work; the worker threads are created and joined
+ * inside the call (the library keeps no threads of its own). */
 int pmt_host_copy_2d(void *host_dst, size_t dst_pitch, const void *host_src, size_t src_pitch, size_t width_bytes, size_t height, int threads);
 /* host: block until the plan's recorded fetches / deliveries have landed; errors as pmt_fetch_synchronize */
 int pmt_plan_fetch_synchronize(pmt_plan *plan);
