@@ -99,11 +99,11 @@ extern "C" int pmt_canonical_order_device(const void *terms, int64_t n, int term
     auto finish = [&](int code) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); return code; };
     if (hipMemsetAsync(small, 0, 64, s) != hipSuccess) return finish(fail(PMT_HIP_ERROR, "canonical_order_device: hipMemsetAsync"));
     const unsigned blocks = (unsigned)cdiv(n, 256);
-    hipLaunchKernelGGL(canon_keys_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const char *>(terms), n, term_bytes, keys, vals, too_large);
+    PMT_LAUNCH(canon_keys_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const char *>(terms), n, term_bytes, keys, vals, too_large);
     if ((rc = check_launch("canon_keys_kernel"))) return finish(rc);
     size_t b = tmp_bytes;
     if (rocprim::radix_sort_pairs(tmp, b, keys, keys2, vals, perm, un, 0, 64, s) != hipSuccess) return finish(fail(PMT_HIP_ERROR, "rocprim::radix_sort_pairs"));
-    hipLaunchKernelGGL(canon_heads_kernel, dim3(blocks), dim3(256), 0, s, keys2, n, head);
+    PMT_LAUNCH(canon_heads_kernel, dim3(blocks), dim3(256), 0, s, keys2, n, head);
     if ((rc = check_launch("canon_heads_kernel"))) return finish(rc);
     b = tmp_bytes;
     if (rocprim::select(tmp, b, rocprim::counting_iterator<int64_t>(0), head, seg_ptr, count, un, s) != hipSuccess) return finish(fail(PMT_HIP_ERROR, "rocprim::select"));

@@ -501,3 +501,27 @@ def test_full_size_affine_and_gram_properties():
     assert float(((l2[:, 0].view(torch.float64) - wl).abs() / wl.abs()).max()) <= 1e-12
     assert torch.equal(l2[:, 1], xvar)
     assert float(oc[0]) == pytest.approx(float((db * db).sum()), rel=1e-13)
+
+
+def test_scale_numbers_and_qp_bounds_entry_points():
+    """two small entry points the Python host reaches only through other shapes (the Julia binding calls them directly):
+    pmt_scale_numbers_f64 — scale!(dest, s, y) on number arrays, src/functions.jl:917-925, with the scalar on the device (a Parameter) and
+    as an immediate; pmt_qp_bounds_f64 — one constraint block's rows `f(x) in set` turned into l <= a'x <= u for the three cones."""
+    import gpu_util as g
+    rng = np.random.default_rng(8)
+    for n in (1, 255, 70000):
+        y = rng.random(n) - 0.5
+        dy, ds, out = g.to_dev(y), g.to_dev(np.array([-2.75])), g.empty_f64(n)
+        g.call("pmt_scale_numbers_f64", g.ptr(dy), n, g.ptr(ds), 9.0, g.ptr(out), g.stream())         # device scalar wins over the immediate
+        assert g.same_bits(g.f64_to_host(out, n), -2.75 * y)
+        g.call("pmt_scale_numbers_f64", g.ptr(dy), n, None, 3.5, g.ptr(out), g.stream())
+        assert g.same_bits(g.f64_to_host(out, n), 3.5 * y)
+    m = 1000
+    consts = rng.random(m) - 0.5
+    dc = g.to_dev(consts)
+    for kind, value in ((0, 0.0), (1, 0.25), (2, -1.5)):                # PMT_SET_EQUAL / GREATER / LESS
+        l, u = g.empty_f64(m), g.empty_f64(m)
+        g.call("pmt_qp_bounds_f64", g.ptr(dc), m, kind, value, 1e20, g.ptr(l), g.ptr(u), g.stream())
+        b = value - consts
+        assert g.same_bits(g.f64_to_host(l, m), np.full(m, -1e20) if kind == 2 else b)
+        assert g.same_bits(g.f64_to_host(u, m), np.full(m, 1e20) if kind == 1 else b)
