@@ -529,6 +529,7 @@ function record_host_handoff!(hm::HIPModel, rec)
     # array d.host), so a dense block's CSC values are already here — copy_A! copies them on the host while the device works.  (A host whose
     # Parameter values live on the device records pitched fetches out of the Parameter buffers instead: pmt_plan_record_fetch_2d at the front
     # of the side lane, ParametronHIP.record_fetch_matrix!; the Python host of this repository does both.)
+    H.set_lane!(hm.plan, 0)
     nothing
 end
 
