@@ -809,10 +809,10 @@ def summary_of(out):
 
 def ordered_for_the_tail(out):
     """Same object, keys re-ordered: the bulky sections (per-kernel tables, the other configurations with their prose) first, then the
-    contract's own fields, the roofline and CPU-baseline objects, and a compact `summary` LAST."""
+    contract's own fields, the CPU-baseline and roofline objects, and a compact `summary` LAST."""
     bulky = ("kernels", "configs", "host_api", "cpu_canonical_blas", "roofline_affine", "roofline_constraint_pack", "constraint_pack",
              "value_with_param_refresh", "value_200_steps")
-    last = ("config", "roofline", "cpu_baseline")
+    last = ("config", "cpu_baseline", "roofline")        # (the driver's text tail also carries a few lines of stderr: the shortest objects go last)
     res = {}
     for k in bulky:
         if k in out:

@@ -75,7 +75,7 @@ def test_line_ends_with_the_contract_objects_and_a_compact_summary():
     res = bench.ordered_for_the_tail(out)
     assert set(res) == set(out) | {"summary"}
     keys = list(res)
-    assert keys[-1] == "summary" and keys[-3:-1] == ["roofline", "cpu_baseline"] and keys.index("kernels") < keys.index("metric") < keys.index("roofline")
+    assert keys[-1] == "summary" and keys[-3:-1] == ["cpu_baseline", "roofline"] and keys.index("kernels") < keys.index("metric") < keys.index("roofline")
     s = res["summary"]
     for k in ("C3_ms", "C4_ms", "C4_frac", "C5_ms", "C5_frac", "host_csc_ms", "moi_ms", "device_ms", "pack_in_step_frac", "affine_warm_frac", "affine_cold_frac",
               "ranks_seen", "rccl_calls_made", "gram_frac", "value", "ms_per_step"):
