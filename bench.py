@@ -223,25 +223,42 @@ def timed_loop(torch, fn, steps):
 
 
 def constraint_pack_microbench(torch, _lib, wl, reps=20):
-    """affine_tile_kernel<VAT> on config 2's constraint block (C 512 x 4096 -> MOI.VectorAffineTerms), launched alone on the stream: the
-    kernel a plan WITHOUT a side lane runs for this node (bench.py --no-side-lane puts it back into the timed step)."""
+    """affine_tile_kernel<VAT> on config 2's constraint block (C 512 x 4096 -> MOI.VectorAffineTerms), launched alone on the stream.
+    In the step this kernel runs behind the contraction, which has streamed ~1 GB through the Infinity Cache since C was last touched: its
+    input is always COLD there (and the kernel reads a large block with the nontemporal policy for that reason, affine.hip).  The stand-alone
+    figure is therefore taken over SIX (C, output) pairs visited in turn (403 MB > the 256 MiB cache); `warm` — the same pair every launch,
+    what rounds 1-3 reported — is kept beside it."""
     m, n = wl.m, wl.n
-    def run():
-        _lib.call("pmt_affine_pack_vector_f64", dptr(wl.Cm), wl.ldc, m, n, dptr(wl.xvar), dptr(wl.d), -1, dptr(wl.varmap), 0, dptr(wl.Ct), dptr(wl.Cc), wl.stream)
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    _lib.call("pmt_profile_enable", 1)
-    for _ in range(reps):
-        run()
-    torch.cuda.synchronize()
-    rep = profile_report(_lib)
-    _lib.call("pmt_profile_enable", 0)
-    k = rep.get("affine_tile_kernel<VAT>")
+    Cs = [wl.Cm] + [torch.empty_like(wl.Cm) for _ in range(5)]
+    outs = [wl.Ct] + [torch.empty_like(wl.Ct) for _ in range(5)]
+    for c in Cs[1:]:
+        _lib.call("pmt_fill_uniform_matrix_f64", dptr(c), m, n, wl.ldc, 78, 1.0, wl.stream)
+
+    def run(i):
+        _lib.call("pmt_affine_pack_vector_f64", dptr(Cs[i % 6]), wl.ldc, m, n, dptr(wl.xvar), dptr(wl.d), -1, dptr(wl.varmap), 0, dptr(outs[i % 6]), dptr(wl.Cc), wl.stream)
+
+    def timed(which):
+        for i in range(6):
+            run(which(i))
+        torch.cuda.synchronize()
+        _lib.call("pmt_profile_enable", 1)
+        for i in range(reps + reps // 2):
+            run(which(i))
+        torch.cuda.synchronize()
+        rep = profile_report(_lib)
+        _lib.call("pmt_profile_enable", 0)
+        return rep.get("affine_tile_kernel<VAT>")
+    k = timed(lambda i: i)
+    kw = timed(lambda i: 0)
     if not k:
         return None
-    return hbm_roofline("affine_tile_kernel<VAT>", k["avg_ms"], 32.0 * m * n, "pmt::affine_tile_kernel<1",
-                        note="stand-alone launches of the tile kernel (not in the timed step: the step packs this block on the side lane)")
+    out = hbm_roofline("affine_tile_kernel<VAT>", k["avg_ms"], 32.0 * m * n, "pmt::affine_tile_kernel<1",
+                       note="stand-alone launches of the tile kernel over six (C, output) pairs visited in turn (cold inputs, as in the step)")
+    if kw:
+        out["warm"] = {"avg_ms": kw["avg_ms"], "achieved": 32.0 * m * n / (kw["avg_ms"] * 1e-3) / 1e9, "frac": 32.0 * m * n / (kw["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "what": "the same (C, output) pair every launch: C comes out of the Infinity Cache, where the nontemporal read policy of the "
+                               "large-block form costs; not how the step runs it"}
+    return out
 
 
 def affine_microbench(torch, _lib, wl, reps=20):

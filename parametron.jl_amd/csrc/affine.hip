@@ -15,9 +15,11 @@
 
 namespace pmt {
 
-#ifndef PMT_AFFINE_NT_LOAD
-#define PMT_AFFINE_NT_LOAD 0      // 1: the matrix is read with the nontemporal policy (a stream read once per re-evaluation)
-#endif
+// NTL (nontemporal loads of the matrix): measured (profiles/r04_batch_small.txt section 3, r04_affine_pack_nt.txt) — a matrix that is still in
+// the Infinity Cache is read 16 % slower with the policy, a cold one faster.  The MOI pack of a LARGE constraint block runs behind the
+// objective's contraction, which has streamed ~1 GB through the cache since the block was last touched: it is always cold there, and the
+// policy takes the in-step launch of config 2's 512 x 4096 block from 15.4 to ~13.8 us.  Small blocks and the LinearTerm form keep plain loads.
+constexpr int64_t NTL_MIN_BYTES = 8 << 20;
 
 constexpr int TILE = 64;
 constexpr int PITCH = TILE + 1;
@@ -41,7 +43,7 @@ __device__ __forceinline__ void store8(u64 *p, u64 v) {
 // TR: rows per tile (64, or 32 for blocks that would otherwise give fewer than ~4 workgroups per CU: the 512 x 4096 constraint block
 // of config 2 is 512 tiles of 64 x 64 — two per CU, 8 waves, tail-dominated: 19 us inside the step against 13 us when it had the
 // chip to itself; with 32-row tiles 1024 workgroups of half the LDS)
-template <int MODE, bool NT, int TR>
+template <int MODE, bool NT, int TR, bool NTL = false>
 __global__ __launch_bounds__(256) void affine_tile_kernel(
     const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
     const int64_t *__restrict__ xvar, const double *__restrict__ b, int sign,
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
 #pragma unroll
         for (int it = 0; it < TILE / CPI; ++it) {
             const f64x2 *src = reinterpret_cast<const f64x2 *>(base + (int64_t)it * CPI * lda);
-            f64x2 v = PMT_AFFINE_NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+            f64x2 v = NTL ? __builtin_nontemporal_load(src) : *src;
             const int c = it * CPI + cg;
             tile[lr * PITCH + c] = v.x;
             tile[(lr + 1) * PITCH + c] = v.y;
@@ -286,11 +288,18 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
     u64 *out = reinterpret_cast<u64 *>(out_terms);
     // small blocks: 32-row tiles, twice the workgroups (see the kernel's comment); ~1024 = 4 per CU is where 64-row tiles start to fill the chip
     const bool small = cdiv(cols, TILE) * cdiv(rows, TILE) < 1024 && rows > 32;
-#define AFFINE_LAUNCH(NTV, TRV)                                                                                                          \
-    PMT_LAUNCH_NAMED(name, (affine_tile_kernel<MODE, NTV, TRV>), dim3((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TRV)), dim3(256), 0, s, A, lda, \
-                     rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out)
-    if (env_nt()) { if (small) AFFINE_LAUNCH(true, 32); else AFFINE_LAUNCH(true, 64); }
-    else { if (small) AFFINE_LAUNCH(false, 32); else AFFINE_LAUNCH(false, 64); }
+    const bool ntl = MODE == 1 && rows * cols * (int64_t)sizeof(double) >= NTL_MIN_BYTES;
+#define AFFINE_LAUNCH(NTV, TRV, NTLV)                                                                                                    \
+    PMT_LAUNCH_NAMED(name, (affine_tile_kernel<MODE, NTV, TRV, NTLV>), dim3((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TRV)), dim3(256), 0, s, A, \
+                     lda, rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out)
+    if constexpr (MODE == 1) {
+        if (ntl) {
+            if (small) AFFINE_LAUNCH(true, 32, true); else AFFINE_LAUNCH(true, 64, true);
+            return check_launch("affine_tile_kernel");
+        }
+    }
+    if (env_nt()) { if (small) AFFINE_LAUNCH(true, 32, false); else AFFINE_LAUNCH(true, 64, false); }
+    else { if (small) AFFINE_LAUNCH(false, 32, false); else AFFINE_LAUNCH(false, 64, false); }
 #undef AFFINE_LAUNCH
     return check_launch("affine_tile_kernel");
 }
