@@ -756,7 +756,7 @@ def main():
         out["roofline_affine"] = guarded(affine_microbench, torch, _lib, wl)
         wl.close()          # the plan and its side stream go before the other configurations create theirs (streams share hardware queues)
         if not args.no_configs:
-            ksteps = max(20, min(args.steps, 100))
+            ksteps = max(50, min(args.steps, 100))      # (at least 50 steps: 20 steps of a 1.3 ms configuration are 26 ms, too short to average out a box hiccup)
             out["configs"] = {"C3": guarded(config_c3, torch, P, _lib, ksteps), "C4": guarded(config_c4, torch, _lib, ksteps),
                               "C5": guarded(config_c5, torch, P, _lib, ksteps)}
             out["host_api"] = guarded(host_api_c2, torch, P, 10)
@@ -767,7 +767,7 @@ def main():
     if not args.no_configs:
         # every rank: BASELINE config 4 sharded by instance over the N ranks (N = 1: the same code path, single-rank communicator)
         from parametron_jl_amd import batch
-        ksteps = max(20, min(args.steps, 100))
+        ksteps = max(50, min(args.steps, 100))      # (at least 50 steps: 20 steps of a 1.3 ms configuration are 26 ms, too short to average out a box hiccup)
         # This section has only ever run with one rank on hardware.  Should a collective of it hang with N > 1 (one rank failing alone), the
         # headline — complete at this point — must still come out: after 150 s rank 0 prints the line without the section and every rank exits.
         import threading
