@@ -13,20 +13,48 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+__device__ __forceinline__ double uniform_at(uint64_t base, uint64_t i, double scale) {
+    return scale * ((double)(splitmix64(base + i) >> 11) * 0x1.0p-53);
+}
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// two consecutive elements per thread and store (16 bytes per lane: a wave store covers 1 KiB); an unaligned head / odd tail go singly
 __global__ void fill_uniform_kernel(double *__restrict__ dst, int64_t n, uint64_t base, double scale) {
+    const int64_t head = (int64_t)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1);           // dst + head is 16-byte aligned
+    const int64_t npairs = (n - head) / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        dst[i] = scale * ((double)(splitmix64(base + (uint64_t)i) >> 11) * 0x1.0p-53);
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 == 0 && head && n > 0) dst[0] = uniform_at(base, 0, scale);
+    if (t0 == 0 && head + 2 * npairs < n) dst[n - 1] = uniform_at(base, (uint64_t)(n - 1), scale);
+    for (int64_t p = t0; p < npairs; p += stride) {
+        const int64_t i = head + 2 * p;
+        f64x2 v;
+        v.x = uniform_at(base, (uint64_t)i, scale);
+        v.y = uniform_at(base, (uint64_t)i + 1, scale);
+        *reinterpret_cast<f64x2 *>(dst + i) = v;
+    }
 }
 
 // column-major matrix with a padded leading dimension: dst[c*lda + i] = scale * U(seed, c*rows + i) — the VALUES are those of the
-// contiguous stream (identical to pmt_fill_uniform_f64 on a rows x cols array); only the placement in HBM differs
-__global__ void fill_uniform_matrix_kernel(double *__restrict__ dst, int64_t rows, int64_t cols, int64_t lda, uint64_t base, double scale) {
-    const int64_t n = rows * cols;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t c = i / rows, r = i - c * rows;
-        dst[c * lda + r] = scale * ((double)(splitmix64(base + (uint64_t)i) >> 11) * 0x1.0p-53);
+// contiguous stream (identical to pmt_fill_uniform_f64 on a rows x cols array); only the placement in HBM differs.
+// blockIdx.y walks the columns (no division per element), a thread writes a row pair of its column as one 16-byte store when the column
+// starts on a 16-byte boundary (even lda, aligned base), singly otherwise.
+__global__ void fill_uniform_matrix_kernel(double *__restrict__ dst, int64_t rows, int64_t cols, int64_t lda, uint64_t base, double scale, int vec) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = 2 * t;
+    if (r >= rows) return;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y) {
+        double *col = dst + c * lda;
+        const uint64_t i = (uint64_t)(c * rows + r);
+        const double x = uniform_at(base, i, scale);
+        if (r + 1 < rows) {
+            const double y = uniform_at(base, i + 1, scale);
+            if (vec) { f64x2 v; v.x = x; v.y = y; *reinterpret_cast<f64x2 *>(col + r) = v; }
+            else { col[r] = x; col[r + 1] = y; }
+        } else {
+            col[r] = x;
+        }
     }
 }
 
@@ -41,8 +69,11 @@ extern "C" int pmt_fill_uniform_matrix_f64(double *dst, int64_t rows, int64_t co
     PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform_matrix: null pointer");
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull;
     return dispatch(stream, [=](hipStream_t s) {
-        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cols, 256), 256 * 8);
-        PMT_LAUNCH(fill_uniform_matrix_kernel, dim3(blocks), dim3(256), 0, s, dst, rows, cols, lda, base, scale);
+        const int vec = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+        const int64_t bx = cdiv(cdiv(rows, 2), 256);
+        // enough workgroups to fill the chip (8 per CU) without more than the grid's y limit; the rest of the columns are walked in the kernel
+        const unsigned by = (unsigned)std::min<int64_t>(cols, std::max<int64_t>(1, std::min<int64_t>(65535, cdiv(2048, bx))));
+        PMT_LAUNCH(fill_uniform_matrix_kernel, dim3((unsigned)bx, by), dim3(256), 0, s, dst, rows, cols, lda, base, scale, vec);
         return check_launch("fill_uniform_matrix_kernel");
     });
 }
@@ -55,7 +86,7 @@ extern "C" int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed
     PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform: null pointer");
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull + index_offset;
     return dispatch(stream, [=](hipStream_t s) {
-        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 2), 256), 256 * 8);
         PMT_LAUNCH(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
         return check_launch("fill_uniform_kernel");
     });
@@ -67,7 +98,7 @@ extern "C" int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, doubl
     PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform: null pointer");
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull;
     return dispatch(stream, [=](hipStream_t s) {
-        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
+        const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 2), 256), 256 * 8);
         PMT_LAUNCH(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
         return check_launch("fill_uniform_kernel");
     });

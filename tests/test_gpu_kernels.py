@@ -30,6 +30,41 @@ def test_fill_uniform_matches_oracle_stream():
     assert g.same_bits(g.f64_to_host(d, n), O.fill_uniform(n, 12345, 2.0))
 
 
+@pytest.mark.parametrize("n,shift", [(1, 0), (1, 1), (2, 1), (7, 0), (8, 1), (513, 1), (100003, 1), (70000, 0)])
+def test_fill_uniform_odd_lengths_and_unaligned_bases(n, shift):
+    """the fill writes 16 bytes per lane: an 8-byte-aligned base, an odd length and the one-element cases take the single-element head / tail;
+    neighbours of the range stay untouched; the offset form continues the same stream"""
+    g = G()
+    buf = g.empty_f64(n + 4)
+    buf.fill_(-7.0)
+    d = buf[1 + shift:]                                             # (torch allocations are 16-byte aligned: shift picks the parity)
+    g.call("pmt_fill_uniform_f64", g.ptr(d), n, 77, 1.5, g.stream())
+    host = g.f64_to_host(buf, n + 4)
+    want = O.fill_uniform(n, 77, 1.5)
+    assert g.same_bits(host[1 + shift:1 + shift + n], want)
+    assert np.all(host[:1 + shift] == -7.0) and np.all(host[1 + shift + n:] == -7.0)
+    k = n // 3
+    g.call("pmt_fill_uniform_offset_f64", g.ptr(d), n - k, C.c_uint64(77), C.c_uint64(k), 1.5, g.stream())
+    assert g.same_bits(g.f64_to_host(d, n - k), want[k:])
+
+
+@pytest.mark.parametrize("rows,cols,pad,shift", [(1, 1, 0, 0), (1, 9, 2, 1), (2, 3, 0, 0), (5, 7, 1, 0), (64, 33, 0, 1), (513, 70, 3, 0), (4096, 40, 64, 0),
+                                                 (100, 70000, 0, 0)])
+def test_fill_uniform_matrix_is_the_contiguous_stream_placed_with_a_pitch(rows, cols, pad, shift):
+    """pmt_fill_uniform_matrix_f64: column c of the padded device matrix holds elements c*rows .. of the CONTIGUOUS stream (what the oracle
+    fills); the padding rows are not written; odd row counts, odd leading dimensions and unaligned bases take the single-element stores"""
+    g = G()
+    lda = rows + pad
+    buf = g.empty_f64(lda * cols + 2)
+    buf.fill_(-3.0)
+    d = buf[shift:]
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(d), rows, cols, lda, C.c_uint64(9), 2.0, g.stream())
+    host = g.f64_to_host(buf, lda * cols + 2)
+    m = host[shift:shift + lda * cols].reshape(cols, lda)
+    assert g.same_bits(m[:, :rows].copy().reshape(-1), O.fill_uniform(rows * cols, 9, 2.0))
+    assert np.all(m[:, rows:] == -3.0) and np.all(host[:shift] == -3.0) and np.all(host[shift + lda * cols:] == -3.0)
+
+
 # ------------------------------------------------------------------ affine_assemble (matvecmul! + vecadd!/vecsubtract!)
 @pytest.mark.parametrize("rows,cols,pad", [(3, 4, 0), (8, 8, 0), (2, 8, 0), (64, 64, 0), (65, 129, 1), (100, 37, 3),
                                            (128, 256, 0), (1, 1, 0), (512, 1024, 0)])
