@@ -553,7 +553,10 @@ int pmt_plan_end_record(pmt_plan *plan);
  * while the fix-up pass runs, instead of adding their own kernels and in-stream gaps behind it.
  * Lane 2 is the FRONT of the side lane: the same stream, but replayed before every other entry of the tape whatever its position in the
  * recording — for an entry that needs nothing of this re-evaluation, e.g. the recorded fetch of a dense constraint block's CSC values
- * straight out of its Parameter buffer (pmt_plan_record_fetch_2d): PCIe is busy from the first microseconds of the solve. */
+ * straight out of its Parameter buffer (pmt_plan_record_fetch_2d): PCIe is busy from the first microseconds of the solve.
+ * Lane 3 is lane 2 WITHOUT the fork from the plan's stream: for an entry whose inputs are produced on the side stream itself (a Parameter
+ * committed there, pmt_plan_commit_lane, or regenerated there, pmt_plan_lane_stream) — it does not wait for what the plan's stream still has
+ * to do in front of the tape (the callbacks of the objective's Parameters).  The caller vouches for that; everything joins at the end. */
 int pmt_plan_set_lane(pmt_plan *plan, int lane);
 /* The HIP stream the entries of a lane are replayed on (0: pmt_plan_stream; 1, 2: the side stream).  A device-side Parameter callback whose
  * value only side-lane entries read may run THERE (in front of pmt_plan_update): a transfer at the front of the side lane then does not

@@ -36,7 +36,8 @@ struct pmt_plan {
     std::vector<void *> allocations;
     size_t bytes = 0;
     std::vector<pmt::Launch> tape;
-    std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane (pmt_plan_set_lane)
+    std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
+                                      // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
     char record_lane = 0;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
     hipGraph_t graph = nullptr;
@@ -554,6 +555,15 @@ static int replay(pmt_plan *plan, hipStream_t s) {
     // lane 2 first: entries that depend on nothing of this replay (a transfer of Parameter values that are already in place) are queued on
     // the side stream in front of everything the tape puts there — e.g. in front of the Gram node's affine reduction, behind which a
     // lane-1 entry would start ~0.1 ms into the re-evaluation
+    // lane 3 before that, without the fork: entries whose inputs are produced ON the side stream (a Parameter committed / regenerated there,
+    // pmt_plan_commit_lane / pmt_plan_lane_stream) do not wait for what the plan's stream still has to do before the tape — e.g. the
+    // device-side callback of the objective's 134 MB matrix
+    bool side_used = false;
+    for (size_t i = 0; side && i < plan->tape.size(); ++i)
+        if (plan->lanes[i] == 3) {
+            side_used = true;
+            if (int rc = plan->tape[i](side)) return rc;
+        }
     for (size_t i = 0; side && i < plan->tape.size(); ++i) {
         if (plan->lanes[i] != 2) continue;
         if (!forked) { PMT_HIP_CHECK(hipStreamWaitEvent(side, plan->lane_fork, 0)); forked = true; }
@@ -561,7 +571,7 @@ static int replay(pmt_plan *plan, hipStream_t s) {
     }
     for (size_t i = 0; i < plan->tape.size(); ++i) {
         hipStream_t target = s;
-        if (side && plan->lanes[i] == 2) continue;
+        if (side && plan->lanes[i] >= 2) continue;
         if (side && plan->lanes[i]) {
             if (!forked) { PMT_HIP_CHECK(hipStreamWaitEvent(side, plan->lane_fork, 0)); forked = true; }
             target = side;
@@ -569,7 +579,7 @@ static int replay(pmt_plan *plan, hipStream_t s) {
         int rc = plan->tape[i](target);
         if (rc) return rc;
     }
-    if (forked) {
+    if (forked || side_used) {
         PMT_HIP_CHECK(hipEventRecord(plan->lane_join, side));
         PMT_HIP_CHECK(hipStreamWaitEvent(s, plan->lane_join, 0));
     }
@@ -630,7 +640,7 @@ extern "C" int pmt_plan_fetch_synchronize(pmt_plan *plan) {
 extern "C" int pmt_plan_set_lane(pmt_plan *plan, int lane) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_set_lane: null plan");
     PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan_set_lane: the plan is not recording");
-    PMT_REQUIRE(lane >= 0 && lane <= 2, PMT_INVALID_ARGUMENT, "plan_set_lane: lane must be 0, 1 or 2");
+    PMT_REQUIRE(lane >= 0 && lane <= 3, PMT_INVALID_ARGUMENT, "plan_set_lane: lane must be 0, 1, 2 or 3");
     plan->record_lane = (char)lane;
     return PMT_OK;
 }

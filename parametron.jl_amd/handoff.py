@@ -85,8 +85,9 @@ def _parameter_of(expr, dmat):
 class _Transfer:
     """one device -> host copy of a re-evaluation: `nbytes` linear, or `height` rows of `nbytes` with the given pitches"""
 
-    def __init__(self, host_ptr, dev_ptr, nbytes, dst_pitch=0, src_pitch=0, height=0):
+    def __init__(self, host_ptr, dev_ptr, nbytes, dst_pitch=0, src_pitch=0, height=0, param_id=None):
         self.host_ptr, self.dev_ptr, self.nbytes, self.dst_pitch, self.src_pitch, self.height = int(host_ptr), int(dev_ptr), int(nbytes), dst_pitch, src_pitch, height
+        self.param_id = param_id                  # id() of the Parameter a pitched transfer reads, if any
 
     def record(self, ctx):
         if self.height:
@@ -135,7 +136,8 @@ class HostQP:
         if qp.A.only_rects:
             # A's static entries (bounds rows: 1.0) were fetched once at set-up; per solve only the dense blocks travel
             # (blocks of host-updated Parameters do not travel at all: host_copies())
-            early = [_Transfer(self.Ax.ctypes.data + 8 * r.first, r.mat.buf, 8 * r.mat.rows, 8 * r.pitch, 8 * r.mat.lda, r.mat.cols)
+            early = [_Transfer(self.Ax.ctypes.data + 8 * r.first, r.mat.buf, 8 * r.mat.rows, 8 * r.pitch, 8 * r.mat.lda, r.mat.cols,
+                               param_id=id(r.param) if r.param is not None else None)
                      for r in qp.A.rects if not r.host_resident()]
         else:
             early = [_Transfer(self.Ax.ctypes.data, qp.A.values_ptr, self.Ax.nbytes)]
@@ -328,9 +330,13 @@ class DeviceQP:
                 for name, args in self._launches:
                     ctx.call(name, *args)
                 if host == "overlap":
+                    side_made = model._side_refreshed_parameter_ids() if in_tape == "side" else set()
                     for t in self.host.transfers(late=False):
                         # a dense block straight out of its Parameter buffer depends on nothing of this re-evaluation: front of the side lane
-                        ctx.set_lane(2 if (t.height and in_tape == "side") else (1 if in_tape == "side" else 0))
+                        # (lane 2) — and when the Parameter's value is itself produced on the side stream (only side-lane records read it),
+                        # without waiting for the plan's stream at all (lane 3: not for the objective's callbacks either)
+                        front = 3 if (t.param_id in side_made) else 2
+                        ctx.set_lane(front if (t.height and in_tape == "side") else (1 if in_tape == "side" else 0))
                         t.record(ctx)
                 ctx.set_lane(0)
                 if host == "overlap":                       # behind the objective's own kernels on the plan's stream

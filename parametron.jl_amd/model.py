@@ -349,6 +349,13 @@ class Model:
         objective instead of standing in front of it.  Every other Parameter keeps the plan's stream."""
         lane_records = getattr(self, "_lane_records", [])
         handoff_ok = self.device_qp is None or getattr(self.device_qp, "_in_tape_lane", None) == "side"
+        for x, side_only in self._parameter_readers().values():
+            # (a graph replay launches the side-lane entries as nodes of ONE graph on the plan's stream: no side stream to order against)
+            x._commit_on_side_lane = bool(side_only and handoff_ok and lane_records and not self._use_graph)
+
+    def _parameter_readers(self):
+        """{id(Parameter): [Parameter, read by side-lane records only]}"""
+        lane_records = getattr(self, "_lane_records", [])
         readers = {}
         for r in self._records:
             if not isinstance(r.expr, DeviceNode):
@@ -357,9 +364,14 @@ class Model:
             for x in schedule([r.expr]):
                 if isinstance(x, Parameter):
                     readers.setdefault(id(x), [x, True])[1] &= on_side
-        for x, side_only in readers.values():
-            # (a graph replay launches the side-lane entries as nodes of ONE graph on the plan's stream: no side stream to order against)
-            x._commit_on_side_lane = bool(side_only and handoff_ok and lane_records and not self._use_graph)
+        return readers
+
+    def _side_refreshed_parameter_ids(self):
+        """Parameters whose values will be produced ON the side stream (committed / regenerated there) once a hand-off recorded on the side
+        lane exists: what a front-of-lane transfer may read without waiting for the plan's stream (lane 3)"""
+        if self._use_graph or not getattr(self, "_lane_records", []):
+            return set()
+        return {k for k, (x, side_only) in self._parameter_readers().items() if side_only}
 
     @staticmethod
     def _side_lane_ok(r):

@@ -150,7 +150,7 @@ def test_set_lane_state_and_argument_errors():
         g.call("pmt_plan_set_lane", plan, 1)                            # not recording
     g.call("pmt_plan_begin_record", plan)
     with pytest.raises(P.ArgumentError):
-        g.call("pmt_plan_set_lane", plan, 3)
+        g.call("pmt_plan_set_lane", plan, 4)
     g.call("pmt_plan_set_lane", plan, 1)
     g.call("pmt_plan_set_lane", plan, 0)
     g.call("pmt_plan_end_record", plan)
