@@ -75,8 +75,9 @@ __device__ __forceinline__ int sk_fresh_tid() {
     return t;
 }
 
+// hsel >= 0: only the row half hsel of the tile is written (balanced pair fold: each of the two workgroups of a split tile finishes one half)
 template <int TN>
-__device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int) {
+__device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, const double (&acc)[Cfg<TN>::NACC], double *smem, int, int hsel = -1) {
     using C = Cfg<TN>;
 #if defined(PMT_SK_EPI_ABL) && PMT_SK_EPI_ABL == 3
     {   // ablation: no epilogue at all (the accumulators stay live through a store that never happens): what a FREE write-out would give
@@ -98,8 +99,9 @@ __device__ __forceinline__ void sk_epilogue(const SKArgs &g, int jb, int kb, con
     const int wr = wave / C::NWC;
     u64 *out = reinterpret_cast<u64 *>(g.out_quad);
     for (int h = 0; h < 2; ++h) {
+        if (hsel >= 0 && h != hsel) continue;
         __syncthreads();
-        if (g.out_quad && h == 0 && tid < 128) {
+        if (g.out_quad && (h == 0 || hsel >= 0) && tid < 128) {
             const int64_t k = k0 + tid;
             const int64_t kv = k < n ? g.xvar[k] : 1;
             cmap[tid] = (u64)(g.moi ? map_var(g.varmap, kv) : kv);
@@ -471,56 +473,66 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
 
             bool whole = c0 == 0 && c1 == g.nchunk;
             const bool pair = RANGED && g.pair_flags != nullptr && !whole;
-            if (pair && c0 != 0) {
-                // PAIR FOLD, second half (stages of a host delivery whose tiles are split exactly in two, launcher): the workgroup with the
-                // first half is the previous one (both run at the same time, one workgroup per CU); wait for its flag, add its sum IN FRONT of
-                // this one — 0 + first + second, the order of the fix-up pass — and write the tile with the coalescing epilogue below.  No
-                // fix-up launch for this stage: 17 us + two in-stream gaps less per stage.
-                // (workgroups are dispatched in order, so the partner — one block id lower — is on the chip or done when this one runs; the
-                // wait is bounded all the same, and a tile whose partner never showed up is written as NaN, not as a plausible half sum)
+            int hsel = -1;                                       // row half the epilogue below writes (-1: both)
+            if (pair) {
+                // BALANCED PAIR FOLD (stages of a host delivery whose tiles are split exactly in two, launcher).  The two workgroups of a tile —
+                // block ids 2t (rows [0, r/2) of the contraction) and 2t + 1, on the chip at the same time, one per CU — each FINISH one row half
+                // of the tile: the one with the first half keeps its wave rows 0 (tile rows 0..63) and hands its partial of wave rows 1 to the
+                // partner through the workspace (agent-scope write-through stores, then its flag), the other one the other way round; each waits
+                // for the partner's flag, adds the 64 KB it was handed to what it kept (first + second: a sum of two, the same bits whoever
+                // adds) and writes its 64 rows through the coalescing epilogue.  No fix-up launch, and half the partial traffic and half the
+                // write-out on each workgroup's path (round 3's fold had the second workgroup read 128 KB and write the whole tile while the
+                // first sat idle: ~10 us per stage).  The wait is bounded; a half whose partner never showed up is written as NaN and the
+                // launch's error word is raised (pmt_plan_fetch_synchronize returns PMT_HIP_ERROR, gram.hip).
+                const bool first = c0 == 0;
+                const int keep = first ? 0 : 1;
+                const int ftid = sk_fresh_tid();                                 // (fresh: nothing of this is live across the stage loop)
+                const int mywr = __builtin_amdgcn_readfirstlane(ftid >> 6) / C::NWC;          // wave-uniform: the two roles are scalar branches
+                if (mywr != keep) {
+                    double *w = g.ws + (int64_t)(2 * bid) * SLOT + ftid;
+    #pragma unroll
+                    for (int r = 0; r < C::NACC; ++r) __hip_atomic_store(&w[r * C::NT], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
                 if (tid == 0) {
+                    __hip_atomic_store(&g.pair_flags[(first ? 0 : 512) + rtile], g.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned *other = &g.pair_flags[(first ? 512 : 0) + rtile];
                     const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                     double late = 0.0;
-                    while (__hip_atomic_load(&g.pair_flags[rtile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) {
+                    while (__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) {
                         __builtin_amdgcn_s_sleep(8);
                         if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > g.pair_timeout) { late = 1.0; break; }   // 2 s (100 MHz ticks)
                     }
-                    // reported, not only marked: pmt_plan_fetch_synchronize / pmt_fetch_synchronize return PMT_HIP_ERROR (gram.hip)
                     if (late != 0.0 && g.error) __hip_atomic_store(g.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     lds[0][0][0] = late;                         // (the panels are idle between the stage loop and the epilogue)
                 }
                 __syncthreads();
                 const bool late = lds[0][0][0] != 0.0;
-                const double *w = g.ws + (int64_t)(2 * (bid - 1)) * SLOT + sk_fresh_tid();      // (fresh: nothing of this is live across the stage loop)
+                if (mywr == keep) {
+                    const double *w = g.ws + (int64_t)(2 * (bid ^ 1)) * SLOT + ftid;
     #pragma unroll
-                for (int r0 = 0; r0 < C::NACC; r0 += 8) {      // eight loads in flight at a time
-                    double first[8];
+                    for (int r0 = 0; r0 < C::NACC; r0 += 4) {      // four loads in flight at a time (register budget)
+                        double other[4];
     #pragma unroll
-                    for (int r = 0; r < 8; ++r) first[r] = __hip_atomic_load(&w[(r0 + r) * C::NT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int r = 0; r < 4; ++r) other[r] = __hip_atomic_load(&w[(r0 + r) * C::NT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     #pragma unroll
-                    for (int r = 0; r < 8; ++r) acc[r0 + r] = late ? __builtin_nan("") : first[r] + acc[r0 + r];
-                    asm volatile("" ::: "memory");
+                        for (int r = 0; r < 4; ++r) acc[r0 + r] = late ? __builtin_nan("") : other[r] + acc[r0 + r];
+                        asm volatile("" ::: "memory");
+                    }
                 }
                 whole = true;
+                hsel = keep;
             }
             if (whole) {
                 static_assert(2 * 2 * ST * GP >= EPI_DOUBLES, "panel LDS must hold the epilogue staging tile");
-                sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
+                sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid, RANGED ? hsel : -1);
             } else {
-                // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map.  Pair fold,
-                // first half: agent-scope write-through stores, and once they are acknowledged the tile's flag takes the launch's epoch
+                // partial tile -> workspace slot, stored [accumulator index][thread] (coalesced); the fix-up kernel knows the map
                 const int slot = 2 * bid + (u == u0 ? 0 : 1);
                 double *w = g.ws + (int64_t)slot * SLOT + (RANGED ? sk_fresh_tid() : tid);
-                if (pair) {
     #pragma unroll
-                    for (int r = 0; r < C::NACC; ++r) __hip_atomic_store(&w[r * C::NT], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_s_waitcnt(0);
-                    __syncthreads();
-                    if (tid == 0) __hip_atomic_store(&g.pair_flags[rtile], g.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-    #pragma unroll
-                    for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
-                }
+                for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
             }
             u += (c1 - c0);
         }
