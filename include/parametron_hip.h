@@ -194,9 +194,11 @@ int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t co
 /* The same node (values only, no term structs) with the values additionally DELIVERED TO THE HOST while the contraction runs — the
  * reference's boundary is a host solver (MOI.set, src/moi_interop.jl:131-137; OSQP's update_P takes exactly this array).  host_P_values
  * is page-locked host memory (pmt_host_alloc) of cols*(cols+1)/2 doubles.  The contraction runs in STAGES over the column bands of P
- * (`ngroups` stages, 0 = default: half a grid's worth of 128 x 128 tiles per stage, at most 16): each stage is a launch over all CUs with
- * its tiles split along the contraction and summed by a second launch, and the copy engine (HSA SDMA; a courier kernel where that is not
- * available) ships the bands a stage has completed while the next stage is computed, so P leaves at PCIe speed from the first stage on.
+ * (`ngroups` stages, 0 = default: half a grid's worth of 128 x 128 tiles per stage, at most 16), walked from the LAST band to the first (the
+ * long bands leave while the contraction is still busy, the short ones are what is left at its end): each stage is a launch over all CUs
+ * with its tiles split in two along the contraction — the two workgroups of a tile exchange halves through the workspace and each finishes
+ * one row half (other stage sizes: a second launch adds the partial sums) — and the copy engine (HSA SDMA; a courier kernel where that is
+ * not available) ships the bands a stage has completed while the next stage is computed, so P leaves at PCIe speed from the first stage on.
  * Splitting a tile changes its summation order (two half sums added): out_P_values here and from pmt_quad_gram_csc_f64 agree to rounding
  * (a few ulp), not bit for bit; both are deterministic, and host_P_values is out_P_values of the same call bit for bit.  `stream` does not
  * wait for the delivery: pmt_plan_fetch_synchronize (or pmt_fetch_synchronize for a plain stream) does — PMT_HIP_ERROR there if a transfer
