@@ -233,3 +233,49 @@ def test_back_to_back_immediate_deliveries_do_not_overtake_each_other(delivery, 
         assert np.array_equal(host, dev)
         np.testing.assert_allclose(host, want, rtol=1e-13, atol=0)          # (staged: split tiles are two half sums)
     _lib.call("pmt_host_free", hp)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_lane_3_transfer_reads_what_the_side_stream_produced(delivery, mode):
+    """C ABI: a value regenerated ON the side stream (pmt_plan_lane_stream) and a recorded pitched fetch of it at the front of the side lane
+    without the fork from the plan's stream (lane 3) — while a long fill occupies the plan's stream.  Update after update the host block
+    holds THIS update's values (the side stream orders callback -> transfer; the previous transfer is drained by the host before the
+    next callback, as both hosts do), and the tape's main-lane entry sees the plan's stream's own work."""
+    from oracle import oracle as O
+    delivery(mode)
+    rows, cols, lda, tall = 64, 50, 80, 96
+    plan = C.c_void_p()
+    _lib.call("pmt_plan_create", 0, None, C.byref(plan))
+    side = C.c_void_p()
+    _lib.call("pmt_plan_lane_stream", plan, 1, C.byref(side))
+    main = C.c_void_p(_lib.load().pmt_plan_stream(plan))
+    assert side.value and side.value != main.value
+    dev = torch.zeros(lda * cols, dtype=torch.float64, device=DEV)
+    big = torch.empty(1 << 24, dtype=torch.float64, device=DEV)              # 128 MB: the "objective's callback" on the plan's stream
+    small = torch.empty(1000, dtype=torch.float64, device=DEV)
+    out = torch.empty(1000, dtype=torch.float64, device=DEV)
+    hp = C.c_void_p()
+    _lib.call("pmt_host_alloc", 8 * tall * cols, C.byref(hp))
+    host = np.frombuffer((C.c_char * (8 * tall * cols)).from_address(hp.value), dtype=np.float64).reshape(cols, tall)
+    rec = C.c_void_p(_lib.load().pmt_plan_recording_stream(plan))
+    _lib.call("pmt_plan_begin_record", plan)
+    _lib.call("pmt_scale_numbers_f64", ptr(small), 1000, None, 2.0, ptr(out), rec)          # main lane: reads what the plan's stream wrote
+    _lib.call("pmt_plan_set_lane", plan, 3)
+    _lib.call("pmt_plan_record_fetch_2d", plan, C.c_void_p(hp.value + 8 * 5), 8 * tall, ptr(dev), 8 * lda, 8 * rows, cols)
+    _lib.call("pmt_plan_set_lane", plan, 0)
+    _lib.call("pmt_plan_end_record", plan)
+    torch.cuda.synchronize()
+    for it in range(4):
+        host[:] = -1.0
+        _lib.call("pmt_plan_fetch_synchronize", plan)                                                  # (the previous transfer has read `dev`)
+        _lib.call("pmt_fill_uniform_f64", ptr(big), 1 << 24, C.c_uint64(100 + it), 1.0, main)        # plan's stream: long
+        _lib.call("pmt_fill_uniform_f64", ptr(small), 1000, C.c_uint64(200 + it), 1.0, main)
+        _lib.call("pmt_fill_uniform_matrix_f64", ptr(dev), rows, cols, lda, C.c_uint64(300 + it), 1.0, side)   # side stream: this update's value
+        _lib.call("pmt_plan_update", plan)
+        _lib.call("pmt_plan_fetch_synchronize", plan)
+        want = O.fill_uniform(rows * cols, 300 + it).reshape(cols, rows)
+        assert np.array_equal(host[:, 5:5 + rows], want) and np.all(host[:, :5] == -1.0) and np.all(host[:, 5 + rows:] == -1.0)
+        _lib.call("pmt_plan_synchronize", plan)
+        assert np.array_equal(out.cpu().numpy(), 2.0 * O.fill_uniform(1000, 200 + it))
+    _lib.call("pmt_plan_destroy", plan)
+    _lib.call("pmt_host_free", hp)
