@@ -430,6 +430,13 @@ int pmt_profile_enable(int on);
  * free (a few microseconds of queue time each), so a benchmark times only the kernel it reports on */
 int pmt_profile_filter(const char *substring);
 int64_t pmt_profile_report(char *host_buf, size_t cap);
+/* Measurement hook for ONE kernel inside a step, without the in-stream gap a HIP-event pair around an in-step launch includes: while
+ * `device_words3` (three zero-initialisable uint64 words in device memory, word 0 preset to UINT64_MAX) is set, every workgroup of the
+ * MOI pack kernel (affine_tile_kernel<VAT>, pmt_affine_pack_vector_f64) reports min(start), max(end) of the constant-rate device clock
+ * (wall_clock64, hipDeviceAttributeWallClockRate kHz) and counts itself.  NULL (the default) switches it off: one uniform branch. */
+int pmt_profile_kernel_stamps(void *device_words3);
+/* rate of that clock in kHz (hipDeviceAttributeWallClockRate) */
+int pmt_device_clock_khz(int device, int *khz);
 
 /* ---------------------------------------------------------------------------------------
  * Multi-GPU exchange of the batched configuration (BASELINE config 4): one process per GPU, rank g owns the instances
@@ -455,6 +462,9 @@ int pmt_comm_unique_id(void *out_id_128_bytes);
 int pmt_comm_init_rank(int nranks, int rank, const void *unique_id_128_bytes, int device, void **out_comm);
 int64_t pmt_comm_rccl_calls(void *comm);
 int pmt_comm_destroy(void *comm);
+/* the shard of rank `rank`: per_rank = total / nranks instances starting at `first`.  The exchange assumes the SAME per_rank on every
+ * rank (the gathered buffer is nranks * per_rank slabs): a batch that does not divide is PMT_DIMENSION_MISMATCH, never an uneven split. */
+int pmt_batch_shard(int64_t total, int nranks, int rank, int64_t *per_rank, int64_t *first);
 int64_t pmt_batch_num_chunks(int64_t per_rank, int64_t chunk);
 int pmt_batch_chunk_range(int64_t per_rank, int64_t chunk, int64_t c, int64_t *lo, int64_t *hi);
 int64_t pmt_batch_gathered_offset(int rank, int64_t per_rank, int64_t local_instance, int64_t stride);

@@ -308,6 +308,12 @@ function comm_init_rank(nranks::Integer, rank::Integer, id::Vector{UInt8}, devic
     ref[]
 end
 comm_destroy(comm::Ptr{Cvoid}) = check(ccall((:pmt_comm_destroy, lib), Cint, (Ptr{Cvoid},), comm))
+"(per_rank, first) of `rank`'s shard of `total` instances; DimensionMismatch when the batch does not divide over the ranks"
+function batch_shard(total::Integer, nranks::Integer, rank::Integer)
+    per = Ref{Int64}(0); first = Ref{Int64}(0)
+    check(ccall((:pmt_batch_shard, lib), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), total, nranks, rank, per, first))
+    per[], first[]
+end
 "one re-evaluation of this rank's instances, chunk c on the wire while chunk c + 1 is computed; `gathered` ends up with every rank's slabs"
 batch_step!(comm::Ptr{Cvoid}, A::DevPtr, b::DevPtr, C::DevPtr, d::DevPtr, per_rank, n, r, m, local_slabs::DevPtr, gathered::DevPtr, stride, chunk, stream) =
     check(ccall((:pmt_batch_step_f64, lib), Cint,

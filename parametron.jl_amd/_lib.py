@@ -111,6 +111,7 @@ SIGNATURES = {
     "pmt_batch_num_chunks": (_i64, [_i64, _i64]),
     "pmt_batch_chunk_range": (_ci, [_i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "pmt_batch_gathered_offset": (_i64, [_ci, _i64, _i64, _i64]),
+    "pmt_batch_shard": (_ci, [_i64, _ci, _ci, C.POINTER(_i64), C.POINTER(_i64)]),
     "pmt_batch_allgather_f64": (_ci, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "pmt_batch_step_f64": (_ci, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _ci, _ci, _vp, _vp, _i64, _i64, _vp]),
     "pmt_consts_f64": (_ci, [_vp, _i64, _ci, _vp, _vp]),
@@ -118,6 +119,8 @@ SIGNATURES = {
     "pmt_fill_uniform_offset_f64": (_ci, [_vp, _i64, _u64, _u64, _f64, _vp]),
     "pmt_profile_enable": (_ci, [_ci]),
     "pmt_profile_filter": (_ci, [C.c_char_p]),
+    "pmt_profile_kernel_stamps": (_ci, [_vp]),
+    "pmt_device_clock_khz": (_ci, [_ci, C.POINTER(_ci)]),
     "pmt_profile_report": (_i64, [C.c_char_p, _sz]),
     "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),
     "pmt_plan_destroy": (_ci, [_vp]),

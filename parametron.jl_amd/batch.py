@@ -16,10 +16,11 @@ from ._lib import ArgumentError
 
 
 def shard_range(total, rank, world):
-    """Contiguous instance range [lo, hi) owned by `rank`."""
-    if not (0 <= rank < world):
-        raise ArgumentError("rank %d outside world of %d" % (rank, world))
-    return total * rank // world, total * (rank + 1) // world
+    """Contiguous instance range [lo, hi) owned by `rank` (pmt_batch_shard): equal shards, or DimensionMismatch — the exchange lays the
+    gathered buffer out as world * per_rank slabs, an uneven split would corrupt it silently."""
+    per, first = C.c_int64(), C.c_int64()
+    _lib.call("pmt_batch_shard", total, world, rank, C.byref(per), C.byref(first))
+    return first.value, first.value + per.value
 
 
 def slab_layout(n, m):
@@ -115,8 +116,6 @@ class BatchLSQ:
     SEEDS = {"A": 101, "b": 102, "C": 103, "d": 104}
 
     def __init__(self, torch, total, n, r, m, rank=0, world=1, device=None):
-        if total % world:
-            raise ArgumentError("batch size %d is not divisible by the number of ranks %d" % (total, world))
         _lib.require_gpu()
         self.torch, self.total, self.n, self.r, self.m, self.rank, self.world = torch, total, n, r, m, rank, world
         self.lo, self.hi = shard_range(total, rank, world)

@@ -48,11 +48,13 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
     const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
     const int64_t *__restrict__ xvar, const double *__restrict__ b, int sign,
     const int64_t *__restrict__ varmap, int64_t row_offset,
-    u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out) {
+    u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out, u64 *stamps) {
     __shared__ double tile[TR * PITCH];
     __shared__ u64 vmx[TILE];
 
     const int t = threadIdx.x;
+    // measurement hook (pmt_profile_kernel_stamps; null in production): earliest workgroup start of the launch, constant 100 MHz clock
+    if (stamps && t == 0) atomicMin(stamps, (u64)wall_clock64());
     const int lane = t & 63;
     const int wave = t >> 6;
     const int64_t c0 = (int64_t)blockIdx.x * TILE;
@@ -136,6 +138,14 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
                     store8<NT>(p + 2, var);
                 }
             }
+        }
+    }
+    if (stamps) {                    // ... and the latest workgroup end, behind this workgroup's stores
+        __syncthreads();
+        if (t == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            atomicMax(stamps + 1, (u64)wall_clock64());
+            atomicAdd(stamps + 2, (u64)1);
         }
     }
 }
@@ -278,6 +288,9 @@ static bool env_nt() {
 #endif
 }
 
+// pmt_profile_kernel_stamps: device words {min start, max end, workgroups} the affine tile kernel of the NEXT launches reports into
+static u64 *g_stamps = nullptr;
+
 template <int MODE>
 static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
                          const int64_t *varmap, int64_t row_offset, void *out_terms, double *out_consts, hipStream_t s) {
@@ -289,9 +302,10 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
     // small blocks: 32-row tiles, twice the workgroups (see the kernel's comment); ~1024 = 4 per CU is where 64-row tiles start to fill the chip
     const bool small = cdiv(cols, TILE) * cdiv(rows, TILE) < 1024 && rows > 32;
     const bool ntl = MODE == 1 && rows * cols * (int64_t)sizeof(double) >= NTL_MIN_BYTES;
+    u64 *stamps = MODE == 1 ? g_stamps : nullptr;
 #define AFFINE_LAUNCH(NTV, TRV, NTLV)                                                                                                    \
     PMT_LAUNCH_NAMED(name, (affine_tile_kernel<MODE, NTV, TRV, NTLV>), dim3((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TRV)), dim3(256), 0, s, A, \
-                     lda, rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out)
+                     lda, rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out, stamps)
     if constexpr (MODE == 1) {
         if (ntl) {
             if (small) AFFINE_LAUNCH(true, 32, true); else AFFINE_LAUNCH(true, 64, true);
@@ -307,6 +321,17 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
 }  // namespace pmt
 
 using namespace pmt;
+
+extern "C" int pmt_profile_kernel_stamps(void *device_words3) {
+    g_stamps = reinterpret_cast<u64 *>(device_words3);
+    return PMT_OK;
+}
+
+extern "C" int pmt_device_clock_khz(int device, int *khz) {
+    PMT_REQUIRE(khz, PMT_INVALID_ARGUMENT, "device_clock_khz: null pointer");
+    PMT_HIP_CHECK(hipDeviceGetAttribute(khz, hipDeviceAttributeWallClockRate, device));
+    return PMT_OK;
+}
 
 extern "C" int pmt_affine_assemble_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
                                        int sign, pmt_linear_term *out_terms, double *out_consts, void *stream) {

@@ -156,6 +156,16 @@ extern "C" int pmt_comm_destroy(void *comm) {
 // ---- the chunk schedule (pure host arithmetic: the 2-rank gloo test on CPU drives the same functions) ----------------------------------
 // rank g owns the instances [g * per_rank, (g + 1) * per_rank) of the batch; its chunk c is the local range [c * chunk, min(., per_rank));
 // in the gathered buffer the slab of global instance i sits at i * stride doubles.
+extern "C" int pmt_batch_shard(int64_t total, int nranks, int rank, int64_t *per_rank, int64_t *first) {
+    PMT_REQUIRE(total >= 0 && nranks >= 1 && per_rank && first, PMT_INVALID_ARGUMENT, "batch_shard: bad argument");
+    PMT_REQUIRE(rank >= 0 && rank < nranks, PMT_INVALID_ARGUMENT, "batch_shard: rank outside the communicator");
+    PMT_REQUIRE(total % nranks == 0, PMT_DIMENSION_MISMATCH,
+                "batch_shard: " + std::to_string(total) + " instances do not divide over " + std::to_string(nranks) + " ranks (the exchange needs equal shards)");
+    *per_rank = total / nranks;
+    *first = *per_rank * rank;
+    return PMT_OK;
+}
+
 extern "C" int64_t pmt_batch_num_chunks(int64_t per_rank, int64_t chunk) {
     if (per_rank <= 0) return 0;
     if (chunk <= 0 || chunk > per_rank) chunk = per_rank;

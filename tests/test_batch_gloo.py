@@ -124,11 +124,24 @@ def test_two_rank_instance_sharding_and_allgather():
 
 
 def test_shard_range_partitions_any_world():
-    from parametron_jl_amd import batch
-    for total in (1, 7, 8192):
+    """equal contiguous shards (pmt_batch_shard); a batch that does not divide over the ranks is a DimensionMismatch, never an uneven split
+    (comm.hip lays the gathered buffer out as world * per_rank slabs)"""
+    import pytest
+    from parametron_jl_amd import batch, _lib
+    for total in (0, 6, 24, 8192):
         for world in (1, 2, 3, 8):
+            if total % world:
+                with pytest.raises(_lib.DimensionMismatch):
+                    batch.shard_range(total, 0, world)
+                continue
             spans = [batch.shard_range(total, k, world) for k in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[k][1] == spans[k + 1][0] for k in range(world - 1))
+            assert len({hi - lo for lo, hi in spans}) == 1
+    for total, world in ((7, 2), (8192, 3), (1, 8)):
+        with pytest.raises(_lib.DimensionMismatch):
+            batch.shard_range(total, world - 1, world)
+    with pytest.raises(_lib.ArgumentError):
+        batch.shard_range(8, 2, 2)
     off, L = batch.slab_layout(128, 16)
     assert L == 8256 + 128 + 1 + 2048 + 16 and off["C"] == 8385

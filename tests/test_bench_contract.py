@@ -70,7 +70,8 @@ def test_line_ends_with_the_contract_objects_and_a_compact_summary():
                        "C5": {"ms_per_step": 0.03, "roofline": {"frac": 0.55}}, "C4_sharded": {"ms_per_step": 0.45, "rccl_calls_made": True}},
            "host_api": {"handoff_device": {"ms_per_solve": 1.29}, "handoff_host_csc": {"ms_per_solve": 1.73}, "handoff_moi": {"ms_per_solve": 4.7},
                         "c3_host_csc": {"ms_per_solve": 1.97}},
-           "roofline_constraint_pack": {"frac": 0.63, "in_step": {"frac": 0.44, "rocprofv3": {"frac": 0.55}}},
+           "roofline_constraint_pack": {"frac": 0.63, "in_step": {"hip_events": {"frac": 0.40}, "device_clock": {"frac": 0.44, "measured_in_this_run": True},
+                                                                  "rocprofv3_replayed": {"frac": 0.55, "measured_in_this_run": False}}},
            "roofline_affine": {"frac": 0.8, "cold": {"frac": 0.6}}, "cpu_baseline": {"value": 0.004, "sample": "z" * 500}, "ranks_seen": 1}
     res = bench.ordered_for_the_tail(out)
     assert set(res) == set(out) | {"summary"}
@@ -80,7 +81,7 @@ def test_line_ends_with_the_contract_objects_and_a_compact_summary():
     for k in ("C3_ms", "C4_ms", "C4_frac", "C5_ms", "C5_frac", "host_csc_ms", "moi_ms", "device_ms", "pack_in_step_frac", "affine_warm_frac", "affine_cold_frac",
               "ranks_seen", "rccl_calls_made", "gram_frac", "value", "ms_per_step"):
         assert k in s, k
-    assert s["pack_in_step_frac"] == 0.55 and s["C4_frac"] == 0.54 and s["host_csc_ms"] == 1.73 and s["rccl_calls_made"] is True
+    assert s["pack_in_step_frac"] == 0.44 and s["pack_in_step_frac_rocprof_replayed"] == 0.55 and s["C4_frac"] == 0.54 and s["host_csc_ms"] == 1.73 and s["rccl_calls_made"] is True
     text = json.dumps(res)
     tail = text[-2000:]
     assert '"summary"' in tail and '"roofline"' in tail and len(json.dumps(s)) < 1200
@@ -102,3 +103,65 @@ def test_stdout_carries_the_json_line_only(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "m", "value": 1}
     assert "banner" in r.stderr and "a python print somewhere" in r.stderr
+
+
+# ---- `--gpus N` launches N ranks by itself ----------------------------------------------------------------------
+
+def _run_bench(*argv, env=None, timeout=180):
+    import os
+    import subprocess
+    root = str(__import__("pathlib").Path(bench.__file__).parent)
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, "bench.py"] + list(argv), capture_output=True, text=True, cwd=root, env=e, timeout=timeout)
+
+
+def _only_line(r):
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_gpus_n_dry_launch_prints_the_exact_command():
+    r = _run_bench("--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-launch")
+    assert r.returncode == 0, r.stderr
+    line = _only_line(r)
+    cmd = line["launch"]
+    assert line["n_gpus"] == 2 and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    k = [i for i, a in enumerate(cmd) if a.endswith("bench.py")][0]
+    assert cmd[k + 1:] == ["--gpus", "2", "--steps", "20", "--warmup", "5"]          # the same argv, minus --dry-launch
+
+
+def test_gpus_n_refuses_when_fewer_gpus_are_visible():
+    """`python bench.py --gpus 2` on a box with fewer than two GPUs: rc != 0 and ONE JSON object naming the device count — never a line
+    that says n_gpus: 1"""
+    from parametron_jl_amd import _lib
+    have = int(_lib.load().pmt_device_count())
+    if have >= 2:
+        pytest.skip("two GPUs visible")
+    r = _run_bench("--gpus", "2", "--steps", "5", "--warmup", "1")
+    assert r.returncode != 0
+    line = _only_line(r)
+    assert "error" in line and line["gpus_requested"] == 2 and line["gpus_visible"] == have
+    assert "value" not in line and "n_gpus" not in line and "metric" not in line
+
+
+def test_gpus_n_launches_n_ranks_by_itself():
+    """the launcher path end to end without a GPU: `--gpus 2 --workload launch-check` starts two ranks (torch.distributed.run, gloo), they
+    count themselves, rank 0 alone prints"""
+    r = _run_bench("--gpus", "2", "--workload", "launch-check", env={"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _only_line(r)
+    assert line == {"launch_check": True, "n_gpus": 2, "ranks_seen": 2, "gpus_requested": 2}
+
+
+def test_world_size_must_match_gpus():
+    """a launcher that starts a different number of ranks than --gpus names: an error object, rc != 0"""
+    r = _run_bench("--gpus", "8", "--workload", "launch-check", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    line = _only_line(r)
+    assert "error" in line and line["gpus_requested"] == 8 and line["world_size"] == 1
