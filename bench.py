@@ -353,6 +353,99 @@ def config_c3(torch, P, _lib, steps):
     return out
 
 
+def config_c1(torch, P, _lib, steps=400):
+    """BASELINE config 1 — README Example 1 (n = 8, m = 2, literal objective), the one configuration the reference publishes a number for
+    (README.md:132-136: solve! 51.863 us including OSQP; the update! share is ~15 us on one CPU core).  Through the host API
+    with device-side Parameter callbacks; Model.initialize records callbacks + tape and the library replays them as ONE launch (small plan,
+    csrc/small.hip).  update_us = host wall time per update!(model) in a pipelined loop (setdirty! + seeds + one launch, no MOI fetch);
+    kernel_us = HIP-event time of that launch; the same plan replayed as recorded (9 launches) beside it."""
+    model = P.Model(P.MockOptimizer(), quadratic_mode="literal")
+    n, m = 8, 2
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((n, n), 1, model); b = P.DeviceUniformParameter((n,), 2, model)
+    Cm = P.DeviceUniformParameter((m, n), 3, model); d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    r = A * x - b
+    P.objective(model, P.Minimize, P.dot(r, r)); P.constraint(model, Cm * x == d)
+    P.solve(model)
+    ctx = model.device()
+
+    def upd():
+        model.setdirty(); model._run_tape(fetch=False)
+
+    def wall(fn, k):
+        for _ in range(50):
+            fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / k * 1e6
+
+    def kernel_us():
+        _lib.call("pmt_profile_enable", 1)
+        for _ in range(50):
+            upd()
+        ctx.synchronize()
+        rep = profile_report(_lib)
+        _lib.call("pmt_profile_enable", 0)
+        return {k: v["avg_ms"] * 1e3 for k, v in rep.items()}
+    fz = ctx.fused()
+    out = {"workload": "C1 README Example 1: n=8 variables, A 8x8, m=2 equality rows, literal objective, device-side rand! callbacks",
+           "fused": fz, "tape_entries": ctx.tape_length()}
+    out["update_us"] = wall(upd, steps)
+    out["plan_update_us"] = wall(ctx.replay, steps)            # the C-ABI call alone (pmt_plan_update), seeds unchanged
+    out["kernel_us"] = kernel_us()
+    ctx.synchronize()
+    ctx.set_fusion(False)
+    out["unfused"] = {"update_us": wall(upd, steps), "plan_update_us": wall(ctx.replay, steps), "kernel_us": kernel_us(), "launches": ctx.fused()["exec_length"]}
+    ctx.set_fusion(True)
+    out["reference"] = {"solve_us_incl_osqp": 51.863, "update_us_estimate": 15.0,
+                        "source": "README.md:132-136 (BenchmarkTools median of solve!, other hardware); the update! share per BASELINE.md section 1"}
+    model.close()
+    return out
+
+
+TALL_SHAPES = ((1 << 20, 128), (262144, 512), (65536, 1024), (8192, 128))
+
+
+def config_tall(torch, _lib, steps=20):
+    """The Gram node (pmt_quad_gram_f64: Q, q, constant) on tall least-squares shapes — rows >> columns, the usual shape of README.md:34-38
+    with real data.  Per shape: node time, the algorithmic flops r n (n + 1) against the f64 MFMA peak and the algorithmic bytes
+    (8 r n read + 24 n (n + 1) / 2 written) against HBM; `binding` names the roofline whose algorithmic time is longer."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    from parametron_jl_amd.device import padded_lda
+    out = {}
+    for r, n in TALL_SHAPES:
+        lda = padded_lda(r)
+        A = torch.empty(lda * n, dtype=torch.float64, device=dev); b = torch.empty(r, dtype=torch.float64, device=dev)
+        _lib.call("pmt_fill_uniform_matrix_f64", dptr(A), r, n, lda, 1, 1.0, stream); _lib.call("pmt_fill_uniform_f64", dptr(b), r, 2, 1.0, stream)
+        xvar = torch.arange(1, n + 1, dtype=torch.int64, device=dev)
+        nq = n * (n + 1) // 2
+        Q = torch.empty(nq * 3, dtype=torch.int64, device=dev); q = torch.empty(n * 2, dtype=torch.int64, device=dev)
+        c = torch.empty(1, dtype=torch.float64, device=dev)
+        ws = torch.empty(max(1, _lib.load().pmt_quad_gram_workspace_bytes(r, n) // 8), dtype=torch.float64, device=dev)
+
+        def run():
+            _lib.call("pmt_quad_gram_f64", dptr(A), lda, r, n, dptr(xvar), dptr(b), -1, 1, dptr(xvar), dptr(Q), dptr(q), dptr(c), dptr(ws), stream)
+        for _ in range(10):
+            run()
+        t = timed_loop(torch, run, steps) / steps
+        _lib.call("pmt_profile_enable", 1)
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        kern = {k: v["avg_ms"] for k, v in profile_report(_lib).items()}
+        _lib.call("pmt_profile_enable", 0)
+        flops, nbytes = float(r) * n * (n + 1), 8.0 * r * n + 24.0 * nq
+        t_mfma, t_hbm = flops / (F64_MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+        out["%dx%d" % (r, n)] = {"node_ms": t * 1e3, "mfma_frac": t_mfma / t, "hbm_frac": t_hbm / t, "binding": "mfma" if t_mfma >= t_hbm else "hbm",
+                                 "frac": max(t_mfma, t_hbm) / t, "tflops": flops / t / 1e12, "A_TBps": 8.0 * r * n / t / 1e12, "kernels_ms": kern}
+        del A, b, Q, q, ws
+    return out
+
+
 def config_c4(torch, _lib, steps):
     from parametron_jl_amd import batch
     total, n, r, m = 8192, 128, 128, 16
@@ -500,28 +593,29 @@ def host_api_c2(torch, P, steps):
 
 def pack_in_step_stamps(torch, _lib, wl, step, steps):
     """affine_tile_kernel<VAT> INSIDE the step, by the device's own constant-rate clock: every workgroup of the launch reports min(start) /
-    max(end) of wall_clock64 into three device words (pmt_profile_kernel_stamps) — the kernel's own duration without the in-stream gap a
+    max(end) of wall_clock64 — one slot per workgroup (pmt_profile_kernel_stamps), reduced on the host — the kernel's own duration without the in-stream gap a
     HIP-event pair around an in-step launch includes.  Measured in this run, `steps` steps, one read-back per step (outside any timing)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     khz = C.c_int()
     _lib.call("pmt_device_clock_khz", torch.cuda.current_device(), C.byref(khz))
     rate_khz = khz.value
-    words = torch.zeros(3, dtype=torch.int64, device=dev)
-    init = torch.tensor([-1, 0, 0], dtype=torch.int64, device=dev)       # word 0: UINT64_MAX
+    cap = 4096
+    words = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
     durs, wgs = [], 0
-    _lib.call("pmt_profile_kernel_stamps", dptr(words))
+    _lib.call("pmt_profile_kernel_stamps", dptr(words), cap)
     try:
         for _ in range(steps):
-            words.copy_(init)
+            words.zero_()
             step()
             torch.cuda.synchronize()
-            w = words.cpu().numpy().view("uint64")
-            if int(w[2]) == 0:
+            w = words.cpu().numpy().view("uint64").reshape(cap, 2)
+            w = w[w[:, 1] != 0]
+            if len(w) == 0:
                 continue
-            durs.append((int(w[1]) - int(w[0])) / (rate_khz * 1e3))          # seconds
-            wgs = int(w[2])
+            durs.append((int(w[:, 1].max()) - int(w[:, 0].min())) / (rate_khz * 1e3))          # seconds
+            wgs = len(w)
     finally:
-        _lib.call("pmt_profile_kernel_stamps", None)
+        _lib.call("pmt_profile_kernel_stamps", None, 0)
     if not durs:
         return {"error": "no workgroup of affine_tile_kernel<VAT> reported"}
     durs.sort()
@@ -970,8 +1064,9 @@ def main():
         wl.close()          # the plan and its side stream go before the other configurations create theirs (streams share hardware queues)
         if not args.no_configs:
             ksteps = max(50, min(args.steps, 100))      # (at least 50 steps: 20 steps of a 1.3 ms configuration are 26 ms, too short to average out a box hiccup)
-            out["configs"] = {"C3": guarded(config_c3, torch, P, _lib, ksteps), "C4": guarded(config_c4, torch, _lib, ksteps),
-                              "C5": guarded(config_c5, torch, P, _lib, ksteps)}
+            out["configs"] = {"C1": guarded(config_c1, torch, P, _lib), "C3": guarded(config_c3, torch, P, _lib, ksteps),
+                              "C4": guarded(config_c4, torch, _lib, ksteps), "C5": guarded(config_c5, torch, P, _lib, ksteps),
+                              "tall": guarded(config_tall, torch, _lib)}
             out["host_api"] = guarded(host_api_c2, torch, P, 10)
         out["cpu_baseline"] = None if args.no_cpu_baseline else guarded(cpu_baseline, wl)
         out["cpu_canonical_blas"] = None if args.no_cpu_baseline else guarded(cpu_canonical_blas, wl)
@@ -1034,7 +1129,8 @@ def summary_of(out):
         # measured in this run only: the device-clock figure, else the HIP-event lower bound; the replay of a committed profile has its own key
         "pack_in_step_frac": _get(pack, "in_step", "device_clock", "frac") or _get(pack, "in_step", "rocprofv3", "frac") or _get(pack, "in_step", "hip_events", "frac"),
         "pack_in_step_frac_rocprof_replayed": _get(pack, "in_step", "rocprofv3_replayed", "frac"),
-        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"),
+        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
+        "tall_frac": {k: round(v["frac"], 3) for k, v in (c.get("tall") or {}).items() if isinstance(v, dict) and "frac" in v} or None,
         "affine_warm_frac": _get(out, "roofline_affine", "frac"), "affine_cold_frac": _get(out, "roofline_affine", "cold", "frac"),
         "cpu_baseline_value": _get(out, "cpu_baseline", "value"), "ranks_seen": out.get("ranks_seen"),
     }

@@ -416,6 +416,11 @@ int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, double scale, vo
  * contiguous stream.  Device copies of Parameter matrices whose column stride would be a multiple of 4 KiB are kept with a padded
  * lda: a power-of-two stride puts every column segment of a tile on the same memory channel. */
 int pmt_fill_uniform_matrix_f64(double *dst, int64_t rows, int64_t cols, int64_t lda, uint64_t seed, double scale, void *stream);
+/* The matrix fill with the seed read from the HOST word *seed_word at every launch — recorded into a plan, at every replay: a recorded
+ * Parameter callback (README.md:36-43 rand!, new values at every update!) advances by the host storing the next seed into the word before
+ * pmt_plan_update, with no call of its own and, in a small plan, no launch of its own.  cols == 1, lda == rows: a vector.  The word must
+ * outlive the plan's tape.  A tape holding such an entry is not captured into a hipGraph. */
+int pmt_fill_uniform_dyn_f64(double *dst, int64_t rows, int64_t cols, int64_t lda, const uint64_t *seed_word, double scale, void *stream);
 /* the same stream from element index_offset on: dst[i] = scale * U(seed, index_offset + i) (shard of a larger array) */
 int pmt_fill_uniform_offset_f64(double *dst, int64_t n, uint64_t seed, uint64_t index_offset, double scale, void *stream);
 
@@ -431,10 +436,11 @@ int pmt_profile_enable(int on);
 int pmt_profile_filter(const char *substring);
 int64_t pmt_profile_report(char *host_buf, size_t cap);
 /* Measurement hook for ONE kernel inside a step, without the in-stream gap a HIP-event pair around an in-step launch includes: while
- * `device_words3` (three zero-initialisable uint64 words in device memory, word 0 preset to UINT64_MAX) is set, every workgroup of the
- * MOI pack kernel (affine_tile_kernel<VAT>, pmt_affine_pack_vector_f64) reports min(start), max(end) of the constant-rate device clock
- * (wall_clock64, hipDeviceAttributeWallClockRate kHz) and counts itself.  NULL (the default) switches it off: one uniform branch. */
-int pmt_profile_kernel_stamps(void *device_words3);
+ * `device_words` (2 * workgroups uint64 words in device memory, zeroed by the caller) is set, workgroup w < `workgroups` of the MOI pack
+ * kernel (affine_tile_kernel<VAT>, pmt_affine_pack_vector_f64) stores its start / end on the constant-rate device clock (wall_clock64)
+ * into words 2w, 2w + 1; the launch ran from the smallest start to the largest end.  NULL or 0 (the default) switches it off: one
+ * uniform branch. */
+int pmt_profile_kernel_stamps(void *device_words, int64_t workgroups);
 /* rate of that clock in kHz (hipDeviceAttributeWallClockRate) */
 int pmt_device_clock_khz(int device, int *khz);
 
@@ -577,6 +583,17 @@ int pmt_plan_set_lane(pmt_plan *plan, int lane);
 int pmt_plan_lane_stream(pmt_plan *plan, int lane, void **out_stream);
 void *pmt_plan_recording_stream(pmt_plan *plan);
 int64_t pmt_plan_tape_length(const pmt_plan *plan);
+/* SMALL PLANS.  The reference walks a model's lazy-expression DAG at nanoseconds per hop (src/lazyexpression.jl:50-61; README Example 1
+ * re-evaluates in ~15 us on a CPU core, README.md:132-136); a tape replay pays one kernel launch (~5 us) per hop whatever its size.
+ * pmt_plan_end_record therefore replaces every run of two or more consecutive SMALL entries of the tape (lane 0; pmt_fill_uniform_*,
+ * pmt_affine_assemble_f64, pmt_affine_pack_vector_f64, pmt_quad_expand_f64, pmt_vars_addsub_f64, pmt_consts_f64, pmt_pack_*_f64,
+ * pmt_copy_bytes, each writing at most 32768 elements, a run at most 65536) by ONE launch of an interpreter kernel that executes the
+ * run's nodes in tape order with a workgroup barrier between them (csrc/small.hip).  Every element is computed by the same expression
+ * as in the entry's own kernel: outputs are bit-identical.  Automatic; larger entries and everything else replay as recorded.
+ *   pmt_plan_set_fusion  0: replay the tape as recorded (A/B and tests); 1 (default): fuse.  Not while recording / after graph capture.
+ *   pmt_plan_fused       number of fused runs, tape entries they replace, and launches-or-entries one replay executes */
+int pmt_plan_set_fusion(pmt_plan *plan, int on);
+int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_length);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
  * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */
 int pmt_plan_update(pmt_plan *plan);

@@ -62,6 +62,14 @@ synchronize(plan::Plan) = check(ccall((:pmt_plan_synchronize, lib), Cint, (Ptr{C
 recording_stream(plan::Plan) = ccall((:pmt_plan_recording_stream, lib), Ptr{Cvoid}, (Ptr{Cvoid},), plan.handle)
 begin_record!(plan::Plan) = check(ccall((:pmt_plan_begin_record, lib), Cint, (Ptr{Cvoid},), plan.handle))
 end_record!(plan::Plan) = check(ccall((:pmt_plan_end_record, lib), Cint, (Ptr{Cvoid},), plan.handle))
+"small plans: runs of small tape entries replay as ONE launch (automatic); `fusion!(plan, false)` replays the tape as recorded"
+fusion!(plan::Plan, on::Bool) = check(ccall((:pmt_plan_set_fusion, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, on ? 1 : 0))
+"(fused runs, tape entries they replace, launches-or-entries per replay)"
+function fused(plan::Plan)
+    g = Ref{Cint}(0); n = Ref{Cint}(0); len = Ref{Int64}(0)
+    check(ccall((:pmt_plan_fused, lib), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ref{Int64}), plan.handle, g, n, len))
+    Int(g[]), Int(n[]), len[]
+end
 "while recording: lane 1 = the following calls only read Parameter values and are independent of the rest of the tape (side lane), 0 = back"
 set_lane!(plan::Plan, lane::Integer) = check(ccall((:pmt_plan_set_lane, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, lane))
 "One update!(model) worth of kernels (src/model.jl:132-143): replays the tape, no allocation."
@@ -319,6 +327,11 @@ batch_step!(comm::Ptr{Cvoid}, A::DevPtr, b::DevPtr, C::DevPtr, d::DevPtr, per_ra
     check(ccall((:pmt_batch_step_f64, lib), Cint,
                 (Ptr{Cvoid}, DevPtr, DevPtr, DevPtr, DevPtr, Int64, Int64, Int64, Int64, Cint, Cint, DevPtr, DevPtr, Int64, Int64, Ptr{Cvoid}),
                 comm, A, b, C, d, per_rank, n, r, m, -1, -1, local_slabs, gathered, stride, chunk, stream))
+
+"the same callback RECORDED with its seed in a host word (`Ref{UInt64}`, kept alive by the caller): every replay draws the stream of the
+seed the word holds then — `seed[] += 1000` before `update!(plan)` is the whole callback"
+device_uniform_dyn!(dst::DevPtr, rows, cols, lda, seed::Ref{UInt64}, scale, stream) =
+    check(ccall((:pmt_fill_uniform_dyn_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, Ref{UInt64}, Cdouble, Ptr{Cvoid}), dst, rows, cols, lda, seed, scale, stream))
 
 "device-side `rand!` Parameter callback (README.md:36-43): U[0,1)*scale, counter based"
 device_uniform!(dst::DevPtr, n, seed, scale, stream) =

@@ -119,7 +119,7 @@ SIGNATURES = {
     "pmt_fill_uniform_offset_f64": (_ci, [_vp, _i64, _u64, _u64, _f64, _vp]),
     "pmt_profile_enable": (_ci, [_ci]),
     "pmt_profile_filter": (_ci, [C.c_char_p]),
-    "pmt_profile_kernel_stamps": (_ci, [_vp]),
+    "pmt_profile_kernel_stamps": (_ci, [_vp, _i64]),
     "pmt_device_clock_khz": (_ci, [_ci, C.POINTER(_ci)]),
     "pmt_profile_report": (_i64, [C.c_char_p, _sz]),
     "pmt_plan_create": (_ci, [_ci, _vp, C.POINTER(_vp)]),
@@ -151,6 +151,9 @@ SIGNATURES = {
     "pmt_plan_lane_stream": (_ci, [_vp, _ci, C.POINTER(_vp)]),
     "pmt_plan_recording_stream": (_vp, [_vp]),
     "pmt_plan_tape_length": (_i64, [_vp]),
+    "pmt_plan_set_fusion": (_ci, [_vp, _ci]),
+    "pmt_plan_fused": (_ci, [_vp, C.POINTER(_ci), C.POINTER(_ci), C.POINTER(_i64)]),
+    "pmt_fill_uniform_dyn_f64": (_ci, [_vp, _i64, _i64, _i64, C.POINTER(_u64), _f64, _vp]),
     "pmt_plan_update": (_ci, [_vp]),
     "pmt_plan_instantiate_graph": (_ci, [_vp]),
 }

@@ -48,13 +48,15 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
     const double *__restrict__ A, int64_t lda, int64_t rows, int64_t cols,
     const int64_t *__restrict__ xvar, const double *__restrict__ b, int sign,
     const int64_t *__restrict__ varmap, int64_t row_offset,
-    u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out, u64 *stamps) {
+    u64 *__restrict__ out, double *__restrict__ out_consts, int vec_in, int vec_out, u64 *stamps, unsigned stamp_cap) {
     __shared__ double tile[TR * PITCH];
     __shared__ u64 vmx[TILE];
 
     const int t = threadIdx.x;
-    // measurement hook (pmt_profile_kernel_stamps; null in production): earliest workgroup start of the launch, constant 100 MHz clock
-    if (stamps && t == 0) atomicMin(stamps, (u64)wall_clock64());
+    // measurement hook (pmt_profile_kernel_stamps; null in production): this workgroup's start on the device's constant-rate clock, into
+    // its own slot (plain stores — atomics of a thousand workgroups on one word serialise and triple the launch)
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (stamps && t == 0 && wg < stamp_cap) stamps[2 * wg] = (u64)wall_clock64();
     const int lane = t & 63;
     const int wave = t >> 6;
     const int64_t c0 = (int64_t)blockIdx.x * TILE;
@@ -142,10 +144,9 @@ __global__ __launch_bounds__(256) void affine_tile_kernel(
     }
     if (stamps) {                    // ... and the latest workgroup end, behind this workgroup's stores
         __syncthreads();
-        if (t == 0) {
+        if (t == 0 && wg < stamp_cap) {
             __builtin_amdgcn_s_waitcnt(0);
-            atomicMax(stamps + 1, (u64)wall_clock64());
-            atomicAdd(stamps + 2, (u64)1);
+            stamps[2 * wg + 1] = (u64)wall_clock64();
         }
     }
 }
@@ -288,8 +289,9 @@ static bool env_nt() {
 #endif
 }
 
-// pmt_profile_kernel_stamps: device words {min start, max end, workgroups} the affine tile kernel of the NEXT launches reports into
+// pmt_profile_kernel_stamps: device words {start, end} per workgroup the affine tile kernel of the NEXT launches reports into
 static u64 *g_stamps = nullptr;
+static unsigned g_stamp_cap = 0;
 
 template <int MODE>
 static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,
@@ -305,7 +307,7 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
     u64 *stamps = MODE == 1 ? g_stamps : nullptr;
 #define AFFINE_LAUNCH(NTV, TRV, NTLV)                                                                                                    \
     PMT_LAUNCH_NAMED(name, (affine_tile_kernel<MODE, NTV, TRV, NTLV>), dim3((unsigned)cdiv(cols, TILE), (unsigned)cdiv(rows, TRV)), dim3(256), 0, s, A, \
-                     lda, rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out, stamps)
+                     lda, rows, cols, xvar, b, sign, varmap, row_offset, out, out_consts, vec_in, vec_out, stamps, g_stamp_cap)
     if constexpr (MODE == 1) {
         if (ntl) {
             if (small) AFFINE_LAUNCH(true, 32, true); else AFFINE_LAUNCH(true, 64, true);
@@ -322,8 +324,10 @@ static int launch_affine(const double *A, int64_t lda, int64_t rows, int64_t col
 
 using namespace pmt;
 
-extern "C" int pmt_profile_kernel_stamps(void *device_words3) {
-    g_stamps = reinterpret_cast<u64 *>(device_words3);
+extern "C" int pmt_profile_kernel_stamps(void *device_words, int64_t workgroups) {
+    PMT_REQUIRE(workgroups >= 0 && workgroups < ((int64_t)1 << 31), PMT_INVALID_ARGUMENT, "profile_kernel_stamps: bad capacity");
+    g_stamps = workgroups > 0 ? reinterpret_cast<u64 *>(device_words) : nullptr;
+    g_stamp_cap = g_stamps ? (unsigned)workgroups : 0;
     return PMT_OK;
 }
 
@@ -340,9 +344,12 @@ extern "C" int pmt_affine_assemble_f64(const double *A, int64_t lda, int64_t row
     if (cols == 0 && rows > 0 && out_consts)
         return b && sign ? pmt_consts_f64(b, rows, sign, out_consts, stream)
                          : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
+    SmallNode nd;
+    nd.op = SOP_AFFINE_LT; nd.sign = sign; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols; nd.d[3] = 0;
+    nd.in[0] = A; nd.in[1] = xvar; nd.in[2] = b; nd.out[0] = out_terms; nd.out[1] = out_consts; nd.work = rows * cols + rows;
     return dispatch(stream, [=](hipStream_t s) {
         return launch_affine<0>(A, lda, rows, cols, xvar, b, sign, nullptr, 0, out_terms, out_consts, s);
-    });
+    }, nd);
 }
 
 extern "C" int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
@@ -353,9 +360,12 @@ extern "C" int pmt_affine_pack_vector_f64(const double *A, int64_t lda, int64_t 
     if (cols == 0 && rows > 0 && out_consts)
         return b && sign ? pmt_consts_f64(b, rows, sign, out_consts, stream)
                          : dispatch(stream, [=](hipStream_t s) { PMT_HIP_CHECK(hipMemsetAsync(out_consts, 0, rows * sizeof(double), s)); return PMT_OK; });
+    SmallNode nd;
+    nd.op = SOP_AFFINE_VAT; nd.sign = sign; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols; nd.d[3] = row_offset;
+    nd.in[0] = A; nd.in[1] = xvar; nd.in[2] = b; nd.in[3] = varmap; nd.out[0] = out_terms; nd.out[1] = out_consts; nd.work = rows * cols + rows;
     return dispatch(stream, [=](hipStream_t s) {
         return launch_affine<1>(A, lda, rows, cols, xvar, b, sign, varmap, row_offset, out_terms, out_consts, s);
-    });
+    }, nd);
 }
 
 extern "C" int pmt_affine_pack_vector_background_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b,
@@ -386,21 +396,26 @@ extern "C" int pmt_vars_addsub_f64(const int64_t *xvar, int64_t n, const double 
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(xvar, PMT_INVALID_ARGUMENT, "vars_addsub: null xvar");
     PMT_REQUIRE(sign == 0 || v, PMT_INVALID_ARGUMENT, "vars_addsub: sign != 0 needs v");
+    SmallNode nd;
+    nd.op = SOP_VARS_ADDSUB; nd.sign = sign; nd.d[0] = n; nd.d[1] = row_offset; nd.in[0] = xvar; nd.in[1] = v; nd.in[2] = varmap;
+    nd.out[0] = out_terms_lt; nd.out[1] = out_terms_vat; nd.out[2] = out_consts; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(vars_addsub_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, xvar, n, v, sign, varmap, row_offset,
                            out_terms_lt, out_terms_vat, out_consts);
         return check_launch("vars_addsub_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_consts_f64(const double *d, int64_t n, int sign, double *out, void *stream) {
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "consts: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(d && out, PMT_INVALID_ARGUMENT, "consts: null pointer");
+    SmallNode nd;
+    nd.op = SOP_CONSTS; nd.sign = sign; nd.d[0] = n; nd.in[0] = d; nd.out[0] = out; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(consts_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d, n, sign, out);
         return check_launch("consts_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_pack_scalar_affine_f64(const pmt_linear_term *terms, int64_t n, const int64_t *varmap, pmt_linear_term *out_terms,
@@ -408,10 +423,12 @@ extern "C" int pmt_pack_scalar_affine_f64(const pmt_linear_term *terms, int64_t 
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "pack_scalar_affine: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(terms && out_terms, PMT_INVALID_ARGUMENT, "pack_scalar_affine: null pointer");
+    SmallNode nd;
+    nd.op = SOP_PACK_SA; nd.d[0] = n; nd.in[0] = terms; nd.in[1] = varmap; nd.out[0] = out_terms; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(pack_scalar_affine_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, terms, n, varmap, out_terms);
         return check_launch("pack_scalar_affine_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int64_t nq, const int64_t *varmap,
@@ -419,11 +436,13 @@ extern "C" int pmt_pack_scalar_quadratic_f64(const pmt_quadratic_term *quad, int
     PMT_REQUIRE(nq >= 0, PMT_DIMENSION_MISMATCH, "pack_scalar_quadratic: negative length");
     if (nq == 0) return PMT_OK;
     PMT_REQUIRE(quad && out_quad, PMT_INVALID_ARGUMENT, "pack_scalar_quadratic: null pointer");
+    SmallNode nd;
+    nd.op = SOP_PACK_SQ; nd.d[0] = nq; nd.in[0] = quad; nd.in[1] = varmap; nd.out[0] = out_quad; nd.work = nq;
     return dispatch(stream, [=](hipStream_t s) {
         const int aligned = (((reinterpret_cast<uintptr_t>(quad) | reinterpret_cast<uintptr_t>(out_quad)) & 15) == 0) ? 1 : 0;
         PMT_LAUNCH(pack_scalar_quadratic_kernel, dim3((unsigned)cdiv(nq, 256)), dim3(256), 0, s, quad, nq, varmap, out_quad, aligned);
         return check_launch("pack_scalar_quadratic_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const int64_t *row_ptr, int64_t rows, int64_t row_len,
@@ -431,9 +450,14 @@ extern "C" int pmt_pack_vector_affine_f64(const pmt_linear_term *terms, const in
     PMT_REQUIRE(rows >= 0 && row_len >= 0, PMT_DIMENSION_MISMATCH, "pack_vector_affine: negative dimension");
     if (rows == 0) return PMT_OK;
     PMT_REQUIRE((terms && out_terms) || (!row_ptr && row_len == 0), PMT_INVALID_ARGUMENT, "pack_vector_affine: null pointer");
+    SmallNode nd;
+    nd.op = SOP_PACK_VA; nd.d[0] = rows; nd.d[1] = row_len; nd.d[2] = row_offset; nd.in[0] = terms; nd.in[1] = row_ptr; nd.in[2] = varmap;
+    nd.out[0] = out_terms;
+    // (ragged rows: the term count is on the device; such a node joins a group only when its row count alone bounds it)
+    nd.work = row_ptr ? SMALL_NODE_WORK_MAX + 1 : rows * row_len;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(pack_vector_affine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, terms, row_ptr, rows, row_len, varmap,
                            row_offset, out_terms);
         return check_launch("pack_vector_affine_kernel");
-    });
+    }, nd);
 }

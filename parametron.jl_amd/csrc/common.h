@@ -34,6 +34,30 @@ int fail(int code, const std::string &msg);
 // appended to that plan's tape (plan.cpp).
 using Launch = std::function<int(hipStream_t)>;
 int dispatch(void *stream, Launch launch);
+
+// Small plans (small.hip): the reference walks a tiny model's DAG in nanoseconds per hop (src/lazyexpression.jl:50-61); on the device every
+// hop is a kernel launch of ~5 us.  An entry point whose work can also be described by a SmallNode records the description beside its
+// closure; pmt_plan_end_record then replaces every run of consecutive small nodes by ONE launch of an interpreter kernel that executes
+// them in tape order with a workgroup barrier between dependent nodes.  Outputs are bit-identical to the separate kernels.
+enum SmallOp : int {
+    SOP_FILL = 1, SOP_AFFINE_LT, SOP_AFFINE_VAT, SOP_QUAD_EXPAND, SOP_VARS_ADDSUB, SOP_CONSTS, SOP_PACK_SA, SOP_PACK_SQ, SOP_PACK_VA, SOP_COPY8
+};
+struct SmallNode {
+    int op = 0, sign = 0, moi = 0;
+    int dyn = -1;                   // slot of the launch's dynamic-seed table (SOP_FILL with a host seed word), or -1
+    int64_t d[4] = {0, 0, 0, 0};
+    const void *in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *out[3] = {nullptr, nullptr, nullptr};
+    double scale = 0.0;
+    uint64_t seed = 0;
+    // host side only
+    int64_t work = 0;               // elements written (the grouping bound)
+    const uint64_t *seed_host = nullptr;
+};
+constexpr int SMALL_MAX_DYN = 16;
+constexpr int64_t SMALL_NODE_WORK_MAX = 32768;       // a node writing more than this many elements is launched on its own
+constexpr int64_t SMALL_GROUP_WORK_MAX = 65536;      // ... and a group is cut before it exceeds this
+int dispatch(void *stream, Launch launch, const SmallNode &node);
 bool is_recording_handle(void *stream);        // `stream` is a plan's recording handle, not a HIP stream
 
 // Per-kernel timing (the analogue of the reference's per-node `findallocs` report, src/debug.jl:4-23): when enabled

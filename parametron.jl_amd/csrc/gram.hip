@@ -36,6 +36,11 @@ void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
                    unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s);
+bool gram_tall_applies(int64_t rows, int64_t cols);
+size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols);
+int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
+                     const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
+                     double *out_const, void *workspace, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
 // a CSC delivery computes the tiles column band by column band (super-columns of ONE tile column: a band's completion is never held back by
@@ -412,9 +417,11 @@ hipStream_t side_stream_of(hipStream_t s) {
 using namespace pmt;
 
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
-    // behind the contraction's partial tiles: chunk sums of q (tall matrices) and the chains of the constant (long vectors)
-    return gram_sk_workspace_bytes(rows, cols) + sizeof(double) * ((size_t)linear_splits(rows, cols) * (size_t)std::max<int64_t>(cols, 0) +
-                                                                   blocked_dot_scratch_doubles());
+    // behind the contraction's partial tiles: chunk sums of q (tall matrices) and the chains of the constant (long vectors); the fused
+    // tall form (gram_tall.hip) keeps its per-chunk partials in the same buffer
+    return std::max(gram_tall_workspace_bytes(rows, cols),
+                    gram_sk_workspace_bytes(rows, cols) + sizeof(double) * ((size_t)linear_splits(rows, cols) * (size_t)std::max<int64_t>(cols, 0) +
+                                                                            blocked_dot_scratch_doubles()));
 }
 
 // the signals of one recorded delivery: a dependency signal per band group (a one-thread kernel behind the stage that completes the group
@@ -548,6 +555,11 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
         mark_no_graph(stream);
     }
+    // tall one-tile shapes: triangle, q and c'c in ONE pass over A (gram_tall.hip); no side stream, no separate reductions
+    if (!deliver_host && cols > 0 && gram_tall_applies(rows, cols) && workspace)
+        return dispatch(stream, [=](hipStream_t s) {
+            return launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
+        });
     return dispatch(stream, [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
         // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.

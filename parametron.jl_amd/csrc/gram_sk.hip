@@ -488,6 +488,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                 const int keep = first ? 0 : 1;
                 const int ftid = sk_fresh_tid();                                 // (fresh: nothing of this is live across the stage loop)
                 const int mywr = __builtin_amdgcn_readfirstlane(ftid >> 6) / C::NWC;          // wave-uniform: the two roles are scalar branches
+#if defined(PMT_SK_PAIR_RELAXED) && PMT_SK_PAIR_RELAXED      // round 4's form, kept for the A/B (profiles/r05_pair_fold.txt)
                 if (mywr != keep) {
                     double *w = g.ws + (int64_t)(2 * bid) * SLOT + ftid;
     #pragma unroll
@@ -521,6 +522,45 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                         asm volatile("" ::: "memory");
                     }
                 }
+#else
+                // The hand-off is ordered by the memory model, not by how gfx950 happens to treat write-through stores (round 4's form: relaxed
+                // agent-scope atomics + s_waitcnt): plain stores of the partial, the workgroup barrier (workgroup-scope happens-before to
+                // thread 0), ONE agent-scope RELEASE store of the flag by thread 0; the partner's thread 0 spins on relaxed loads, then ONE
+                // agent-scope ACQUIRE fence, the barrier, and plain loads by everybody (MI355X_MICROARCH.md, inter-workgroup visibility).
+                if (mywr != keep) {
+                    double *w = g.ws + (int64_t)(2 * bid) * SLOT + ftid;
+    #pragma unroll
+                    for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_store(&g.pair_flags[(first ? 0 : 512) + rtile], g.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned *other = &g.pair_flags[(first ? 512 : 0) + rtile];
+                    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                    double late = 0.0;
+                    while (__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.epoch) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > g.pair_timeout) { late = 1.0; break; }   // 2 s (100 MHz ticks)
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (late != 0.0 && g.error) __hip_atomic_store(g.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    lds[0][0][0] = late;                         // (the panels are idle between the stage loop and the epilogue)
+                }
+                __syncthreads();
+                const bool late = lds[0][0][0] != 0.0;
+                if (mywr == keep) {
+                    const double *w = g.ws + (int64_t)(2 * (bid ^ 1)) * SLOT + ftid;
+    #pragma unroll
+                    for (int r0 = 0; r0 < C::NACC; r0 += 4) {      // four loads in flight at a time (register budget)
+                        double other[4];
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) other[r] = w[(r0 + r) * C::NT];
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r0 + r] = late ? __builtin_nan("") : other[r] + acc[r0 + r];
+                        asm volatile("" ::: "memory");
+                    }
+                }
+#endif
                 whole = true;
                 hsel = keep;
             }

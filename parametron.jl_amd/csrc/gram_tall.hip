@@ -1,0 +1,402 @@
+// Canonical least-squares objective for TALL matrices (rows >> columns, at most 128 columns): the usual least-squares shape
+// (README.md:34-38 with many more residual rows than variables).  ONE pass over A produces everything the node needs:
+//   upper triangle of A'A (f64 MFMA), q = A'c and c'c (c = 0.0 (+|-) b), as per-workgroup partials over contiguous row chunks,
+// then one fix-up launch adds the partials in a fixed order and writes the MOI / native terms.
+//
+// Reference semantics replaced: _vecdot!/muladd! literal expansion (src/functions.jl:702-709,548-576) + canonicalize!
+// (src/functions.jl:381-386, src/util.jl:9-26) + update!(::MOI.ScalarQuadraticFunction) (src/moi_interop.jl:45-62): SURVEY Appendix A.3.
+//
+// Why a second form beside the stream-K kernel (gram_sk.hip): with one 128-column tile that kernel computes the full 128 x 128 square
+// (2 r n^2 FLOP for r n (n + 1) needed), its q and c'c are two more kernels that read A and b again, and the constant up to 8192 rows is a
+// one-wave chain.  2^20 x 128: 1.06 ms for 1.07 GB of A.  Here:
+//   * the triangle only: the 128 x 128 tile is 8 x 8 blocks of 16 x 16; the 36 blocks on and above the diagonal are dealt out NINE per
+//     wave to a 4-wave workgroup (one wave per SIMD; 36 accumulator registers per lane), each wave's set chosen so that it needs few
+//     distinct operand rows / columns from LDS.  Executed / needed flops = 36 * 256 / 8256 = 1.12 (the square: 1.98).
+//   * small workgroups (4 waves, ~35 KB LDS): several per CU, their barriers do not line up, the matrix pipes stay fed.
+//   * q and c'c ride along on the VALU: every thread adds c_i * A[i, j] for the 16-byte pieces it has just loaded, before they go to LDS.
+//   * A is read once.  At n = 128 the node needs 16 FLOP per byte of A, the chip delivers ~10: both pipes matter.
+// Summation order (fixed, restated by tests/test_gpu_fullsize_parity.py): rows in order inside a workgroup's chunk (MFMA k order for the
+// triangle; per-thread row pairs, then an 8-lane tree, for q and c'c), then the chunks in 16 interleaved slices, then the slices in order.
+#include "gram_common.h"
+
+// k-steps of a stage unrolled together: 1 = 156 VGPRs (three workgroups per CU), 4 = 220-226 (two)
+#ifndef PMT_TALL_UNROLL
+#define PMT_TALL_UNROLL 1
+#endif
+#ifndef PMT_TALL_WPS
+#define PMT_TALL_WPS 2
+#endif
+#ifndef PMT_TALL_MR
+#define PMT_TALL_MR 32
+#endif
+#ifndef PMT_TALL_ABL
+#define PMT_TALL_ABL 0
+#endif
+#ifndef PMT_TALL_PF
+#define PMT_TALL_PF 2          // stages the global loads run ahead of the MFMAs (1 or 2)
+#endif
+#ifndef PMT_TALL_MAXG
+#define PMT_TALL_MAXG 512
+#endif
+
+namespace pmt {
+
+constexpr int TBK = PMT_TALL_MR;            // rows per stage (one barrier per stage): every column piece a workgroup asks for is 8 * TBK contiguous bytes
+constexpr int TGP = TBK + 2;                // LDS pitch of a column: 2 mod 32 — the 16 columns x 2 k of a half-wave operand read fall on 32 distinct
+                                            // bank pairs, and even, so that the row pairs go to LDS as 16-byte stores
+constexpr int TSUB = TBK / 16;              // 16-row pieces of a column per stage
+constexpr int TCOLS = 128;                  // columns of the one tile
+constexpr int TBLK = 9;                     // 16 x 16 blocks per wave
+constexpr int TACC = TBLK * 4;              // accumulators per lane (4 rotations per block)
+constexpr int TPART = 4 * TACC * 64;        // doubles of triangle partial per workgroup (= 36 blocks x 256)
+constexpr int TSTRIDE = TPART + TCOLS + 8;  // + q partial + c'c partial (padded to 64 bytes)
+constexpr int TSLICES = 16;                 // interleaved slices of the fix-up sum
+constexpr int TALL_MAX_G = PMT_TALL_MAXG;             // workgroups (row chunks) at most
+constexpr int TALL_MIN_CHUNK = 64;          // rows per chunk at least
+
+// the 36 upper-triangular blocks (tm <= tn) of the 8 x 8 block grid, nine per wave:
+//   wave 0: rows {0,1,2} x cols {5,6,7}
+//   wave 1: rows {0,1,2} x cols {3,4}, and the triangle on {3,4}
+//   wave 2: the triangle on {0,1,2}, and row 3 x cols {5,6,7}
+//   wave 3: rows 4..7 x cols {5,6,7} on and above the diagonal
+// (local constexpr tables inside constexpr functions: usable from device code without a device-side definition; every use below has
+// compile-time arguments after unrolling)
+__host__ __device__ constexpr int tw_nr(int w) { constexpr int t[4] = {3, 5, 4, 4}; return t[w]; }
+__host__ __device__ constexpr int tw_nc(int w) { constexpr int t[4] = {3, 2, 6, 3}; return t[w]; }
+__host__ __device__ constexpr int tw_row(int w, int i) {          // i-th distinct block row of wave w
+    constexpr int t[4][5] = {{0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}, {0, 1, 2, 3, 0}, {4, 5, 6, 7, 0}};
+    return t[w][i];
+}
+__host__ __device__ constexpr int tw_col(int w, int i) {          // i-th distinct block column of wave w
+    constexpr int t[4][6] = {{5, 6, 7, 0, 0, 0}, {3, 4, 0, 0, 0, 0}, {0, 1, 2, 5, 6, 7}, {5, 6, 7, 0, 0, 0}};
+    return t[w][i];
+}
+__host__ __device__ constexpr int tw_blk(int w, int k, int which) {   // block k of wave w: (index into its rows, index into its columns)
+    constexpr int t[4][TBLK][2] = {
+        {{0, 0}, {1, 0}, {2, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}},
+        {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {4, 1}},
+        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 3}, {3, 4}, {3, 5}},
+        {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}}};
+    return t[w][k][which];
+}
+
+// (tm, tn) of block k of wave w, for the fix-up kernel (the same tables, as data)
+__device__ __constant__ signed char TALL_BLOCKS[4][TBLK][2] = {
+    {{0, 5}, {1, 5}, {2, 5}, {0, 6}, {1, 6}, {2, 6}, {0, 7}, {1, 7}, {2, 7}},
+    {{0, 3}, {1, 3}, {2, 3}, {3, 3}, {0, 4}, {1, 4}, {2, 4}, {3, 4}, {4, 4}},
+    {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 5}, {3, 6}, {3, 7}},
+    {{4, 5}, {5, 5}, {4, 6}, {5, 6}, {6, 6}, {4, 7}, {5, 7}, {6, 7}, {7, 7}},
+};
+
+struct TallArgs {
+    const double *A; int64_t lda, rows, cols;
+    const double *b; int sign;            // c_i = 0.0 (+|-) b[i]; b == null or sign == 0: c = 0
+    int64_t chunk;                        // stages per workgroup when the stages are dealt out in contiguous chunks (interleave == 0)
+    int64_t nstages;                      // stages of TBK rows in all
+    int interleave;                       // 1: workgroup g takes the stages g, g + G, g + 2G, ..  At any moment the chip then reads ONE band of
+                                          // G * TBK consecutive rows of every column: neighbouring workgroups ask for neighbouring pieces of the
+                                          // same DRAM pages at about the same time.  With contiguous chunks every workgroup streams its own
+                                          // 128 x (8 * TBK bytes) pieces from 128 x G different pages: 2 TB/s (profiles/r05_gram_tall.txt)
+    double *ws;                           // gridDim.x x TSTRIDE doubles
+    int vec_in;                           // A 16-byte aligned and lda even
+};
+
+// one stage of one wave: 4 k-steps x 36 MFMAs from the panel in LDS (`panel` already points at this lane's k offset)
+template <int W>
+__device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int lm, double (&acc)[TACC]) {
+    constexpr int NR = tw_nr(W), NC = tw_nc(W);
+#pragma unroll PMT_TALL_UNROLL
+    for (int ks = 0; ks < TBK / 4; ++ks) {
+        double a[NR];
+#pragma unroll
+        for (int t = 0; t < NR; ++t) a[t] = panel[(tw_row(W, t) * 16 + lm) * TGP + ks * 4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks (gram_sk.hip, lane maps)
+                bv[r] = panel[(tw_col(W, c) * 16 + rc) * TGP + ks * 4];
+            }
+#pragma unroll
+            for (int k = 0; k < TBLK; ++k) {
+                if (tw_blk(W, k, 1) != c) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)], bv[r], acc[k * 4 + r], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// thread (kp = tid & 7, cc = tid >> 3) owns the row pairs 16 j + 2 kp (j < TSUB) of the columns cc + 32 p (p < 4): the TSUB loads of a
+// column are issued back to back, so the memory system sees 8 * TBK contiguous bytes per column and workgroup at a time
+template <bool FAST>
+__device__ __forceinline__ void tall_load(const TallArgs &g, int64_t row0, int64_t rend, int kp, int cc, f64x2 (&reg)[4][TSUB], f64x2 (&cv)[TSUB]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t col = cc + 32 * p;
+#pragma unroll
+        for (int j = 0; j < TSUB; ++j) {
+            const int64_t row = row0 + 16 * j + 2 * kp;
+            const double *src = g.A + col * g.lda + row;
+            f64x2 v;
+            if (FAST) {
+                v = *reinterpret_cast<const f64x2 *>(src);
+            } else {
+                v.x = 0.0; v.y = 0.0;
+                if (col < g.cols) {
+                    if (g.vec_in && row + 1 < rend) v = *reinterpret_cast<const f64x2 *>(src);
+                    else {
+                        if (row < rend) v.x = src[0];
+                        if (row + 1 < rend) v.y = src[1];
+                    }
+                }
+            }
+            reg[p][j] = v;
+        }
+    }
+    // b's row pairs come in RAW: no arithmetic on a loaded value in front of the stage's MFMAs — an `s_waitcnt vmcnt(0)` for it would also
+    // wait for the panel loads above, i.e. serialise the memory phase with the matrix phase (measured: 0.51 ms = 0.26 memory + 0.33 MFMA)
+#pragma unroll
+    for (int j = 0; j < TSUB; ++j) {
+        const int64_t row = row0 + 16 * j + 2 * kp;
+        f64x2 v;
+        v.x = 0.0; v.y = 0.0;
+        if (g.b) {
+            if (FAST) {
+                v = *reinterpret_cast<const f64x2 *>(g.b + row);
+            } else {
+                if (row < rend) v.x = g.b[row];
+                if (row + 1 < rend) v.y = g.b[row + 1];
+            }
+        }
+        cv[j] = v;
+    }
+}
+
+// registers -> LDS (16-byte stores), and the affine part / constant of the rows just loaded
+__device__ __forceinline__ void tall_store(double *__restrict__ panel, const f64x2 (&reg)[4][TSUB], const f64x2 (&cv)[TSUB], int sign, int kp, int cc,
+                                           double (&qacc)[4], double &cacc) {
+#pragma unroll
+    for (int j = 0; j < TSUB; ++j) {
+        // c = 0.0 (+|-) b (rows beyond the matrix were loaded as 0: they add 0 * 0)
+        const double c0 = signed_const(cv[j].x, sign), c1 = signed_const(cv[j].y, sign);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f64x2 *>(panel + (cc + 32 * p) * TGP + 16 * j + 2 * kp) = reg[p][j];
+            qacc[p] = qacc[p] + c0 * reg[p][j].x;
+            qacc[p] = qacc[p] + c1 * reg[p][j].y;
+        }
+        cacc = cacc + c0 * c0;
+        cacc = cacc + c1 * c1;
+    }
+}
+
+// the whole row chunk of one workgroup as seen by wave W.  The wave's block set is a template parameter of the WHOLE body, not of the
+// stage alone: with four stage bodies behind a branch inside one loop the accumulators are a 36-double phi at every merge and the
+// allocator needs ~230 registers; specialised from the top each wave has its own 36 accumulators in fixed registers (~145).  All four
+// bodies execute the same sequence of barriers (s_barrier counts waves, the branch is wave-uniform).
+template <int W, bool FAST>
+__device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TCOLS * TGP], int tid) {
+    const int lane = tid & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int kp = tid & 7, cc = tid >> 3;
+    const int64_t G = gridDim.x, bid = blockIdx.x;
+    const int64_t sbeg = g.interleave ? bid : bid * g.chunk;                       // first stage and stage step of this workgroup
+    const int64_t sstep = g.interleave ? G : 1;
+    const int nstage = (int)(g.interleave ? (g.nstages > bid ? (g.nstages - bid + G - 1) / G : 0) : max((int64_t)0, min(g.chunk, g.nstages - sbeg)));
+    const int64_t rend = g.rows;
+
+    double acc[TACC];
+#pragma unroll
+    for (int r = 0; r < TACC; ++r) acc[r] = 0.0;
+    double qacc[4] = {0.0, 0.0, 0.0, 0.0}, cacc = 0.0;
+    auto stage_row = [&](int s) { return (sbeg + (int64_t)s * sstep) * TBK; };
+#if PMT_TALL_PF == 2
+    // Loads run TWO stages ahead of the MFMAs: two register sets, the stage loop unrolled by two so that the sets are static.  One stage of
+    // matrix work (~1 us with two workgroups per CU) does not cover the ~2 us a 16 KB request round takes when the whole chip streams; with
+    // the loads of stage s + 2 issued before stage s is contracted, a request has two stages to return and the memory pipe never drains.
+    f64x2 regA[4][TSUB], cvA[TSUB], regB[4][TSUB], cvB[TSUB];
+    if (nstage > 0) {
+        tall_load<FAST>(g, stage_row(0), rend, kp, cc, regA, cvA);
+        tall_store(lds[0], regA, cvA, g.sign, kp, cc, qacc, cacc);
+    }
+    if (nstage > 1) tall_load<FAST>(g, stage_row(1), rend, kp, cc, regB, cvB);
+    __syncthreads();
+    for (int s = 0; s < nstage; s += 2) {
+        // even stage: reads LDS 0; set A is free (stored at the end of stage s - 1), set B holds stage s + 1
+        if (s + 2 < nstage) tall_load<FAST>(g, stage_row(s + 2), rend, kp, cc, regA, cvA);
+        tall_stage<W>(lds[0] + lk, lm, acc);
+        if (s + 1 < nstage) tall_store(lds[1], regB, cvB, g.sign, kp, cc, qacc, cacc);
+        __syncthreads();
+        if (s + 1 >= nstage) break;
+        // odd stage: reads LDS 1; set B is free, set A holds stage s + 2
+        if (s + 3 < nstage) tall_load<FAST>(g, stage_row(s + 3), rend, kp, cc, regB, cvB);
+        tall_stage<W>(lds[1] + lk, lm, acc);
+        if (s + 2 < nstage) tall_store(lds[0], regA, cvA, g.sign, kp, cc, qacc, cacc);
+        __syncthreads();
+    }
+#else
+    f64x2 reg[4][TSUB], cv[TSUB];
+
+    if (nstage > 0) {
+        tall_load<FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
+        tall_store(lds[0], reg, cv, g.sign, kp, cc, qacc, cacc);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nstage;
+#if PMT_TALL_ABL == 1      // ablation (wrong results): no global loads / LDS stores after the first stage — the MFMA side alone
+        tall_stage<W>(lds[cur] + lk, lm, acc);
+#elif PMT_TALL_ABL == 2    // ablation (wrong results): no MFMAs — the memory side alone
+        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#else
+        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<W>(lds[cur] + lk, lm, acc);
+        if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#endif
+        __syncthreads();
+    }
+#endif
+
+    // partials -> workspace: [wave][accumulator][lane] (512-byte runs), then q and c'c
+    double *w = g.ws + (int64_t)blockIdx.x * TSTRIDE;
+#pragma unroll
+    for (int r = 0; r < TACC; ++r) w[(W * TACC + r) * 64 + lane] = acc[r];
+    // the 8 row-pair threads of a column are 8 consecutive lanes: tree in fixed order
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        double v = qacc[p];
+        v = v + __shfl_down(v, 4, 8);
+        v = v + __shfl_down(v, 2, 8);
+        v = v + __shfl_down(v, 1, 8);
+        if (kp == 0) w[TPART + cc + 32 * p] = v;
+    }
+    if (W == 0) {
+        double v = cacc;
+        v = v + __shfl_down(v, 4, 8);
+        v = v + __shfl_down(v, 2, 8);
+        v = v + __shfl_down(v, 1, 8);
+        if (tid == 0) w[TPART + TCOLS] = v;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g) {
+    __shared__ double lds[2][TCOLS * TGP];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave == 0) tall_body<0, FAST>(g, lds, tid);
+    else if (wave == 1) tall_body<1, FAST>(g, lds, tid);
+    else if (wave == 2) tall_body<2, FAST>(g, lds, tid);
+    else tall_body<3, FAST>(g, lds, tid);
+}
+
+struct TallFixArgs {
+    const double *ws; int G;
+    int64_t cols; const int64_t *xvar; const int64_t *varmap; int moi;
+    QT *out_quad; double *out_csc; double alpha; LT *out_lin; double *out_const;
+};
+
+// element e of the partial layout summed over the G workgroups: 16 interleaved slices (slice t adds the chunks t, t + 16, .. in order),
+// then the slices in order; 64 consecutive elements per workgroup (512-byte reads).  Then the element goes where it belongs:
+// QuadraticTerm (x 2: (j,k)+(k,j) combined off the diagonal, the MOI doubling on it), LinearTerm 2 * q_j, or the constant.
+__global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
+    __shared__ double part[TSLICES][64];
+    const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    double sum = 0.0;
+    if (e < TPART + TCOLS + 1) {
+        const double *p = f.ws + e;
+        int gidx = slice;
+        for (; gidx + 3 * TSLICES < f.G; gidx += 4 * TSLICES) {
+            const double v0 = p[(int64_t)gidx * TSTRIDE], v1 = p[(int64_t)(gidx + TSLICES) * TSTRIDE];
+            const double v2 = p[(int64_t)(gidx + 2 * TSLICES) * TSTRIDE], v3 = p[(int64_t)(gidx + 3 * TSLICES) * TSTRIDE];
+            sum = sum + v0; sum = sum + v1; sum = sum + v2; sum = sum + v3;
+        }
+        for (; gidx < f.G; gidx += TSLICES) sum = sum + p[(int64_t)gidx * TSTRIDE];
+    }
+    part[slice][el] = sum;
+    __syncthreads();
+    if (slice != 0 || e >= TPART + TCOLS + 1) return;
+    double v = part[0][el];
+#pragma unroll
+    for (int t = 1; t < TSLICES; ++t) v = v + part[t][el];
+    const int64_t n = f.cols;
+    if (e < TPART) {
+        const int lane = e & 63, a = e >> 6;              // a = wave * TACC + block * 4 + rotation
+        const int w = a / TACC, k = (a % TACC) >> 2, r = a & 3;
+        const int tm = TALL_BLOCKS[w][k][0], tn = TALL_BLOCKS[w][k][1];
+        const int i = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3;
+        const int64_t j = 16 * tm + 4 * b + i, kk = 16 * tn + 4 * ((b + r) & 3) + jj;
+        if (kk >= n || j > kk) return;
+        double c = v;
+        if (f.moi || j != kk) c = 2 * c;
+        if (f.out_csc) f.out_csc[kk * (kk + 1) / 2 + j] = f.alpha * c;
+        if (f.out_quad) {
+            const int64_t jv = f.xvar[j], kv = f.xvar[kk];
+            u64 *o = reinterpret_cast<u64 *>(f.out_quad) + (j * n - (j * (j - 1)) / 2 + (kk - j)) * 3;
+            o[0] = (u64)__double_as_longlong(c);
+            o[1] = (u64)(f.moi ? map_var(f.varmap, jv) : jv);
+            o[2] = (u64)(f.moi ? map_var(f.varmap, kv) : kv);
+        }
+    } else if (e < TPART + TCOLS) {
+        const int64_t j = e - TPART;
+        if (j >= n) return;
+        LT t;
+        t.coeff = 2 * v;
+        const int64_t xv = f.xvar[j];
+        t.var = f.moi ? map_var(f.varmap, xv) : xv;
+        f.out_lin[j] = t;
+    } else {
+        *f.out_const = v;
+    }
+}
+
+// shapes the fused tall form takes: one 128-column tile, enough rows that the stream-K form's full square and its separate q / c'c
+// launches cost more than the partial sums (below, the stream-K node keeps the reference's sequential constant bit for bit)
+bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <= TCOLS && rows >= 1024; }
+
+// stages per workgroup: at most TALL_MAX_G workgroups, at least TALL_MIN_CHUNK rows each
+static int64_t tall_chunk(int64_t rows) {
+    const int64_t nst = cdiv(rows, TBK);
+    return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, TALL_MAX_G));
+}
+int gram_tall_groups(int64_t rows) { return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows)); }
+size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols) {
+    return gram_tall_applies(rows, cols) ? sizeof(double) * (size_t)gram_tall_groups(rows) * TSTRIDE : 0;
+}
+
+int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
+                     const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
+                     double *out_const, void *workspace, hipStream_t s) {
+    if (!workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
+    TallArgs g;
+    g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.b = (b && sign) ? b : nullptr; g.sign = g.b ? sign : 0;
+    g.chunk = tall_chunk(rows);
+    g.nstages = cdiv(rows, TBK);
+#ifdef PMT_TUNING
+    static const int inter = [] { const char *e = getenv("PMT_TALL_INTERLEAVE"); return e ? atoi(e) : 1; }();
+    g.interleave = inter;
+#else
+    g.interleave = 1;
+#endif
+    g.ws = reinterpret_cast<double *>(workspace);
+    g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+    const int G = gram_tall_groups(rows);
+    // whole stages, whole panel, aligned pieces (of A and of b): no bounds checks
+    const bool fast = g.vec_in && cols == TCOLS && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
+    if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G), dim3(256), 0, s, g);
+    if (int rc = check_launch("gram_tall_kernel")) return rc;
+    TallFixArgs f;
+    f.ws = g.ws; f.G = G; f.cols = cols; f.xvar = xvar; f.varmap = varmap; f.moi = moi; f.out_quad = out_quad; f.out_csc = out_csc; f.alpha = alpha;
+    f.out_lin = out_lin; f.out_const = out_const;
+    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64)), dim3(1024), 0, s, f);
+    return check_launch("gram_tall_fixup_kernel");
+}
+
+}  // namespace pmt

@@ -28,18 +28,27 @@ extern "C" int pmt_host_copy_2d(void *dst, size_t dst_pitch, const void *src, si
         for (size_t r = r0; r < r1; ++r, d += dst_pitch, s += src_pitch) memcpy(d, s, width_bytes);
     };
     if (nt <= 1) { work(0, height); return PMT_OK; }
+    // The pool lives OUTSIDE the try block: when a thread cannot be started (std::system_error) the ones already running are joinable and
+    // must be joined, not destroyed (std::terminate).  Rows whose thread never started are copied by the calling thread; nothing is copied twice.
+    std::vector<std::thread> pool;
+    const size_t per = (height + (size_t)nt - 1) / (size_t)nt;
+    size_t unassigned = height;                 // first row no started thread owns
     try {
-        std::vector<std::thread> pool;
         pool.reserve((size_t)nt - 1);
-        const size_t per = (height + (size_t)nt - 1) / (size_t)nt;
         for (int t = 1; t < nt; ++t) {
             const size_t r0 = std::min(height, (size_t)t * per), r1 = std::min(height, r0 + per);
-            if (r0 < r1) pool.emplace_back(work, r0, r1);
+            if (r0 < r1) {
+                unassigned = r0;
+                pool.emplace_back(work, r0, r1);
+            }
+            unassigned = r1;
         }
-        work(0, std::min(height, per));
-        for (auto &th : pool) th.join();
+        unassigned = height;
     } catch (const std::exception &) {
-        work(0, height);                      // (no threads to be had: the calling thread copies everything; rows already copied are copied again)
+        // `unassigned` is the first row of the chunk whose thread failed to start
     }
+    work(0, std::min(height, per));
+    if (unassigned < height) work(std::max(unassigned, std::min(height, per)), height);
+    for (auto &th : pool) th.join();
     return PMT_OK;
 }

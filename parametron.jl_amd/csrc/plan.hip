@@ -35,7 +35,15 @@ struct pmt_plan {
     bool recording = false;
     std::vector<void *> allocations;
     size_t bytes = 0;
-    std::vector<pmt::Launch> tape;
+    std::vector<pmt::Launch> tape;    // as recorded, one entry per recorded call
+    // what a replay executes: the tape, with every run of consecutive small nodes (small.hip) replaced by one interpreter launch;
+    // rebuilt by pmt_plan_end_record / pmt_plan_set_fusion
+    std::vector<pmt::Launch> exec;
+    std::vector<char> exec_lanes;
+    std::vector<int> node_of;         // per tape entry: index into `nodes`, or -1 (an entry only its closure can execute)
+    std::vector<pmt::SmallNode> nodes;
+    bool fusion = true;
+    int fused_groups = 0, fused_nodes = 0;
     std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
                                       // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
     char record_lane = 0;
@@ -123,10 +131,24 @@ int dispatch(void *stream, Launch launch) {
             if (!plan->recording) return fail(PMT_STATE_ERROR, "plan is not recording (call pmt_plan_begin_record first)");
             plan->tape.push_back(std::move(launch));
             plan->lanes.push_back(plan->record_lane);
+            plan->node_of.push_back(-1);
             return PMT_OK;
         }
     }
     return launch(reinterpret_cast<hipStream_t>(stream));
+}
+
+int dispatch(void *stream, Launch launch, const SmallNode &node) {
+    pmt_plan *plan = recording_plan(stream);
+    if (plan && plan->recording) {
+        plan->nodes.push_back(node);
+        const int idx = (int)plan->nodes.size() - 1;
+        if (int rc = dispatch(stream, std::move(launch))) { plan->nodes.pop_back(); return rc; }
+        plan->node_of.back() = idx;
+        if (node.seed_host) plan->no_graph = true;          // a seed read from a host word at every replay cannot be captured
+        return PMT_OK;
+    }
+    return dispatch(stream, std::move(launch));
 }
 
 }  // namespace pmt
@@ -521,11 +543,89 @@ extern "C" int pmt_plan_begin_record(pmt_plan *plan) {
     return PMT_OK;
 }
 
+namespace pmt {
+size_t small_table_bytes(int count);
+void small_table_image(const SmallNode *nodes, int count, void *image);
+int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, hipStream_t s);
+}
+
+// exec := tape, with every run of >= 2 consecutive small nodes on the plan's own lane replaced by one interpreter launch (small.hip).  The
+// node tables live in plan-owned device memory, written here once (setup, not the solve path).
+static int build_exec(pmt_plan *plan) {
+    plan->exec.clear(); plan->exec_lanes.clear();
+    plan->fused_groups = 0; plan->fused_nodes = 0;
+    const size_t n = plan->tape.size();
+    auto small = [&](size_t i) {
+        return plan->fusion && plan->node_of[i] >= 0 && plan->lanes[i] == 0 && plan->nodes[(size_t)plan->node_of[i]].work <= pmt::SMALL_NODE_WORK_MAX;
+    };
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        int64_t work = 0;
+        int ndyn = 0;
+        while (j < n && small(j)) {
+            const pmt::SmallNode &nd = plan->nodes[(size_t)plan->node_of[j]];
+            if (work + nd.work > pmt::SMALL_GROUP_WORK_MAX && j > i) break;
+            if (nd.seed_host && ndyn == pmt::SMALL_MAX_DYN) break;
+            work += nd.work;
+            ndyn += nd.seed_host ? 1 : 0;
+            ++j;
+        }
+        if (j - i < 2) {
+            plan->exec.push_back(plan->tape[i]);
+            plan->exec_lanes.push_back(plan->lanes[i]);
+            ++i;
+            continue;
+        }
+        const int count = (int)(j - i);
+        std::vector<pmt::SmallNode> group;
+        std::vector<const uint64_t *> words;
+        for (size_t k = i; k < j; ++k) {
+            pmt::SmallNode nd = plan->nodes[(size_t)plan->node_of[k]];
+            nd.dyn = -1;
+            if (nd.seed_host) { nd.dyn = (int)words.size(); words.push_back(nd.seed_host); }
+            group.push_back(nd);
+        }
+        std::vector<char> image(pmt::small_table_bytes(count));
+        pmt::small_table_image(group.data(), count, image.data());
+        void *table = nullptr;
+        hipError_t e = hipMalloc(&table, image.size());
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        plan->allocations.push_back(table);
+        plan->bytes += image.size();
+        PMT_HIP_CHECK(hipMemcpy(table, image.data(), image.size(), hipMemcpyHostToDevice));
+        plan->exec.push_back([=](hipStream_t s) { return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), s); });
+        plan->exec_lanes.push_back(0);
+        plan->fused_groups += 1;
+        plan->fused_nodes += count;
+        i = j;
+    }
+    return PMT_OK;
+}
+
 extern "C" int pmt_plan_end_record(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_end_record: null plan");
     PMT_REQUIRE(plan->recording, PMT_STATE_ERROR, "plan is not recording");
     plan->recording = false;
     plan->record_lane = 0;
+    return build_exec(plan);
+}
+
+extern "C" int pmt_plan_set_fusion(pmt_plan *plan, int on) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_set_fusion: null plan");
+    PMT_REQUIRE(!plan->recording, PMT_STATE_ERROR, "plan_set_fusion: the plan is recording");
+    PMT_REQUIRE(!plan->graph_exec, PMT_STATE_ERROR, "plan_set_fusion: the plan's graph is already instantiated");
+    plan->fusion = on != 0;
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
+    return build_exec(plan);
+}
+
+extern "C" int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_length) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fused: null plan");
+    if (groups) *groups = plan->fused_groups;
+    if (nodes) *nodes = plan->fused_nodes;
+    if (exec_length) *exec_length = (int64_t)plan->exec.size();
     return PMT_OK;
 }
 
@@ -543,7 +643,7 @@ static int replay(pmt_plan *plan, hipStream_t s) {
     struct End { hipStream_t s; int rc = PMT_OK; bool done = false; int finish() { if (!done) { done = true; rc = pmt::replay_end(s); } return rc; } ~End() { finish(); } } end{s};
     hipStream_t side = nullptr;
     bool any = false;
-    for (char l : plan->lanes) any |= (l != 0);
+    for (char l : plan->exec_lanes) any |= (l != 0);
     if (any && (side = pmt::side_stream_of(s))) {
         if (!plan->lane_fork) {
             PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->lane_fork, hipEventDisableTiming));
@@ -559,24 +659,24 @@ static int replay(pmt_plan *plan, hipStream_t s) {
     // pmt_plan_commit_lane / pmt_plan_lane_stream) do not wait for what the plan's stream still has to do before the tape — e.g. the
     // device-side callback of the objective's 134 MB matrix
     bool side_used = false;
-    for (size_t i = 0; side && i < plan->tape.size(); ++i)
-        if (plan->lanes[i] == 3) {
+    for (size_t i = 0; side && i < plan->exec.size(); ++i)
+        if (plan->exec_lanes[i] == 3) {
             side_used = true;
-            if (int rc = plan->tape[i](side)) return rc;
+            if (int rc = plan->exec[i](side)) return rc;
         }
-    for (size_t i = 0; side && i < plan->tape.size(); ++i) {
-        if (plan->lanes[i] != 2) continue;
+    for (size_t i = 0; side && i < plan->exec.size(); ++i) {
+        if (plan->exec_lanes[i] != 2) continue;
         if (!forked) { PMT_HIP_CHECK(hipStreamWaitEvent(side, plan->lane_fork, 0)); forked = true; }
-        if (int rc = plan->tape[i](side)) return rc;
+        if (int rc = plan->exec[i](side)) return rc;
     }
-    for (size_t i = 0; i < plan->tape.size(); ++i) {
+    for (size_t i = 0; i < plan->exec.size(); ++i) {
         hipStream_t target = s;
-        if (side && plan->lanes[i] >= 2) continue;
-        if (side && plan->lanes[i]) {
+        if (side && plan->exec_lanes[i] >= 2) continue;
+        if (side && plan->exec_lanes[i]) {
             if (!forked) { PMT_HIP_CHECK(hipStreamWaitEvent(side, plan->lane_fork, 0)); forked = true; }
             target = side;
         }
-        int rc = plan->tape[i](target);
+        int rc = plan->exec[i](target);
         if (rc) return rc;
     }
     if (forked || side_used) {
@@ -604,6 +704,7 @@ extern "C" int pmt_plan_record_fetch(pmt_plan *plan, void *host_dst, const void 
     std::shared_ptr<pmt::FetchState> st = std::make_shared<pmt::FetchState>();     // the transfer's signals; goes with the tape entry
     plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, bytes, st.get(), pmt::FetchRect{}); });
     plan->lanes.push_back(plan->record_lane);
+    plan->node_of.push_back(-1);
     return PMT_OK;
 }
 
@@ -627,6 +728,7 @@ extern "C" int pmt_plan_record_fetch_2d(pmt_plan *plan, void *host_dst, size_t d
     r.dst_pitch = dst_pitch; r.src_pitch = src_pitch; r.height = height;
     plan->tape.push_back([=](hipStream_t target) { return pmt::fetch_async(main, target, ev, host_dst, device_src, width_bytes, st.get(), r); });
     plan->lanes.push_back(plan->record_lane);
+    plan->node_of.push_back(-1);
     return PMT_OK;
 }
 

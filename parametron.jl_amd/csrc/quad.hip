@@ -298,6 +298,12 @@ extern "C" int pmt_quad_expand_f64(int64_t rows, const pmt_linear_term *x_terms,
         PMT_REQUIRE(nx * ny == 0 || out_quad, PMT_INVALID_ARGUMENT, "quad_expand: null out_quad");
         PMT_REQUIRE(nx + ny == 0 || out_lin, PMT_INVALID_ARGUMENT, "quad_expand: null out_lin");
     }
+    SmallNode nd;
+    nd.op = SOP_QUAD_EXPAND; nd.moi = moi; nd.d[0] = rows; nd.d[1] = nx; nd.d[2] = ny;
+    nd.in[0] = x_terms; nd.in[1] = x_consts; nd.in[2] = y_terms; nd.in[3] = y_consts; nd.in[4] = varmap;
+    nd.out[0] = out_quad; nd.out[1] = out_lin; nd.out[2] = out_const;
+    // the node's constant is a sequential chain on one thread of the interpreter: short vectors only
+    nd.work = rows > 2048 ? SMALL_NODE_WORK_MAX + 1 : rows * nx * ny + rows * (nx + ny) + 16 * rows;
     return dispatch(stream, [=](hipStream_t s) {
         if (rows > 0 && nx > 0 && ny > 0) {
             dim3 grid((unsigned)cdiv(ny, QE_BT), (unsigned)cdiv(nx, QE_AB), (unsigned)std::min<int64_t>(rows, 65535));
@@ -314,7 +320,7 @@ extern "C" int pmt_quad_expand_f64(int64_t rows, const pmt_linear_term *x_terms,
             if (rc) return rc;
         }
         return launch_seq_dot(x_consts, 2, y_consts, 2, rows, out_const, s);
-    });
+    }, nd);
 }
 
 extern "C" int pmt_bilinear_f64(const double *Q, int64_t ldq, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *yvar, int moi,

@@ -68,6 +68,8 @@ extern "C" int pmt_fill_uniform_matrix_f64(double *dst, int64_t rows, int64_t co
     if (rows == 0 || cols == 0) return PMT_OK;
     PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform_matrix: null pointer");
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull;
+    SmallNode nd;
+    nd.op = SOP_FILL; nd.d[0] = rows; nd.d[1] = cols; nd.d[2] = lda; nd.out[0] = dst; nd.scale = scale; nd.seed = seed; nd.work = rows * cols;
     return dispatch(stream, [=](hipStream_t s) {
         const int vec = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
         const int64_t bx = cdiv(cdiv(rows, 2), 256);
@@ -75,7 +77,28 @@ extern "C" int pmt_fill_uniform_matrix_f64(double *dst, int64_t rows, int64_t co
         const unsigned by = (unsigned)std::min<int64_t>(cols, std::max<int64_t>(1, std::min<int64_t>(65535, cdiv(2048, bx))));
         PMT_LAUNCH(fill_uniform_matrix_kernel, dim3((unsigned)bx, by), dim3(256), 0, s, dst, rows, cols, lda, base, scale, vec);
         return check_launch("fill_uniform_matrix_kernel");
-    });
+    }, nd);
+}
+
+// The same fill with the seed read from a HOST word at every launch / replay: a recorded Parameter callback (README.md:36-43 rand!, which
+// draws new values at every update!) whose stream advances from one re-evaluation to the next without the host re-issuing the call —
+// the host stores the next seed into *seed_word before pmt_plan_update.  cols == 1, lda == rows: a vector.
+extern "C" int pmt_fill_uniform_dyn_f64(double *dst, int64_t rows, int64_t cols, int64_t lda, const uint64_t *seed_word, double scale, void *stream) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0, PMT_DIMENSION_MISMATCH, "fill_uniform_dyn: negative dimension");
+    PMT_REQUIRE(lda >= rows, PMT_DIMENSION_MISMATCH, "fill_uniform_dyn: lda < rows");
+    PMT_REQUIRE(seed_word, PMT_INVALID_ARGUMENT, "fill_uniform_dyn: null seed word");
+    if (rows == 0 || cols == 0) return PMT_OK;
+    PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform_dyn: null pointer");
+    SmallNode nd;
+    nd.op = SOP_FILL; nd.d[0] = rows; nd.d[1] = cols; nd.d[2] = lda; nd.out[0] = dst; nd.scale = scale; nd.seed_host = seed_word; nd.work = rows * cols;
+    return dispatch(stream, [=](hipStream_t s) {
+        const uint64_t base = *seed_word * 0x9E3779B97F4A7C15ull;
+        const int vec = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+        const int64_t bx = cdiv(cdiv(rows, 2), 256);
+        const unsigned by = (unsigned)std::min<int64_t>(cols, std::max<int64_t>(1, std::min<int64_t>(65535, cdiv(2048, bx))));
+        PMT_LAUNCH(fill_uniform_matrix_kernel, dim3((unsigned)bx, by), dim3(256), 0, s, dst, rows, cols, lda, base, scale, vec);
+        return check_launch("fill_uniform_matrix_kernel");
+    }, nd);
 }
 
 // Same stream starting at element `index_offset`: dst[i] = scale * U(seed, index_offset + i).  Lets a shard of a larger
@@ -97,9 +120,11 @@ extern "C" int pmt_fill_uniform_f64(double *dst, int64_t n, uint64_t seed, doubl
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(dst, PMT_INVALID_ARGUMENT, "fill_uniform: null pointer");
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull;
+    SmallNode nd;
+    nd.op = SOP_FILL; nd.d[0] = n; nd.d[1] = 1; nd.d[2] = n; nd.out[0] = dst; nd.scale = scale; nd.seed = seed; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(cdiv(n, 2), 256), 256 * 8);
         PMT_LAUNCH(fill_uniform_kernel, dim3(blocks), dim3(256), 0, s, dst, n, base, scale);
         return check_launch("fill_uniform_kernel");
-    });
+    }, nd);
 }

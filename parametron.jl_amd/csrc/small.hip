@@ -1,0 +1,218 @@
+// Small plans: a run of consecutive small tape entries executed by ONE launch.
+//
+// The reference evaluates a model's lazy-expression DAG by chasing C function pointers, nanoseconds per hop (src/lazyexpression.jl:50-61,
+// src/FunctionWrappersQuickFix.jl:108-126): README Example 1 (n = 8, m = 2) re-evaluates in ~15 us on one CPU core (README.md:132-136,
+// solve! 51.863 us including OSQP).  On the device every hop of the tape is a launch of ~5 us whatever its size, so the same model took
+// 48.5 us (5 launches + the four Parameter callbacks).  Here the tape's nodes are DATA: one 1024-thread workgroup walks the node table in
+// tape order — a grid-stride loop per node, a workgroup barrier between nodes (a later node reads what an earlier one wrote through the
+// CU's own L1 / L2: workgroup-scope visibility is enough) — and one launch replaces the run.  Every element is computed by the same
+// expression as in the node's stand-alone kernel (affine.hip, quad.hip, rng.hip): outputs are bit-identical, tests/test_gpu_small_plan.py.
+#include "common.h"
+
+namespace pmt {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint64_t sp_splitmix64(uint64_t z) {           // rng.hip
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double sp_uniform_at(uint64_t base, uint64_t i, double scale) {
+    return scale * ((double)(sp_splitmix64(base + i) >> 11) * 0x1.0p-53);
+}
+
+struct SmallDyn { uint64_t v[SMALL_MAX_DYN]; };
+
+// the device view of a node (the host-only tail of SmallNode is not uploaded)
+struct SmallDev {
+    int op, sign, moi, dyn;
+    int64_t d[4];
+    const void *in[6];
+    void *out[3];
+    double scale;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, int tid, int nt) {
+    switch (n.op) {
+    case SOP_FILL: {                       // rng.hip: dst[c * lda + i] = scale * U(seed, c * rows + i)
+        const int64_t rows = n.d[0], cols = n.d[1], lda = n.d[2];
+        const uint64_t base = (n.dyn >= 0 ? dyn[n.dyn] : n.seed) * 0x9E3779B97F4A7C15ull;
+        double *dst = static_cast<double *>(n.out[0]);
+        for (int64_t e = tid; e < rows * cols; e += nt) {
+            const int64_t c = e / rows, i = e - c * rows;
+            dst[c * lda + i] = sp_uniform_at(base, (uint64_t)e, n.scale);
+        }
+        break;
+    }
+    case SOP_AFFINE_LT:
+    case SOP_AFFINE_VAT: {                 // affine.hip: matvecmul! + vecadd!/vecsubtract! (+ update!(::MOI.VectorAffineFunction))
+        const int64_t lda = n.d[0], rows = n.d[1], cols = n.d[2], row_offset = n.d[3];
+        const double *A = static_cast<const double *>(n.in[0]);
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[1]);
+        const double *b = static_cast<const double *>(n.in[2]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
+        double *consts = static_cast<double *>(n.out[1]);
+        for (int64_t e = tid; e < rows * cols; e += nt) {
+            const int64_t c = e / rows, r = e - c * rows;              // walk A column-major (coalesced reads)
+            const double v = A[c * lda + r];
+            if (n.op == SOP_AFFINE_LT) {
+                LT t; t.coeff = v; t.var = xvar[c];
+                static_cast<LT *>(n.out[0])[r * cols + c] = t;
+            } else {
+                VAT t; t.output_index = row_offset + r + 1; t.coeff = v; t.var = map_var(varmap, xvar[c]);
+                static_cast<VAT *>(n.out[0])[r * cols + c] = t;
+            }
+        }
+        if (consts)
+            for (int64_t r = tid; r < rows; r += nt) consts[r] = signed_const(b ? b[r] : 0.0, b ? n.sign : 0);
+        break;
+    }
+    case SOP_QUAD_EXPAND: {                // quad.hip: literal _vecdot!/muladd! (+ update!(::MOI.ScalarQuadraticFunction))
+        const int64_t rows = n.d[0], nx = n.d[1], ny = n.d[2];
+        const LT *x = static_cast<const LT *>(n.in[0]);
+        const double *xc = static_cast<const double *>(n.in[1]);
+        const LT *y = static_cast<const LT *>(n.in[2]);
+        const double *yc = static_cast<const double *>(n.in[3]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[4]);
+        QT *oq = static_cast<QT *>(n.out[0]);
+        LT *ol = static_cast<LT *>(n.out[1]);
+        for (int64_t e = tid; e < rows * nx * ny; e += nt) {
+            const int64_t ia = e / ny, k = e - ia * ny, i = ia / nx;
+            const LT xa = x[ia], yk = y[i * ny + k];
+            double c = xa.coeff * yk.coeff;                                   // functions.jl:149
+            if (n.moi && xa.var == yk.var) c = 2 * c;                        // moi_interop.jl:58
+            QT t; t.coeff = c; t.row = n.moi ? map_var(varmap, xa.var) : xa.var; t.col = n.moi ? map_var(varmap, yk.var) : yk.var;
+            oq[e] = t;
+        }
+        const int64_t w = nx + ny;
+        for (int64_t e = tid; e < rows * w; e += nt) {
+            const int64_t i = e / w, k = e - i * w;
+            LT t; double c;
+            if (k < nx) { t = x[i * nx + k]; c = yc[i]; }                    // xlinear[i] * yconst  (:567)
+            else { t = y[i * ny + (k - nx)]; c = xc[i]; }                    // ylinear[i] * xconst  (:571)
+            LT o; o.coeff = c * t.coeff; o.var = n.moi ? map_var(varmap, t.var) : t.var;
+            ol[e] = o;
+        }
+        if (tid == 0) {                                                      // strictly left to right (:574)
+            double acc = 0.0;
+            for (int64_t i = 0; i < rows; ++i) acc = acc + xc[i] * yc[i];
+            *static_cast<double *>(n.out[2]) = acc;
+        }
+        break;
+    }
+    case SOP_VARS_ADDSUB: {                // affine.hip: x (+|-) v for x::Vector{Variable}
+        const int64_t cnt = n.d[0], row_offset = n.d[1];
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[0]);
+        const double *v = static_cast<const double *>(n.in[1]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[2]);
+        LT *olt = static_cast<LT *>(n.out[0]);
+        VAT *ovat = static_cast<VAT *>(n.out[1]);
+        double *oc = static_cast<double *>(n.out[2]);
+        for (int64_t i = tid; i < cnt; i += nt) {
+            const int64_t var = xvar[i];
+            if (olt) { LT t; t.coeff = 1.0; t.var = var; olt[i] = t; }
+            if (ovat) { VAT t; t.output_index = row_offset + i + 1; t.coeff = 1.0; t.var = map_var(varmap, var); ovat[i] = t; }
+            if (oc) oc[i] = signed_const(v ? v[i] : 0.0, v ? n.sign : 0);
+        }
+        break;
+    }
+    case SOP_CONSTS: {
+        const double *d = static_cast<const double *>(n.in[0]);
+        double *o = static_cast<double *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) o[i] = signed_const(d[i], n.sign);
+        break;
+    }
+    case SOP_PACK_SA: {                    // moi_interop.jl:35-43
+        const LT *in = static_cast<const LT *>(n.in[0]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[1]);
+        LT *o = static_cast<LT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) { LT t = in[i]; t.var = map_var(varmap, t.var); o[i] = t; }
+        break;
+    }
+    case SOP_PACK_SQ: {                    // moi_interop.jl:45-62
+        const QT *in = static_cast<const QT *>(n.in[0]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[1]);
+        QT *o = static_cast<QT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) {
+            const QT t = in[i];
+            QT r; r.coeff = (t.row == t.col) ? 2 * t.coeff : t.coeff; r.row = map_var(varmap, t.row); r.col = map_var(varmap, t.col);
+            o[i] = r;
+        }
+        break;
+    }
+    case SOP_PACK_VA: {                    // moi_interop.jl:64-81; uniform rows (row_len) or ragged (row_ptr)
+        const LT *in = static_cast<const LT *>(n.in[0]);
+        const int64_t *row_ptr = static_cast<const int64_t *>(n.in[1]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[2]);
+        const int64_t rows = n.d[0], row_len = n.d[1], row_offset = n.d[2];
+        VAT *o = static_cast<VAT *>(n.out[0]);
+        if (!row_ptr) {
+            for (int64_t e = tid; e < rows * row_len; e += nt) {
+                const LT t = in[e];
+                VAT r; r.output_index = row_offset + e / row_len + 1; r.coeff = t.coeff; r.var = map_var(varmap, t.var);
+                o[e] = r;
+            }
+        } else {
+            const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+            for (int64_t row = wave; row < rows; row += nw)
+                for (int64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
+                    const LT t = in[e];
+                    VAT r; r.output_index = row_offset + row + 1; r.coeff = t.coeff; r.var = map_var(varmap, t.var);
+                    o[e] = r;
+                }
+        }
+        break;
+    }
+    case SOP_COPY8: {
+        const u64 *src = static_cast<const u64 *>(n.in[0]);
+        u64 *dst = static_cast<u64 *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) dst[i] = src[i];
+        break;
+    }
+    default: break;
+    }
+}
+
+__global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__restrict__ table, int count, SmallDyn dyn) {
+    __shared__ SmallDev node;
+    __shared__ uint64_t sdyn[SMALL_MAX_DYN];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // (static indices: a kernel argument array indexed by a register would be copied to scratch)
+#pragma unroll
+    for (int i = 0; i < SMALL_MAX_DYN; ++i)
+        if (tid == i) sdyn[i] = dyn.v[i];
+    for (int k = 0; k < count; ++k) {
+        // the node description goes through LDS: one read of the table per node instead of one per thread
+        if (tid < (int)(sizeof(SmallDev) / 8)) reinterpret_cast<u64 *>(&node)[tid] = reinterpret_cast<const u64 *>(table + k)[tid];
+        __syncthreads();
+        sp_node(node, sdyn, tid, nt);
+        __syncthreads();                   // what this node wrote is visible to the next one (same workgroup), and `node` may be rewritten
+    }
+}
+
+size_t small_table_bytes(int count) { return sizeof(SmallDev) * (size_t)count; }
+
+// host: the device image of `count` nodes (the caller uploads it once)
+void small_table_image(const SmallNode *nodes, int count, void *image) {
+    SmallDev *d = static_cast<SmallDev *>(image);
+    for (int i = 0; i < count; ++i) {
+        const SmallNode &s = nodes[i];
+        d[i].op = s.op; d[i].sign = s.sign; d[i].moi = s.moi; d[i].dyn = s.dyn;
+        for (int k = 0; k < 4; ++k) d[i].d[k] = s.d[k];
+        for (int k = 0; k < 6; ++k) d[i].in[k] = s.in[k];
+        for (int k = 0; k < 3; ++k) d[i].out[k] = s.out[k];
+        d[i].scale = s.scale; d[i].seed = s.seed;
+    }
+}
+
+int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, hipStream_t s) {
+    SmallDyn dyn;
+    for (int i = 0; i < SMALL_MAX_DYN; ++i) dyn.v[i] = (i < ndyn && seed_words[i]) ? *seed_words[i] : 0;
+    PMT_LAUNCH(small_plan_kernel, dim3(1), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn);
+    return check_launch("small_plan_kernel");
+}
+
+}  // namespace pmt

@@ -220,10 +220,16 @@ extern "C" int pmt_scale_numbers_f64(const double *y, int64_t n, const double *s
 extern "C" int pmt_copy_bytes(void *dst, const void *src, size_t bytes, void *stream) {
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(dst && src, PMT_INVALID_ARGUMENT, "copy_bytes: null pointer");
-    return dispatch(stream, [=](hipStream_t s) {
+    Launch copy = [=](hipStream_t s) {
         PMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
         return PMT_OK;
-    });
+    };
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 7) == 0) {
+        SmallNode nd;
+        nd.op = SOP_COPY8; nd.d[0] = (int64_t)(bytes / 8); nd.in[0] = src; nd.out[0] = dst; nd.work = (int64_t)(bytes / 8);
+        return dispatch(stream, copy, nd);
+    }
+    return dispatch(stream, copy);
 }
 
 extern "C" int pmt_affvec_combine_f64(int64_t rows, const pmt_linear_term *xa_terms, const int64_t *xa_row_ptr, int64_t xa_row_len,

@@ -193,6 +193,16 @@ class DeviceContext:
     def tape_length(self):
         return int(self.lib.pmt_plan_tape_length(self.plan))
 
+    def fused(self):
+        """small plans (include/parametron_hip.h): {groups, nodes, exec_length} — runs of small tape entries replayed as ONE launch each, the
+        tape entries they replace, and what one replay executes"""
+        g, n, ln = C.c_int(), C.c_int(), C.c_int64()
+        _lib.call("pmt_plan_fused", self.plan, C.byref(g), C.byref(n), C.byref(ln))
+        return {"groups": g.value, "nodes": n.value, "exec_length": ln.value}
+
+    def set_fusion(self, on):
+        _lib.call("pmt_plan_set_fusion", self.plan, 1 if on else 0)
+
 
 def P(ptr):
     return C.c_void_p(ptr) if ptr else None

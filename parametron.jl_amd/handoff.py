@@ -269,7 +269,7 @@ class DeviceQP:
                     ablocks.append(_Block(rows, t["var"].copy(), c.dev["terms"], 16))
                     bounds.append((row0, 1, kind, value, c.dev["const"], None))
             else:
-                t = c.f.terms
+                t = c.f._terms          # (structure; the coefficients of a static dense block are not host data: moi.VectorAffineFunction)
                 if c.isconstant:
                     ablocks.append(_Block(t["out"] + row0, vm[t["var"] - 1], host_coeff=t["coeff"].copy()))
                     bounds.append((row0, c.nrows, kind, value, None, np.asarray(c.f.constants, dtype=np.float64).copy()))

@@ -145,6 +145,11 @@ def device_value_of(x, ctx=None):
                 x._dev = DVec(ctx, x.shape[0]) if len(x.shape) == 1 else DMat(ctx, *x.shape)
             else:
                 x._dev = _alloc_like(ctx, val)
+        if x._dev_version != x.version and getattr(x, "_in_tape", False) and getattr(ctx, "_refreshing", False) and not ctx.recording:
+            # the callback is an entry of the tape (a small model, Model._record_parameter_callbacks): the replay that follows draws the values
+            x._seed_word.value = x.current_seed() % (1 << 64)
+            x._dev_version = x.version
+            return x._dev
         if x._dev_version != x.version:
             if getattr(x, "device_resident", False):
                 # a value only side-lane records read is regenerated on the side stream (inside update! only: there the replay joins the

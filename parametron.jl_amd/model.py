@@ -13,6 +13,8 @@ device fill); replay the recorded tape of node kernels and MOI-pack kernels on t
 (pmt_plan_update — no allocation, no host term bookkeeping); copy the MOI buffers to the host function objects and hand
 them to the optimizer with MOI.set (third party from there on).
 """
+import ctypes as C
+
 import numpy as np
 
 from . import moi
@@ -294,6 +296,7 @@ class Model:
                     x.prepare()
             ctx.begin_record()
             try:
+                self._record_parameter_callbacks(ctx)
                 for x in self._order:
                     if isinstance(x, DeviceNode):
                         x.emit(ctx)
@@ -342,6 +345,29 @@ class Model:
         self._mark_side_lane_parameters()
         if records and self._use_graph:
             self.device().instantiate_graph()
+
+    SMALL_MODEL_ELEMENTS = 32768
+
+    def _record_parameter_callbacks(self, ctx):
+        """SMALL models: the device-side callbacks of the DeviceUniformParameters go INTO the tape, at its front, with their seeds in host
+        words (pmt_fill_uniform_dyn_f64) — update! then stores the next seeds and replays, and the library runs callbacks and tape as one
+        small plan: one launch (csrc/small.hip).  README Example 1's update! is launch-bound on the device: four callbacks + five kernels
+        took ~48 us where the reference's CPU walk of the same DAG takes ~15 (README.md:132-136)."""
+        from .parameter import DeviceUniformParameter
+        from .device import DMat, DVec
+        if self._use_graph:
+            return
+        ps = [x for x in self._order if isinstance(x, Parameter)]
+        if sum(int(np.prod(np.shape(getattr(x, "val", 0)) or (1,))) for x in ps) > self.SMALL_MODEL_ELEMENTS:
+            return
+        for x in ps:
+            dv = getattr(x, "_dev", None)
+            if not isinstance(x, DeviceUniformParameter) or getattr(x, "pattern", None) is not None or not isinstance(dv, (DMat, DVec)):
+                continue
+            x._seed_word = C.c_uint64(x.current_seed() % (1 << 64))
+            rows, cols, lda = (dv.rows, dv.cols, dv.lda) if isinstance(dv, DMat) else (int(x.shape[0]), 1, int(x.shape[0]))
+            ctx.call("pmt_fill_uniform_dyn_f64", C.c_void_p(dv.buf), rows, cols, lda, C.byref(x._seed_word), x.scale)
+            x._in_tape = True
 
     def _mark_side_lane_parameters(self):
         """Host-updated Parameters that ONLY side-lane records read (and, with a hand-off, only when its launches are side-lane entries too)

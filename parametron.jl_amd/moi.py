@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import LT, QT, VAT, ArgumentError, DimensionMismatch
+from ._lib import LT, QT, VAT, ArgumentError, DimensionMismatch, ErrorException
 from .device import DAff, DAffVec, DDenseAff, DQuad, DSparseAff, DVarsAff, P
 from .functions import AffineFunction, LinearTerm, QuadraticFunction, QuadraticTerm, Variable, _isnum
 from .lazyexpression import DeviceNode, kind_of
@@ -64,8 +64,27 @@ class ScalarQuadraticFunction:
 
 class VectorAffineFunction:
     def __init__(self, nterms=0, nrows=0, alloc=_zeros):
-        self.terms = alloc(nterms, VAT)
+        self._terms = alloc(nterms, VAT)
         self.constants = alloc(nrows, np.float64)
+        self.coefficients_unavailable = None      # a reason: the coefficients are NOT on the host (handoff="host_csc", dense block)
+
+    @property
+    def terms(self):
+        """MOI.VectorAffineTerm[] (src/moi_interop.jl:64-81).  With handoff="host_csc" the terms of a dense block A*x (+|-) b are never packed —
+        the solver's A is delivered as CSC values straight out of the Parameter's buffer — and only their STRUCTURE (`structure`) is host
+        data: reading the coefficients is an error, not a NaN."""
+        if self.coefficients_unavailable:
+            raise ErrorException(self.coefficients_unavailable)
+        return self._terms
+
+    @terms.setter
+    def terms(self, value):
+        self._terms = value
+
+    @property
+    def structure(self):
+        """(output rows, optimizer variables) of the terms — always host data"""
+        return self._terms["out"], self._terms["var"]
 
 
 class SingleVariable:
@@ -254,9 +273,12 @@ class _Record:
             dense = isinstance(out, DDenseAff)
             if not dense or (len(xv) and np.all(np.diff(xv) > 0)):            # (a dense block whose columns are permuted or repeated keeps its terms)
                 self.f = VectorAffineFunction(out.nterms, out.rows)
-                t = self.f.terms
+                t = self.f._terms
                 if dense:
                     t["out"], t["var"], t["coeff"] = np.repeat(np.arange(1, out.rows + 1), out.mat.cols), np.tile(xv, out.rows), np.nan
+                    self.f.coefficients_unavailable = ("handoff=\"host_csc\": the MOI terms of a dense constraint block are not packed (its coefficients "
+                                                       "are the Parameter matrix, delivered as the CSC values of model.device_qp.host); use .structure for "
+                                                       "rows / variables, or handoff=\"moi\" for the reference's MOI functions")
                 else:
                     t["out"], t["var"], t["coeff"] = np.arange(1, out.rows + 1), xv, 1.0
                 dc = ctx.alloc(8 * max(out.rows, 1))

@@ -320,3 +320,34 @@ def test_config3_full_size_inequalities_bounds_and_manual_parameters():
     want = 2 * np.einsum("ij,ij->j", Ah[:, iu[0][rows]], Ah[:, iu[1][rows]])
     np.testing.assert_allclose(f.quadratic_terms["coeff"][rows], want, rtol=1e-12)
     assert np.array_equal(f.quadratic_terms["row"][rows], vm[iu[0][rows]]) and np.array_equal(f.quadratic_terms["col"][rows], vm[iu[1][rows]])
+
+
+# ------------------------------------------------------------------ test/model.jl:364-395 (quadratic constraint functions; build only — the
+# reference needs Gurobi to SOLVE this model, the hot path is the function assembly)
+def test_quadratic_constraint_model_functions():
+    rng = np.random.default_rng(1)
+    opt = P.MockOptimizer(variable_offset=4)
+    model = P.Model(opt)
+
+    def newdir(v):
+        v[:] = rng.standard_normal(2)
+        v /= np.linalg.norm(v)
+    direction = P.Parameter(newdir, np.zeros(2), model)
+    zmax = P.Parameter(lambda: float(rng.random()), model)
+    x, y, z = Variable(model), Variable(model), Variable(model)
+    mu = 0.7
+    P.constraint(model, x ** 2 + y ** 2 <= mu ** 2 * z ** 2)
+    P.constraint(model, z >= 0)
+    P.constraint(model, z <= zmax)
+    P.objective(model, P.Maximize, P.dot(direction, [x, y]))
+    for _ in range(5):
+        P.solve(model)
+        f = model.objective.f                                               # direction . [x, y] with optimizer indices 5, 6
+        assert f.terms.tolist() == [(direction()[0], 5), (direction()[1], 6)] and f.constant == 0.0
+        cons = {c.spec: c for c in model.constraints}
+        assert sorted(cons) == ["scalaraffinefunction_in_greaterthan", "scalaraffinefunction_in_lessthan", "scalarquadraticfunction_in_lessthan"]
+        zc = cons["scalaraffinefunction_in_lessthan"].f                     # z - zmax <= 0
+        assert zc.terms.tolist() == [(1.0, 7)] and zc.constant == 0.0 - zmax()
+        qc = cons["scalarquadraticfunction_in_lessthan"].f                  # x^2 + y^2 - mu^2 z^2 <= 0, constant: model indices, set once
+        assert qc.quadratic_terms.tolist() == [(2.0, 1, 1), (2.0, 2, 2), (2 * (0.0 - mu ** 2), 3, 3)] and qc.affine_terms.tolist() == []
+    assert opt.sense == P.Maximize and opt.optimize_calls == 5

@@ -1,0 +1,155 @@
+"""-m gpu: the device node of every `optimize` rewrite rule (src/lazyexpression.jl:198-302) against the ORACLE
+directly — oracle/parametron_oracle.c's restatement of the builder the rule splices in — not through the package's own host algebra
+(tests/test_gpu_lazyexpression.py transcribes test/lazyexpression.jl, whose assertions compare with the out-of-place expression; that
+is a two-hop chain).  Exact equality of coefficients, variable indices and order: every one of these nodes is a literal form.
+
+rule :200-204 matvecmul! (both x types)      :206-217 adjoint             :219-226 bilinearmul!        :228-232 vecdot!
+     :234-236 n-ary +                        :238-258 add!/subtract!, vecadd!/vecsubtract!
+     :260-274 mul! (4 orderings)             :276-278 vcat! (ragged)      :284-290 scale! (both orders, three y types)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+import parametron_jl_amd as P  # noqa: E402
+from parametron_jl_amd import Variable  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def affvec(fs):
+    return [([(t.coeff, t.var.index) for t in f.linear], f.constant) for f in fs]
+
+
+def aff(f):
+    return ([(t.coeff, t.var.index) for t in f.linear], f.constant)
+
+
+def quad(q):
+    return ([(t.coeff, t.rowvar.index, t.colvar.index) for t in q.quadratic], [(t.coeff, t.var.index) for t in q.affine.linear], q.affine.constant)
+
+
+@pytest.fixture()
+def setup():
+    model = P.mock_model(quadratic_mode="literal")
+    rng = np.random.default_rng(11)
+    n = 4
+    x = [Variable(model) for _ in range(n)]
+    y = [Variable(model) for _ in range(3)]
+    return model, rng, x, [v.index for v in x], y, [v.index for v in y]
+
+
+def test_adjoint_rule(setup):                                        # :206-217 — dest[j, i] = A[i, j], then matvecmul!
+    model, rng, x, xi, y, yi = setup
+    A = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((4, 6)), model)
+    for expr in (P.adjoint(A) * x, A.T * x):
+        for _ in range(2):
+            model.setdirty()
+            got = expr()
+            assert affvec(got) == O.AffVec(6).matvecmul_vars(np.ascontiguousarray(A().T), xi).as_tuples()
+    B = P.Parameter(model, val=rng.random((3, 4)))
+    chained = A.T * (B.T * y)                                        # A' (B' y): the adjoint feeding matvecmul! over Vector{AffineFunction}
+    inner = O.AffVec(4).matvecmul_vars(np.ascontiguousarray(B().T), yi)
+    assert affvec(chained()) == O.AffVec(6).matvecmul_affs(np.ascontiguousarray(A().T), inner).as_tuples()
+
+
+def test_nary_plus_rule(setup):                                      # :234-236 — a + b + c + d  ->  ((a + b) + c) + d with vecadd!
+    model, rng, x, xi, y, yi = setup
+    A = P.Parameter(model, val=rng.random((3, 4)))
+    B = P.Parameter(model, val=rng.random((3, 3)))
+    b = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(3)), np.zeros(3), model)
+    c = P.Parameter(model, val=rng.random(3))
+    f1, f2 = A * x, B * y
+    expr = f1 + f2 + b + c
+    for _ in range(2):
+        model.setdirty()
+        r1 = O.AffVec(3).matvecmul_vars(A(), xi)
+        r2 = O.AffVec(3).matvecmul_vars(B(), yi)
+        s1 = O.AffVec(3).vecadd(r1, r2)
+        s2 = O.AffVec(3).vecadd(s1, b())
+        want = O.AffVec(3).vecadd(s2, c())
+        assert affvec(expr()) == want.as_tuples()
+    # scalar n-ary +: quadratic + affine + number  (add! forms :238-247)
+    q = P.Parameter(model, val=rng.random(4))
+    s = P.Parameter(lambda: 1.25, model)
+    e2 = P.dot(f1, f1) + P.dot(q, x) + s
+    w = O.Quad().vecdot_affs_affs(r1, r1)
+    lin = O.vecdot_aff_numbers_vars(q(), xi)
+    got = quad(e2())
+    # add!(dest::QuadraticFunction, x, ::AffineFunction) appends the affine terms and adds the constants, add!(dest, ::Number) the number
+    # (src/functions.jl:452-461): built from the oracle's pieces
+    wq, wl, wc = w.as_tuple()
+    ll, lc = lin.as_tuple()
+    assert got[0] == wq and got[1] == wl + ll and got[2] == (wc + lc) + 1.25
+
+
+def test_mul_rule_all_orderings(setup):                              # :260-274 — mul!(dest, a, b), four orderings
+    model, rng, x, xi, y, yi = setup
+    A = P.Parameter(model, val=rng.random((3, 4)))
+    b = P.Parameter(model, val=rng.random(3))
+    w = P.Parameter(lambda: 3.5, model)
+    res = A * x - b
+    ref_res = O.AffVec(3).vecsubtract(O.AffVec(3).matvecmul_vars(A(), xi), b())
+    qq = P.dot(res, res)
+    ref_q = O.Quad().vecdot_affs_affs(ref_res, ref_res)
+    for expr in (w * qq, qq * w):                                    # Number x QuadraticFunction, both orders
+        assert quad(expr()) == O.Quad().mul_quad_number(ref_q, 3.5).as_tuple()
+    f = P.dot(b, res)                                                # an AffineFunction (numbers . Vector{AffineFunction})
+    ref_f = O.vecdot_aff_numbers_affs(b(), ref_res)
+    for expr in (w * f, f * w):                                      # Number x AffineFunction
+        assert aff(expr()) == O.Aff().mul_aff_number(ref_f, 3.5).as_tuple()
+    for expr in (f * x[1], x[1] * f):                                # AffineFunction x Variable -> QuadraticFunction
+        assert quad(expr()) == O.Quad().mul_aff_var(ref_f, xi[1]).as_tuple()
+
+
+def test_bilinearmul_rule(setup):                                    # :219-226 — transpose(x) * Q * y  (functions.jl:840-858, the Q' pairing)
+    model, rng, x, xi, y, yi = setup
+    Q = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((4, 4)), model)
+    expr = P.transpose(x) * Q * x
+    for _ in range(2):
+        model.setdirty()
+        assert quad(expr()) == O.Quad().bilinearmul(Q(), xi, xi).as_tuple()
+    R = P.Parameter(model, val=rng.random((4, 3)))                   # rectangular: x' R y
+    assert quad((P.transpose(x) * R * y)()) == O.Quad().bilinearmul(R(), xi, yi).as_tuple()
+    assert quad(P.bilinear(x, R, y)()) == O.Quad().bilinearmul(R(), xi, yi).as_tuple()
+
+
+def test_scale_rule_three_operand_types(setup):                      # :284-290 — scale!(dest, a, b), both orders
+    model, rng, x, xi, y, yi = setup
+    dt = P.Parameter(lambda: 0.75, model)
+    for expr in (dt * x, x * dt):                                    # Number x Vector{Variable} -> Vector{LinearTerm}
+        assert [(t.coeff, t.var.index) for t in expr()] == [tuple(t) for t in O.scale_number_vars(0.75, xi)]
+    v = P.Parameter(model, val=rng.random(5))
+    for expr in (dt * v, v * dt):                                    # Number x Vector{Number}
+        assert np.array_equal(expr(), 0.75 * v())
+    A = P.Parameter(model, val=rng.random((3, 4)))
+    b = P.Parameter(model, val=rng.random(3))
+    r = A * x + b
+    ref = O.AffVec(3).vecadd(O.AffVec(3).matvecmul_vars(A(), xi), b())
+    for expr in (dt * r, r * dt):                                    # Number x Vector{AffineFunction}
+        assert affvec(expr()) == O.AffVec(3).scale_number_affs(0.75, ref).as_tuples()
+
+
+def test_vcat_rule_ragged(setup):                                    # :276-278 — vcat!(dest, args...) over rows of 4, 3, 1 and 0 terms
+    model, rng, x, xi, y, yi = setup
+    A = P.Parameter(lambda a: a.__setitem__(slice(None), rng.random(a.shape)), np.zeros((2, 4)), model)
+    B = P.Parameter(model, val=rng.random((3, 3)))
+    l = P.Parameter(model, val=rng.random(4))
+    f1, f2, f3 = A * x, B * y, x - l
+    expr = P.vcat(f1, f2, f3, f1)
+    for _ in range(2):
+        model.setdirty()
+        r1 = O.AffVec(2).matvecmul_vars(A(), xi)
+        r2 = O.AffVec(3).matvecmul_vars(B(), yi)
+        r3 = O.AffVec(4).vecsubtract(xi, l())
+        assert affvec(expr()) == O.AffVec(2 + 3 + 4 + 2).vcat(r1, r2, r3, r1).as_tuples()
+
+
+def test_vecdot_rule_variable_forms(setup):                          # :228-232 — x . x, terms . terms (functions.jl:665-700)
+    model, rng, x, xi, y, yi = setup
+    s = P.Parameter(lambda: 2.0, model)
+    sx = s * x                                                       # Vector{LinearTerm}
+    got = quad(P.dot(sx, sx)())
+    assert got == O.Quad().vecdot_terms_terms([(2.0, i) for i in xi], [(2.0, i) for i in xi]).as_tuple()
+    got2 = quad(P.dot(sx, x)())
+    assert got2 == O.Quad().vecdot_terms_terms([(2.0, i) for i in xi], [(1.0, i) for i in xi]).as_tuple()

@@ -1,0 +1,248 @@
+"""-m gpu: small plans (csrc/small.hip) — a run of small tape entries replayed as ONE launch of the interpreter kernel.
+
+The reference walks README Example 1's DAG at nanoseconds per hop (src/lazyexpression.jl:50-61, src/model.jl:132-143); the fused replay is
+what makes the device path competitive there.  Checked here: (1) through the C ABI alone, the fused replay of config 1's whole update!
+(four Parameter callbacks with dynamic seeds, residual, literal objective with the MOI copy under a permuted varmap, constraint block)
+against the committed golden fixture and the oracle, bit for bit, and against the unfused replay of the same tape; (2) every supported
+node kind, fused against unfused; (3) the bounds — a large node stays a launch of its own; (4) through the host API: Model.initialize
+selects the small plan by itself and update! is one launch."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class Plan:
+    def __init__(self):
+        import gpu_util as g
+        g.lib()
+        self.g = g
+        self.plan = C.c_void_p()
+        g.call("pmt_plan_create", 0, g.stream(), C.byref(self.plan))
+        self.rec = C.c_void_p(g.lib().pmt_plan_recording_stream(self.plan))
+
+    def __enter__(self):
+        self.g.call("pmt_plan_begin_record", self.plan)
+        return self
+
+    def __exit__(self, *a):
+        self.g.call("pmt_plan_end_record", self.plan)
+
+    def fused(self):
+        gr, n, ln = C.c_int(), C.c_int(), C.c_int64()
+        self.g.call("pmt_plan_fused", self.plan, C.byref(gr), C.byref(n), C.byref(ln))
+        return gr.value, n.value, ln.value
+
+    def update(self):
+        self.g.call("pmt_plan_update", self.plan)
+
+    def fusion(self, on):
+        self.g.call("pmt_plan_set_fusion", self.plan, 1 if on else 0)
+
+    def close(self):
+        torch.cuda.synchronize()
+        self.g.call("pmt_plan_destroy", self.plan)
+
+
+def test_config1_update_is_one_launch_and_matches_golden_and_oracle():
+    import gpu_util as g
+    from oracle import oracle as O
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1_readme_example1.npz"))
+    n, r, m = int(gold["n"]), int(gold["r"]), int(gold["m"])
+    A, b, Cm, d = g.empty_f64(r * n), g.empty_f64(r), g.empty_f64(m * n), g.empty_f64(m)
+    xvar, vm = g.to_dev(np.arange(1, n + 1, dtype=np.int64)), g.to_dev(gold["varmap"])
+    lt, cst = g.empty_terms(r * n, g.LT), g.empty_f64(r)
+    oq, ol, oc = g.empty_terms(r * n * n, g.QT), g.empty_terms(2 * r * n, g.LT), g.empty_f64(1)
+    vt, vc = g.empty_terms(m * n, g.VAT), g.empty_f64(m)
+    seeds = [C.c_uint64(s) for s in (1, 2, 3, 4)]                     # the golden fixture's Parameter streams
+    p = Plan()
+    with p:
+        g.call("pmt_fill_uniform_dyn_f64", g.ptr(A), r, n, r, C.byref(seeds[0]), 1.0, p.rec)
+        g.call("pmt_fill_uniform_dyn_f64", g.ptr(b), r, 1, r, C.byref(seeds[1]), 1.0, p.rec)
+        g.call("pmt_fill_uniform_dyn_f64", g.ptr(Cm), m, n, m, C.byref(seeds[2]), 1.0, p.rec)
+        g.call("pmt_fill_uniform_dyn_f64", g.ptr(d), m, 1, m, C.byref(seeds[3]), 2.0, p.rec)
+        g.call("pmt_affine_assemble_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, g.ptr(lt), g.ptr(cst), p.rec)
+        g.call("pmt_quad_expand_f64", r, g.ptr(lt), n, g.ptr(cst), g.ptr(lt), n, g.ptr(cst), 1, g.ptr(vm), g.ptr(oq), g.ptr(ol), g.ptr(oc), p.rec)
+        g.call("pmt_affine_pack_vector_f64", g.ptr(Cm), m, m, n, g.ptr(xvar), g.ptr(d), -1, g.ptr(vm), 0, g.ptr(vt), g.ptr(vc), p.rec)
+    assert p.fused() == (1, 7, 1)                                     # one run, seven tape entries, ONE launch per update!
+    assert int(g.lib().pmt_plan_tape_length(p.plan)) == 7
+
+    def outputs():
+        return (g.terms_to_host(oq, r * n * n, g.QT), g.terms_to_host(ol, 2 * r * n, g.LT), g.f64_to_host(oc, 1),
+                g.terms_to_host(vt, m * n, g.VAT), g.f64_to_host(vc, m), g.f64_to_host(A, r * n))
+
+    p.update()
+    q, l, c, v, vcs, a_host = outputs()
+    assert g.same_bits(a_host, gold["A"])
+    g.assert_terms_equal(q, gold["literal_quad"])
+    g.assert_terms_equal(l, gold["literal_aff"])
+    assert g.same_bits(c, gold["const"])
+    g.assert_terms_equal(v, gold["constraint_terms"])
+    assert g.same_bits(vcs, gold["constraint_consts"])
+    # the next update!: every callback draws its next stream (seed + 1000 per epoch); against the oracle, and against the unfused replay
+    for epoch in (1, 2):
+        for k, w in enumerate(seeds):
+            w.value = k + 1 + 1000 * epoch
+        p.update()
+        fused = outputs()
+        Ah = O.fill_uniform(r * n, 1 + 1000 * epoch); bh = O.fill_uniform(r, 2 + 1000 * epoch)
+        Ch = O.fill_uniform(m * n, 3 + 1000 * epoch); dh = O.fill_uniform(m, 4 + 1000 * epoch, 2.0)
+        w_ = O.LsqWorkspace(n, r, m)
+        xi = np.arange(1, n + 1, dtype=np.int64)
+        w_.eval_objective(Ah, bh, xi); w_.eval_constraint(Ch, dh, xi)
+        at, qt, const = w_.objective.moi(gold["varmap"])
+        ct, cc = w_.constraint.moi(gold["varmap"])
+        assert np.array_equal(fused[0].view(np.int64), qt.view(np.int64)) and np.array_equal(fused[1].view(np.int64), at.view(np.int64))
+        assert fused[2][0] == const and np.array_equal(fused[3].view(np.int64), ct.view(np.int64)) and np.array_equal(fused[4], cc)
+        for t in (oq, ol, vt):
+            t.fill_(-7)
+        p.fusion(False)
+        assert p.fused() == (0, 0, 7)
+        p.update()
+        plain = outputs()
+        p.fusion(True)
+        for f_, u_ in zip(fused, plain):
+            assert np.array_equal(np.ascontiguousarray(f_).view(np.int64), np.ascontiguousarray(u_).view(np.int64))
+    p.close()
+
+
+def test_every_node_kind_fused_equals_unfused():
+    """vars_addsub (bounds), consts, the three MOI packs of materialised functions (uniform and ragged rows), copy, static-seed fills, the
+    native (moi = 0) literal objective: one tape, replayed fused and as recorded; identical bytes in every output buffer"""
+    import gpu_util as g
+    rng = np.random.default_rng(5)
+    n, rows = 11, 5
+    vmh = rng.permutation(n).astype(np.int64) + 1
+    xvar, vm = g.to_dev(np.arange(1, n + 1, dtype=np.int64)), g.to_dev(vmh)
+    A, b, lows = g.empty_f64(rows * n), g.empty_f64(rows), g.empty_f64(n)
+    lt, cst = g.empty_terms(rows * n, g.LT), g.empty_f64(rows)
+    q0, l0, c0 = g.empty_terms(rows * n * n, g.QT), g.empty_terms(2 * rows * n, g.LT), g.empty_f64(1)
+    sq, sa = g.empty_terms(rows * n * n, g.QT), g.empty_terms(2 * rows * n, g.LT)
+    va = g.empty_terms(rows * n, g.VAT)
+    ragged_ptr = np.array([0, 3, 3, 10, 11, rows * n], dtype=np.int64)
+    va2, rp = g.empty_terms(rows * n, g.VAT), g.to_dev(ragged_ptr)
+    bt_lt, bt_vat, bc = g.empty_terms(n, g.LT), g.empty_terms(n, g.VAT), g.empty_f64(n)
+    cs, cp = g.empty_f64(rows), g.empty_f64(rows)
+    outs = [lt, cst, q0, l0, c0, sq, sa, va, va2, bt_lt, bt_vat, bc, cs, cp]
+    p = Plan()
+    with p:
+        g.call("pmt_fill_uniform_matrix_f64", g.ptr(A), rows, n, rows, C.c_uint64(11), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(b), rows, C.c_uint64(12), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(lows), n, C.c_uint64(13), -1.0, p.rec)
+        g.call("pmt_affine_assemble_f64", g.ptr(A), rows, rows, n, g.ptr(xvar), g.ptr(b), 1, g.ptr(lt), g.ptr(cst), p.rec)
+        g.call("pmt_quad_expand_f64", rows, g.ptr(lt), n, g.ptr(cst), g.ptr(lt), n, g.ptr(cst), 0, None, g.ptr(q0), g.ptr(l0), g.ptr(c0), p.rec)
+        g.call("pmt_pack_scalar_quadratic_f64", g.ptr(q0), rows * n * n, g.ptr(vm), g.ptr(sq), p.rec)
+        g.call("pmt_pack_scalar_affine_f64", g.ptr(l0), 2 * rows * n, g.ptr(vm), g.ptr(sa), p.rec)
+        g.call("pmt_pack_vector_affine_f64", g.ptr(lt), None, rows, n, g.ptr(vm), 3, g.ptr(va), p.rec)
+        g.call("pmt_pack_vector_affine_f64", g.ptr(lt), g.ptr(rp), rows, 0, g.ptr(vm), 0, g.ptr(va2), p.rec)
+        g.call("pmt_vars_addsub_f64", g.ptr(xvar), n, g.ptr(lows), -1, g.ptr(vm), 2, g.ptr(bt_lt), g.ptr(bt_vat), g.ptr(bc), p.rec)
+        g.call("pmt_consts_f64", g.ptr(b), rows, -1, g.ptr(cs), p.rec)
+        g.call("pmt_copy_bytes", g.ptr(cp), g.ptr(cs), 8 * rows, p.rec)
+    groups, nodes, ln = p.fused()
+    # the ragged pack's size lives on the device: it stays a launch of its own and cuts the run in two
+    assert (groups, nodes, ln) == (2, 11, 3)
+    p.update()
+    torch.cuda.synchronize()
+    fused = [t.clone() for t in outs]
+    for t in outs:
+        t.fill_(-7) if t.dtype == torch.int64 else t.fill_(float("nan"))
+    p.fusion(False)
+    p.update()
+    torch.cuda.synchronize()
+    for f_, t in zip(fused, outs):
+        assert torch.equal(f_.view(torch.int64), t.view(torch.int64))
+    # and the values mean what they should: the bounds rows, the doubled diagonal of the scalar quadratic pack
+    sqh, q0h = g.terms_to_host(sq, rows * n * n, g.QT), g.terms_to_host(q0, rows * n * n, g.QT)
+    diag = q0h["row"] == q0h["col"]
+    assert np.array_equal(sqh["coeff"][diag], 2 * q0h["coeff"][diag]) and np.array_equal(sqh["coeff"][~diag], q0h["coeff"][~diag])
+    assert np.array_equal(sqh["row"], vmh[q0h["row"] - 1]) and np.array_equal(sqh["col"], vmh[q0h["col"] - 1])
+    bth = g.terms_to_host(bt_vat, n, g.VAT)
+    assert np.array_equal(bth["out"], np.arange(3, n + 3)) and np.all(bth["coeff"] == 1.0) and np.array_equal(bth["var"], vmh)
+    p.close()
+
+
+def test_large_nodes_keep_their_own_kernels():
+    """the interpreter is one workgroup: an entry that writes more than 32768 elements is replayed by its own kernel, and a run is cut
+    before it exceeds 65536"""
+    import gpu_util as g
+    n, r = 256, 256                                               # 65536 LinearTerms: above the per-node bound
+    A, b = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    lt, cst = g.empty_terms(r * n, g.LT), g.empty_f64(r)
+    small_out = [g.empty_f64(20000) for _ in range(5)]
+    p = Plan()
+    with p:
+        g.call("pmt_fill_uniform_f64", g.ptr(b), r, C.c_uint64(2), 1.0, p.rec)
+        g.call("pmt_fill_uniform_matrix_f64", g.ptr(A), r, n, r, C.c_uint64(1), 1.0, p.rec)                   # 65536 elements: alone
+        g.call("pmt_affine_assemble_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, g.ptr(lt), g.ptr(cst), p.rec)   # alone
+        for k, t in enumerate(small_out):                                                                      # 5 x 20000: runs of 3 + 2
+            g.call("pmt_fill_uniform_f64", g.ptr(t), 20000, C.c_uint64(20 + k), 1.0, p.rec)
+    assert p.fused() == (2, 5, 5)          # [b] [A] [assemble] [3 fills] [2 fills]
+    p.update()
+    from oracle import oracle as O
+    for k, t in enumerate(small_out):
+        assert g.same_bits(g.f64_to_host(t, 20000), O.fill_uniform(20000, 20 + k))
+    got = g.terms_to_host(lt, r * n, g.LT)
+    assert g.same_bits(got["coeff"].reshape(r, n), O.fill_uniform(r * n, 1).reshape(n, r).T)
+    p.close()
+
+
+@pytest.mark.parametrize("mode", ["literal", "canonical"])
+def test_model_selects_the_small_plan_by_itself(mode):
+    """README Example 1 through the host API with device-side callbacks: Model.initialize records the callbacks into the tape and the
+    library fuses; update! is ONE launch (literal) and what the optimizer receives equals the oracle for every epoch's Parameter values"""
+    import parametron_jl_amd as P
+    from oracle import oracle as O
+    from qp_solver import DenseQPOptimizer
+    n, m = 8, 2
+    opt = DenseQPOptimizer(variable_offset=0, permute_seed=7)
+    model = P.Model(opt, quadratic_mode=mode)
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((n, n), 1, model); b = P.DeviceUniformParameter((n,), 2, model)
+    Cm = P.DeviceUniformParameter((m, n), 3, model); d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, Cm * x == d)
+    for it in range(4):
+        P.solve(model)
+        fz = model.device().fused()
+        # every kernel of the update! — four callbacks, residual, objective, constraint — is ONE launch; what is left of the tape are the
+        # recorded D2H fetches of the MOI buffers (copies, not kernels)
+        assert fz["groups"] == 1 and fz["nodes"] >= 7 and fz["exec_length"] == model.device().tape_length() - fz["nodes"] + 1, fz
+        if mode == "literal":
+            P.profile_enable(True)
+            model.setdirty(); model._run_tape(fetch=False); model.device().synchronize()
+            rep = P.profile_report()
+            P.profile_enable(False)
+            assert list(rep) == ["small_plan_kernel"] and rep["small_plan_kernel"]["launches"] == 1, rep
+        assert all(getattr(p_, "_in_tape", False) for p_ in (A, b, Cm, d))
+        vm = model.model_var_to_optimizer
+        w = O.LsqWorkspace(n, n, m)
+        xi = np.arange(1, n + 1, dtype=np.int64)
+        Ah, bh, Ch, dh = (O.fill_uniform(int(np.prod(p_.shape)), p_.current_seed(), p_.scale) for p_ in (A, b, Cm, d))
+        assert g_same(np.asfortranarray(A()).reshape(-1, order="F"), Ah) and g_same(d(), dh)       # the host copies are this epoch's values
+        w.eval_objective(Ah, bh, xi); w.eval_constraint(Ch, dh, xi)
+        f = model.objective.f
+        if mode == "canonical":
+            w.objective.canonicalize()
+        at, qt, const = w.objective.moi(vm)
+        assert np.array_equal(f.quadratic_terms["row"], qt["row"]) and np.array_equal(f.quadratic_terms["col"], qt["col"])
+        if mode == "literal":
+            assert np.array_equal(f.quadratic_terms.view(np.int64), qt.view(np.int64)) and np.array_equal(f.affine_terms.view(np.int64), at.view(np.int64))
+        else:
+            np.testing.assert_allclose(f.quadratic_terms["coeff"], qt["coeff"], rtol=1e-12, atol=0)
+            np.testing.assert_allclose(f.affine_terms["coeff"], at["coeff"], rtol=1e-12, atol=0)
+        assert f.constant == const
+        ct, cc = w.constraint.moi(vm)
+        cf = list(model.constraints)[0].f
+        assert np.array_equal(cf.terms.view(np.int64), ct.view(np.int64)) and np.array_equal(cf.constants, cc)
+    model.close()
+
+
+def g_same(a, b):
+    import gpu_util as g
+    return g.same_bits(a, b)
