@@ -177,6 +177,16 @@ int pmt_quad_expand_f64(int64_t rows,
  *   native canonical form has diagonal coefficient (A'A)[j,j] and off-diagonal 2*(A'A)[j,k].
  * f64 MFMA contraction; `workspace` (device, pmt_quad_gram_workspace_bytes) holds split-K partial tiles and the chunk / chain sums. */
 size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
+/* The summation order of the node's constant c'c for an r x n problem — fixed by (rows, cols) alone, reported so that a caller (and the
+ * parity tests) can restate it:
+ *   order 0  sequential, the reference's left-to-right sum (src/functions.jl:574), bit for bit
+ *   order 1  `groups` = 2048 interleaved chains (chain t adds rows t, t + 2048, .. in order), chain totals added left to right: rows > 8192,
+ *            or a sequential chain that would take half as long as the contraction beside it or longer (few columns; cost model in gram.hip)
+ *   order 2  the fused tall form (cols <= 128, rows >= 1024; csrc/gram_tall.hip): `groups` workgroups, workgroup g takes the stages
+ *            g, g + groups, .. of `stage_rows` rows; per stage eight row-pair lanes (rows 16 j + 2 p, + 1) add their squares in row order,
+ *            an 8-lane tree ((0+4)+(2+6))+((1+5)+(3+7)) closes a workgroup, the workgroups are added in 16 interleaved slices, then the slices
+ * Every order is within (rows / 2048 + 2048) * eps / 2 relative of the exact sum for same-signed terms: far inside the 1e-12 parity bar. */
+int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows);
 int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
                       const int64_t *xvar, const double *b, int sign,
                       int moi, const int64_t *varmap,

@@ -210,6 +210,12 @@ consts!(out::DevPtr, d::DevPtr, n, sign, stream) =
 transpose!(dst::DevPtr, ldd, src::DevPtr, lds, rows, cols, stream) =
     check(ccall((:pmt_transpose_f64, lib), Cint, (DevPtr, Int64, Int64, Int64, DevPtr, Int64, Ptr{Cvoid}), src, lds, rows, cols, dst, ldd, stream))
 
+"(order, groups, stage_rows): the fixed summation order of the node's constant for an r x n problem (include/parametron_hip.h)"
+function quad_gram_constant_order(rows, cols)
+    o = Ref{Cint}(0); g = Ref{Cint}(0); s = Ref{Cint}(0)
+    check(ccall((:pmt_quad_gram_constant_order, lib), Cint, (Int64, Int64, Ref{Cint}, Ref{Cint}, Ref{Cint}), rows, cols, o, g, s))
+    Int(o[]), Int(g[]), Int(s[])
+end
 "bytes of workspace pmt_quad_gram_f64 needs for an r x n problem"
 quad_gram_workspace_bytes(rows, cols) = ccall((:pmt_quad_gram_workspace_bytes, lib), Csize_t, (Int64, Int64), rows, cols)
 

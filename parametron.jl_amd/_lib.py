@@ -59,6 +59,7 @@ SIGNATURES = {
     "pmt_vecdot_numbers_affs_f64": (_ci, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "pmt_quad_expand_f64": (_ci, [_i64, _vp, _i64, _vp, _vp, _i64, _vp, _ci, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_workspace_bytes": (_sz, [_i64, _i64]),
+    "pmt_quad_gram_constant_order": (_ci, [_i64, _i64, C.POINTER(_ci), C.POINTER(_ci), C.POINTER(_ci)]),
     "pmt_quad_gram_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_csc_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pmt_quad_gram_csc_deliver_f64": (_ci, [_vp, _i64, _i64, _i64, _vp, _vp, _ci, _vp, _f64, _vp, _vp, _ci, _vp, _vp, _vp, _vp]),

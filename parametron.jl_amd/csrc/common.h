@@ -40,7 +40,7 @@ int dispatch(void *stream, Launch launch);
 // closure; pmt_plan_end_record then replaces every run of consecutive small nodes by ONE launch of an interpreter kernel that executes
 // them in tape order with a workgroup barrier between dependent nodes.  Outputs are bit-identical to the separate kernels.
 enum SmallOp : int {
-    SOP_FILL = 1, SOP_AFFINE_LT, SOP_AFFINE_VAT, SOP_QUAD_EXPAND, SOP_VARS_ADDSUB, SOP_CONSTS, SOP_PACK_SA, SOP_PACK_SQ, SOP_PACK_VA, SOP_COPY8
+    SOP_FILL = 1, SOP_AFFINE_LT, SOP_AFFINE_VAT, SOP_QUAD_EXPAND, SOP_VARS_ADDSUB, SOP_CONSTS, SOP_PACK_SA, SOP_PACK_SQ, SOP_PACK_VA, SOP_COPY8, SOP_GRAM
 };
 struct SmallNode {
     int op = 0, sign = 0, moi = 0;

@@ -26,7 +26,9 @@ namespace pmt {
 
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 void mark_no_graph(void *stream);
-int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s);
+int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s, int chained);
+int gram_tall_groups(int64_t rows);
+int gram_tall_stage_rows();
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *gbeg, const int64_t *gend, hipStream_t s);
@@ -106,6 +108,20 @@ __global__ __launch_bounds__(256) void gram_linear_finish_kernel(const double *_
 
 constexpr int64_t LIN_CHUNK_MIN = 4096;      // rows per (column, chunk) wave at least: 64 iterations of 64 lanes
 constexpr int64_t LIN_WAVES = 8192;          // waves that fill the chip (256 CUs x 32)
+// The constant c'c of the stream-K node: sequential (the reference's left-to-right sum, src/functions.jl:574, bit for bit) or 2048 chains.
+// The sequential chain runs on one wave beside the contraction at ~0.07 us per row (0.287 ms at r = 4096, profiles/r04_c2_rocprofv3_kernel_stats.csv);
+// the contraction takes T(r) = 0.096 + 0.276 r / 1024 ms at n = 4096 (528 tiles), in proportion to the tile count
+// elsewhere.  The chain is kept where the contraction hides it (config 2: 0.29 of 1.19 ms); where it would be half of the node or more
+// (few columns) the chained form takes over, as it always does above 8192 rows.  Bit-exactness of the constant is not part of the
+// parity bar (1e-12 relative); the order is fixed either way and reported by pmt_quad_gram_constant_order.
+static bool constant_chained(int64_t rows, int64_t cols) {
+    if (rows > 8192) return true;
+    if (rows < 2048) return false;
+    const double nt = (double)cdiv(std::max<int64_t>(cols, 1), GT);
+    const double contraction_ms = (0.096 + 0.276 * (double)rows / 1024.0) * (nt * (nt + 1) / 2) / 528.0;
+    return 0.07e-3 * (double)rows > 0.5 * contraction_ms;
+}
+
 static int linear_splits(int64_t rows, int64_t cols) {
     if (cols <= 0) return 1;
     return (int)std::max<int64_t>(1, std::min(cdiv(LIN_WAVES, cols), rows / LIN_CHUNK_MIN));
@@ -416,6 +432,15 @@ hipStream_t side_stream_of(hipStream_t s) {
 
 using namespace pmt;
 
+extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows) {
+    PMT_REQUIRE(rows >= 0 && cols >= 0 && order, PMT_INVALID_ARGUMENT, "quad_gram_constant_order: bad argument");
+    const bool tall = cols > 0 && gram_tall_applies(rows, cols);
+    *order = tall ? 2 : (constant_chained(rows, cols) ? 1 : 0);
+    if (groups) *groups = tall ? gram_tall_groups(rows) : (*order == 1 ? 2048 : 1);
+    if (stage_rows) *stage_rows = tall ? gram_tall_stage_rows() : 0;
+    return PMT_OK;
+}
+
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
     // behind the contraction's partial tiles: chunk sums of q (tall matrices) and the chains of the constant (long vectors); the fused
     // tall form (gram_tall.hip) keeps its per-chunk partials in the same buffer
@@ -560,7 +585,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         return dispatch(stream, [=](hipStream_t s) {
             return launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
         });
-    return dispatch(stream, [=](hipStream_t s) {
+    Launch node = [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
         // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.
         SideStream *side = side_stream(s);
@@ -619,7 +644,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         double *chains = scratch ? scratch + (size_t)linear_splits(rows, cols) * (size_t)cols : nullptr;
         auto const_part = [=]() -> int {
             int rc2 = PMT_OK;
-            if (b && sign && rows > 0) rc2 = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2);
+            if (b && sign && rows > 0) rc2 = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2, constant_chained(rows, cols) ? 1 : 0);
             else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc2 = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
             if (side) {
                 PMT_HIP_CHECK(hipEventRecord(side->join2, side->stream));
@@ -682,7 +707,17 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
         if (!rc && !defer_const) rc = const_part();          // (behind the contraction's launch: its workgroups are placed first)
         return rc;
-    });
+    };
+    // tiny shapes (README Example 1 with the canonical objective: 8 x 8): also a small-plan node — row-order sums by the interpreter kernel
+    // instead of four launches and a side-stream fork
+    if (!deliver_host && !out_csc && cols > 0 && rows * cols * (cols + 1) / 2 <= 16384 && rows <= 1024) {
+        SmallNode nd;
+        nd.op = SOP_GRAM; nd.sign = (b && sign) ? sign : 0; nd.moi = moi; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols;
+        nd.in[0] = A; nd.in[1] = xvar; nd.in[2] = b; nd.in[3] = varmap; nd.out[0] = out_quad; nd.out[1] = out_lin; nd.out[2] = out_const;
+        nd.work = rows * cols * (cols + 1) / 2 + 64 * rows;
+        return dispatch(stream, node, nd);
+    }
+    return dispatch(stream, node);
 }
 
 extern "C" int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign,

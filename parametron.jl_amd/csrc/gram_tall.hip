@@ -33,7 +33,7 @@
 #define PMT_TALL_ABL 0
 #endif
 #ifndef PMT_TALL_PF
-#define PMT_TALL_PF 2          // stages the global loads run ahead of the MFMAs (1 or 2)
+#define PMT_TALL_PF 1          // stages the global loads run ahead of the MFMAs (1; 2 = two register sets: measured equal, profiles/r05_gram_tall.txt)
 #endif
 #ifndef PMT_TALL_MAXG
 #define PMT_TALL_MAXG 512
@@ -365,6 +365,7 @@ static int64_t tall_chunk(int64_t rows) {
     const int64_t nst = cdiv(rows, TBK);
     return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, TALL_MAX_G));
 }
+int gram_tall_stage_rows() { return TBK; }
 int gram_tall_groups(int64_t rows) { return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows)); }
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols) {
     return gram_tall_applies(rows, cols) ? sizeof(double) * (size_t)gram_tall_groups(rows) * TSTRIDE : 0;

@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void dot_chains_kernel(const double *__restric
 size_t blocked_dot_scratch_doubles() { return DOT_CHAINS; }
 
 // launch_seq_dot for vectors of any length; `scratch` (DOT_CHAINS doubles, device) is only touched above DOT_EXACT_MAX elements
-int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s) {
-    if (n <= DOT_EXACT_MAX || !scratch) return launch_seq_dot(a, sign_a, b, sign_b, n, out, s);
+// chained != 0: take the chained form whatever the length (the caller's cost model, gram.hip: a sequential chain that would outlast the
+// contraction it sits beside)
+int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s, int chained) {
+    if (!scratch || (n <= DOT_EXACT_MAX && !chained)) return launch_seq_dot(a, sign_a, b, sign_b, n, out, s);
     if (n >= ((int64_t)1 << 31) - DOT_CHAINS) return fail(PMT_DIMENSION_MISMATCH, "blocked_dot: vector too long");
     if (a == b && sign_a == sign_b) PMT_LAUNCH_NAMED("dot_chains_kernel", dot_chains_kernel<true>, dim3(DOT_CHAINS / 256), dim3(256), 0, s, a, sign_a, b, sign_b, (int)n, scratch);
     else PMT_LAUNCH_NAMED("dot_chains_kernel", dot_chains_kernel<false>, dim3(DOT_CHAINS / 256), dim3(256), 0, s, a, sign_a, b, sign_b, (int)n, scratch);

@@ -166,6 +166,48 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         }
         break;
     }
+    case SOP_GRAM: {                       // gram.hip for tiny shapes: canonical least-squares objective, every sum in ROW order (the order of
+                                           // the reference's literal expansion, src/functions.jl:705-707, before canonicalize! re-sorts it)
+        const int64_t lda = n.d[0], rows = n.d[1], cols = n.d[2];
+        const double *A = static_cast<const double *>(n.in[0]);
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[1]);
+        const double *b = static_cast<const double *>(n.in[2]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
+        QT *oq = static_cast<QT *>(n.out[0]);
+        LT *ol = static_cast<LT *>(n.out[1]);
+        const int64_t nq = cols * (cols + 1) / 2;
+        for (int64_t e = tid; e < nq; e += nt) {
+            // e -> (j, k), j <= k, row-major upper triangle
+            int64_t j = (int64_t)((2.0 * cols + 1.0 - sqrt((2.0 * cols + 1.0) * (2.0 * cols + 1.0) - 8.0 * (double)e)) * 0.5);
+            if (j < 0) j = 0;
+            if (j > cols - 1) j = cols - 1;
+            while (j > 0 && j * cols - j * (j - 1) / 2 > e) --j;
+            while (j + 1 < cols && (j + 1) * cols - (j + 1) * j / 2 <= e) ++j;
+            const int64_t k = j + (e - (j * cols - j * (j - 1) / 2));
+            double acc = 0.0;
+            for (int64_t i = 0; i < rows; ++i) acc = acc + A[j * lda + i] * A[k * lda + i];
+            double c = acc;
+            if (n.moi || j != k) c = 2 * c;
+            const int64_t jv = xvar[j], kv = xvar[k];
+            QT t; t.coeff = c; t.row = n.moi ? map_var(varmap, jv) : jv; t.col = n.moi ? map_var(varmap, kv) : kv;
+            oq[e] = t;
+        }
+        for (int64_t j = tid; j < cols; j += nt) {
+            double acc = 0.0;
+            if (b && n.sign)
+                for (int64_t i = 0; i < rows; ++i) acc = acc + signed_const(b[i], n.sign) * A[j * lda + i];
+            const int64_t v = xvar[j];
+            LT t; t.coeff = 2 * acc; t.var = n.moi ? map_var(varmap, v) : v;
+            ol[j] = t;
+        }
+        if (tid == 0) {
+            double acc = 0.0;
+            if (b && n.sign)
+                for (int64_t i = 0; i < rows; ++i) { const double c = signed_const(b[i], n.sign); acc = acc + c * c; }
+            *static_cast<double *>(n.out[2]) = acc;
+        }
+        break;
+    }
     case SOP_COPY8: {
         const u64 *src = static_cast<const u64 *>(n.in[0]);
         u64 *dst = static_cast<u64 *>(n.out[0]);

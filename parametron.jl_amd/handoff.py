@@ -331,6 +331,12 @@ class DeviceQP:
                     ctx.call(name, *args)
                 if host == "overlap":
                     side_made = model._side_refreshed_parameter_ids() if in_tape == "side" else set()
+                    # a lane-3 transfer is ordered against its Parameter's producer only when that producer ran on the SIDE stream; the
+                    # Parameters concerned are marked, and whatever writes one of them on the plan's stream instead (the first replay below,
+                    # before Model._mark_side_lane_parameters; a value read outside update!) synchronises behind it (lazyexpression.device_value_of)
+                    for x_, _ in model._parameter_readers().values():
+                        if id(x_) in side_made:
+                            x_._read_unordered_by_lane3 = True
                     for t in self.host.transfers(late=False):
                         # a dense block straight out of its Parameter buffer depends on nothing of this re-evaluation: front of the side lane
                         # (lane 2) — and when the Parameter's value is itself produced on the side stream (only side-lane records read it),

@@ -163,8 +163,14 @@ def device_value_of(x, ctx=None):
                          C.c_uint64(x.current_seed()), x.scale)
                 else:
                     call("pmt_fill_uniform_f64", P(x._dev.buf), int(x.shape[0]), C.c_uint64(x.current_seed()), x.scale)
+                if not side and getattr(x, "_read_unordered_by_lane3", False) and not ctx.recording:
+                    # a recorded transfer at the very front of the side lane (lane 3) reads this buffer WITHOUT waiting for the plan's
+                    # stream: a value written on the plan's stream must be complete before the next replay can start it
+                    ctx.synchronize()
             else:
                 _upload_value(ctx, x._dev, val)
+                if getattr(x, "_read_unordered_by_lane3", False) and not ctx.recording:
+                    ctx.synchronize()                   # (a serial upload travels on the plan's stream as well)
             x._dev_version = x.version
         return x._dev
     return const_device_value(ctx, x)

@@ -280,6 +280,13 @@ class Model:
             self.model_var_to_optimizer = np.asarray(indexmap["variables"], dtype=np.int64).copy()
         if records:
             ctx = self.device()
+            # SMALL models (README Example 1): launch-bound on the device.  Their Parameter callbacks are recorded into the tape and the whole
+            # update! replays as one small plan (csrc/small.hip); overlapped recorded fetches — a signal kernel and a copy-engine transfer per
+            # MOI buffer, worth it for megabytes — would cut the run of small entries and cost more launches than the copies they hide
+            self._small = (not self._use_graph and self.handoff == "moi" and
+                           sum(int(getattr(getattr(p_, "val", None), "nnz", np.size(getattr(p_, "val", 0)))) for p_ in self.params) <= self.SMALL_MODEL_ELEMENTS)
+            if self._small:
+                self._overlap_moi = False
             self._varmap_buf = ctx.alloc(8 * max(self.nvars, 1))
             ident = np.arange(1, self.nvars + 1, dtype=np.int64)     # IdentityVarMap until mapindices! (src/moi_interop.jl:32-33)
             ctx.upload(self._varmap_buf, self.model_var_to_optimizer if early else ident)
@@ -355,11 +362,9 @@ class Model:
         took ~48 us where the reference's CPU walk of the same DAG takes ~15 (README.md:132-136)."""
         from .parameter import DeviceUniformParameter
         from .device import DMat, DVec
-        if self._use_graph:
+        if not getattr(self, "_small", False):
             return
         ps = [x for x in self._order if isinstance(x, Parameter)]
-        if sum(int(np.prod(np.shape(getattr(x, "val", 0)) or (1,))) for x in ps) > self.SMALL_MODEL_ELEMENTS:
-            return
         for x in ps:
             dv = getattr(x, "_dev", None)
             if not isinstance(x, DeviceUniformParameter) or getattr(x, "pattern", None) is not None or not isinstance(dv, (DMat, DVec)):

@@ -78,3 +78,46 @@ def assert_terms_equal(got, want):
             assert same_bits(got[f], want[f]), "field %s differs" % f
         else:
             assert np.array_equal(got[f], want[f]), "field %s differs" % f
+
+
+def constant_in_the_library_order(r, n, b, sign=-1):
+    """c'c restated on the CPU in the fixed order the library reports for an r x n node (pmt_quad_gram_constant_order): the reference's
+    left-to-right sum, the 2048 chains, or the fused tall form's per-workgroup / slice order (include/parametron_hip.h)"""
+    order, groups, stage = C.c_int(), C.c_int(), C.c_int()
+    call("pmt_quad_gram_constant_order", r, n, C.byref(order), C.byref(groups), C.byref(stage))
+    nb = (0.0 - b) if sign < 0 else (0.0 + b)
+    if order.value == 0:
+        seq = 0.0
+        for v in nb:
+            seq = seq + v * v
+        return order.value, seq
+    if order.value == 1:
+        chains = np.zeros(2048)
+        for i0 in range(0, r, 2048):
+            seg = nb[i0:i0 + 2048]
+            chains[:len(seg)] = chains[:len(seg)] + seg * seg
+        seq = 0.0
+        for v in chains:
+            seq = seq + v
+        return order.value, seq
+    G, MR = groups.value, stage.value
+    nst = -(-r // MR)
+    sq = np.zeros((nst + G) * MR)
+    sq[:r] = nb * nb                                                   # (rows beyond the matrix add 0.0: exact)
+    lanes = np.zeros((G, 8))
+    gi = np.arange(G)
+    for k in range(-(-nst // G)):                                      # workgroup g: stages g, g + G, g + 2G, ..
+        base = (gi + k * G) * MR
+        live = (gi + k * G) < nst
+        for j in range(MR // 16):
+            idx = base[:, None] + 16 * j + 2 * np.arange(8)[None, :]
+            lanes = np.where(live[:, None], (lanes + sq[idx]) + sq[idx + 1], lanes)
+    part = ((lanes[:, 0] + lanes[:, 4]) + (lanes[:, 2] + lanes[:, 6])) + ((lanes[:, 1] + lanes[:, 5]) + (lanes[:, 3] + lanes[:, 7]))
+    slices = np.zeros(16)
+    for g0 in range(0, G, 16):
+        seg = part[g0:g0 + 16]
+        slices[:len(seg)] = slices[:len(seg)] + seg
+    total = slices[0]
+    for t in range(1, 16):
+        total = total + slices[t]
+    return order.value, float(total)

@@ -34,12 +34,18 @@ def _sample_pairs(rng, n, count):
     k = rng.integers(1, n + 1, size=count)
     j, k = np.minimum(j, k), np.maximum(j, k)
     diag = rng.integers(1, n + 1, size=count // 10)                  # diagonal terms too (the MOI doubling)
-    edge = np.array([1, n, 1, n // 2, 127, 128, 129, n - 1])          # tile corners / edges
-    return np.concatenate([j, diag, edge[:4], edge[4:]]), np.concatenate([k, diag, [1, n, n, n // 2], [128, 128, 129, n]])
+    edge = np.minimum(np.array([1, n, 1, max(n // 2, 1), 127, 128, 129, max(n - 1, 1)]), n)          # tile corners / edges
+    ek = np.minimum(np.array([1, n, n, max(n // 2, 1), 128, 128, 129, n]), n)
+    ej, ek = np.minimum(edge, ek), np.maximum(edge, ek)
+    return np.concatenate([j, diag, ej]), np.concatenate([k, diag, ek])
 
 
-@pytest.mark.parametrize("r,n,count", [(4096, 4096, 10000), (16384, 1024, 6000), (4090, 1000, 4000), (131072, 256, 3000)])
-def test_canonical_objective_against_cpu_sampled_sums(r, n, count, record_property):
+# expect_order: 0 sequential constant (hidden behind the contraction: config 2), 1 chained (long vectors, or few columns: the cost model of
+# gram.hip), 2 the fused tall form (gram_tall.hip: n <= 128, r >= 1024 — one pass over A for Q, q and the constant)
+@pytest.mark.parametrize("r,n,count,expect_order", [(4096, 4096, 10000, 0), (16384, 1024, 6000, 1), (4090, 1000, 4000, 1), (131072, 256, 3000, 1),
+                                                     (1 << 20, 128, 1500, 2), (8192, 128, 3000, 2), (100003, 100, 2000, 2), (5000, 17, 150, 2),
+                                                     (1000, 128, 2000, 0)])
+def test_canonical_objective_against_cpu_sampled_sums(r, n, count, expect_order, record_property):
     import gpu_util as g
     q, l, const = _gram(g, r, n)
     A = O.fill_uniform(r * n, 1)                                      # the same stream as the device fill, bit for bit
@@ -57,24 +63,12 @@ def test_canonical_objective_against_cpu_sampled_sums(r, n, count, record_proper
     assert np.array_equal(l["var"], jl)
     np.testing.assert_allclose(l["coeff"], lw, rtol=1e-12, atol=0)
     np.testing.assert_allclose(l["coeff"], lw_ld, rtol=1e-12, atol=0)
-    if r <= 8192:
-        seq = 0.0
-        for v in 0.0 - b:
-            seq = seq + v * v
-        assert const == seq                                           # the constant is a left-to-right sum: bit for bit
-    else:
-        # long vectors: 2048 interleaved chains, chain totals added left to right (quad.hip, launch_blocked_dot) — the same fixed order here
-        nb = 0.0 - b
-        chains = np.zeros(2048)
-        for i0 in range(0, r, 2048):
-            seg = nb[i0:i0 + 2048]
-            chains[:len(seg)] = chains[:len(seg)] + seg * seg
-        seq = 0.0
-        for v in chains:
-            seq = seq + v
-        assert const == seq
-        import math
-        assert abs(const - math.fsum(nb * nb)) <= 1e-13 * const
+    # the constant: the library's fixed order for this shape, restated here — bit for bit — and within 1e-13 of the exact sum whatever the order
+    order, seq = g.constant_in_the_library_order(r, n, b)
+    assert order == expect_order and const == seq
+    import math
+    assert abs(const - math.fsum((0.0 - b) * (0.0 - b))) <= 1e-13 * const
+    if order != 0:
         assert _gram(g, r, n)[2] == const                             # deterministic
     err_hip = float(np.max(np.abs(got - want_ld) / np.abs(want_ld)))
     err_cpu = float(np.max(np.abs(want - want_ld) / np.abs(want_ld)))

@@ -96,7 +96,7 @@ def test_row_major_column_major_and_page_locked_parameter_values_upload_identica
 @pytest.mark.parametrize("r,n", [(1000, 40), (70, 130), (4090, 256)])
 def test_row_counts_that_are_not_a_multiple_of_16_use_zero_padded_copies(r, n):
     """The Gram objective is given the zero-padded row count (device.row_padded); zero rows change neither 2A'A, 2A'c nor c'c
-    (c'c stays the exact left-to-right sum: adding 0.0 is the identity), so the result equals numpy on the unpadded data."""
+    (c'c keeps its fixed order: adding 0.0 is the identity), so the result equals numpy on the unpadded data."""
     from parametron_jl_amd.device import row_padded
     from parametron_jl_amd.moi import _gram_rows
     rng = np.random.default_rng(r)
@@ -114,8 +114,10 @@ def test_row_counts_that_are_not_a_multiple_of_16_use_zero_padded_copies(r, n):
         iu = np.triu_indices(n)
         np.testing.assert_allclose(f.quadratic_terms["coeff"], (2 * Av.T @ Av)[iu], rtol=1e-12)
         np.testing.assert_allclose(f.affine_terms["coeff"], -2 * Av.T @ bv, rtol=1e-12)
-        seq = 0.0
-        for v in 0.0 - bv:
-            seq = seq + v * v
-        assert f.constant == seq
+        # the constant in the library's fixed order for the PADDED shape (sequential, or chained where the cost model says so:
+        # pmt_quad_gram_constant_order); the zero rows add 0.0 * 0.0
+        import gpu_util as g
+        rp = row_padded(r)
+        order, seq = g.constant_in_the_library_order(rp, n, np.concatenate([bv, np.zeros(rp - r)]))
+        assert f.constant == seq and order == (1 if (r, n) == (4090, 256) else 0)
         Av[...] = rng.random((r, n)); A.val[...] = Av; bv[...] = rng.random(r)      # overwrite: the padding must stay zero

@@ -145,11 +145,11 @@ def test_vcat_rule_ragged(setup):                                    # :276-278 
         assert affvec(expr()) == O.AffVec(2 + 3 + 4 + 2).vcat(r1, r2, r3, r1).as_tuples()
 
 
-def test_vecdot_rule_variable_forms(setup):                          # :228-232 — x . x, terms . terms (functions.jl:665-700)
+def test_vecdot_rule_variable_forms(setup):                          # :228-232 — x . x (functions.jl:665-687), numbers . x, x . numbers
     model, rng, x, xi, y, yi = setup
     s = P.Parameter(lambda: 2.0, model)
-    sx = s * x                                                       # Vector{LinearTerm}
-    got = quad(P.dot(sx, sx)())
-    assert got == O.Quad().vecdot_terms_terms([(2.0, i) for i in xi], [(2.0, i) for i in xi]).as_tuple()
-    got2 = quad(P.dot(sx, x)())
-    assert got2 == O.Quad().vecdot_terms_terms([(2.0, i) for i in xi], [(1.0, i) for i in xi]).as_tuple()
+    got = quad((s * P.dot(x, x))())                                  # vecdot!(::QuadraticFunction, x, x) under a mul! node
+    assert got == O.Quad().mul_quad_number(O.Quad().vecdot_vars_vars(xi, xi), 2.0).as_tuple()
+    w = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(4)), np.zeros(4), model)
+    for expr in (P.dot(w, x), P.dot(x, w)):
+        assert aff(expr()) == O.vecdot_aff_numbers_vars(w(), xi).as_tuple()
