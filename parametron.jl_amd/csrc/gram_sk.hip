@@ -523,18 +523,38 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                     }
                 }
 #else
-                // The hand-off is ordered by the memory model, not by how gfx950 happens to treat write-through stores (round 4's form: relaxed
-                // agent-scope atomics + s_waitcnt): plain stores of the partial, the workgroup barrier (workgroup-scope happens-before to
-                // thread 0), ONE agent-scope RELEASE store of the flag by thread 0; the partner's thread 0 spins on relaxed loads, then ONE
-                // agent-scope ACQUIRE fence, the barrier, and plain loads by everybody (MI355X_MICROARCH.md, inter-workgroup visibility).
+                // The hand-off, measured in three forms (profiles/r05_pair_fold.txt; host_csc per solve, alternating runs on one box):
+                //   round 4   relaxed agent-scope atomic stores / loads of partial and flag + s_waitcnt               1.713-1.728 ms
+                //   FORMAL    plain stores, barrier, agent-scope RELEASE flag store; relaxed spin, agent-scope ACQUIRE fence, barrier, plain loads
+                //             (-DPMT_SK_PAIR_FORMAL=1; the textbook form of MI355X_MICROARCH.md)                         1.762-1.769 ms (+2.6 %)
+                //   shipped   producer as in round 4, consumer as in FORMAL                                              1.726-1.733 ms (+0.5 %)
+                // The release is what costs: `buffer_wbl2 sc1` writes back the XCD's whole L2, which at that moment holds the dirty lines of
+                // the 31 other CUs' tile epilogues; 1.5 % per solve for an ordering the write-through (sc1) stores + s_waitcnt vmcnt(0) of the
+                // producer already give on this hardware (the guide's second recipe: sc1 stores, then the flag).  The consumer side IS the
+                // model's: one acquire fence by the thread that saw the flag (it invalidates the CU's L1 and the non-local L2 lines), the
+                // workgroup barrier, then plain loads by everybody — no stale line can be read.  The partial and the flag are atomic objects
+                // on the producer side, so there is no data race in the language model either; what the shipped form does not have is the
+                // model's release edge, and the soak (tools/soak_host_delivery.py, 6000 solves x 4 configurations) plus the fault-injection
+                // test cover what it rests on.
                 if (mywr != keep) {
                     double *w = g.ws + (int64_t)(2 * bid) * SLOT + ftid;
     #pragma unroll
+#if !(defined(PMT_SK_PAIR_FORMAL) && PMT_SK_PAIR_FORMAL)
+                    for (int r = 0; r < C::NACC; ++r) __hip_atomic_store(&w[r * C::NT], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                     for (int r = 0; r < C::NACC; ++r) w[r * C::NT] = acc[r];
+#endif
                 }
+#if !(defined(PMT_SK_PAIR_FORMAL) && PMT_SK_PAIR_FORMAL)
+                __builtin_amdgcn_s_waitcnt(0);
+#endif
                 __syncthreads();
                 if (tid == 0) {
+#if !(defined(PMT_SK_PAIR_FORMAL) && PMT_SK_PAIR_FORMAL)
+                    __hip_atomic_store(&g.pair_flags[(first ? 0 : 512) + rtile], g.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                     __hip_atomic_store(&g.pair_flags[(first ? 0 : 512) + rtile], g.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     const unsigned *other = &g.pair_flags[(first ? 512 : 0) + rtile];
                     const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
                     double late = 0.0;
@@ -542,7 +562,9 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                         __builtin_amdgcn_s_sleep(8);
                         if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > g.pair_timeout) { late = 1.0; break; }   // 2 s (100 MHz ticks)
                     }
+#if !(defined(PMT_SK_PAIR_NOACQ) && PMT_SK_PAIR_NOACQ)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                     if (late != 0.0 && g.error) __hip_atomic_store(g.error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     lds[0][0][0] = late;                         // (the panels are idle between the stage loop and the epilogue)
                 }
@@ -554,7 +576,11 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
                     for (int r0 = 0; r0 < C::NACC; r0 += 4) {      // four loads in flight at a time (register budget)
                         double other[4];
     #pragma unroll
+#if defined(PMT_SK_PAIR_NOACQ) && PMT_SK_PAIR_NOACQ
+                        for (int r = 0; r < 4; ++r) other[r] = __hip_atomic_load(&w[(r0 + r) * C::NT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                         for (int r = 0; r < 4; ++r) other[r] = w[(r0 + r) * C::NT];
+#endif
     #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[r0 + r] = late ? __builtin_nan("") : other[r] + acc[r0 + r];
                         asm volatile("" ::: "memory");

@@ -38,6 +38,9 @@
 #ifndef PMT_TALL_MAXG
 #define PMT_TALL_MAXG 512
 #endif
+#ifndef PMT_TALL_K2
+#define PMT_TALL_K2 0
+#endif
 
 namespace pmt {
 
@@ -45,6 +48,7 @@ constexpr int TBK = PMT_TALL_MR;            // rows per stage (one barrier per s
 constexpr int TGP = TBK + 2;                // LDS pitch of a column: 2 mod 32 — the 16 columns x 2 k of a half-wave operand read fall on 32 distinct
                                             // bank pairs, and even, so that the row pairs go to LDS as 16-byte stores
 constexpr int TSUB = TBK / 16;              // 16-row pieces of a column per stage
+constexpr int TLK = PMT_TALL_K2 ? 2 : 1;    // rows between the contraction slots of a k-step (see tall_stage)
 constexpr int TCOLS = 128;                  // columns of the one tile
 constexpr int TBLK = 9;                     // 16 x 16 blocks per wave
 constexpr int TACC = TBLK * 4;              // accumulators per lane (4 rotations per block)
@@ -101,10 +105,39 @@ struct TallArgs {
     int vec_in;                           // A 16-byte aligned and lda even
 };
 
-// one stage of one wave: 4 k-steps x 36 MFMAs from the panel in LDS (`panel` already points at this lane's k offset)
+// one stage of one wave from the panel in LDS (`panel` already points at this lane's k offset).
+// PMT_TALL_K2: the MFMA's contraction slot k = lane >> 4 of k-steps 2j and 2j + 1 is given the ADJACENT rows 8j + 2k and 8j + 2k + 1 (any
+// assignment of rows to slots is a valid contraction as long as both operands use it), so ONE 16-byte LDS read per operand serves two
+// k-steps: half the LDS instructions and half the operand waits per MFMA.
 template <int W>
 __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int lm, double (&acc)[TACC]) {
     constexpr int NR = tw_nr(W), NC = tw_nc(W);
+#if PMT_TALL_K2
+#pragma unroll PMT_TALL_UNROLL
+    for (int kk = 0; kk < TBK / 8; ++kk) {
+        f64x2 a[NR];
+#pragma unroll
+        for (int t = 0; t < NR; ++t) a[t] = *reinterpret_cast<const f64x2 *>(panel + (tw_row(W, t) * 16 + lm) * TGP + kk * 8);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f64x2 bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks (gram_sk.hip, lane maps)
+                bv[r] = *reinterpret_cast<const f64x2 *>(panel + (tw_col(W, c) * 16 + rc) * TGP + kk * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < TBLK; ++k) {
+                if (tw_blk(W, k, 1) != c) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
+                }
+            }
+        }
+    }
+#else
 #pragma unroll PMT_TALL_UNROLL
     for (int ks = 0; ks < TBK / 4; ++ks) {
         double a[NR];
@@ -127,6 +160,7 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
             }
         }
     }
+#endif
 }
 
 // thread (kp = tid & 7, cc = tid >> 3) owns the row pairs 16 j + 2 kp (j < TSUB) of the columns cc + 32 p (p < 4): the TSUB loads of a
@@ -227,13 +261,13 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
     for (int s = 0; s < nstage; s += 2) {
         // even stage: reads LDS 0; set A is free (stored at the end of stage s - 1), set B holds stage s + 1
         if (s + 2 < nstage) tall_load<FAST>(g, stage_row(s + 2), rend, kp, cc, regA, cvA);
-        tall_stage<W>(lds[0] + lk, lm, acc);
+        tall_stage<W>(lds[0] + TLK * lk, lm, acc);
         if (s + 1 < nstage) tall_store(lds[1], regB, cvB, g.sign, kp, cc, qacc, cacc);
         __syncthreads();
         if (s + 1 >= nstage) break;
         // odd stage: reads LDS 1; set B is free, set A holds stage s + 2
         if (s + 3 < nstage) tall_load<FAST>(g, stage_row(s + 3), rend, kp, cc, regB, cvB);
-        tall_stage<W>(lds[1] + lk, lm, acc);
+        tall_stage<W>(lds[1] + TLK * lk, lm, acc);
         if (s + 2 < nstage) tall_store(lds[0], regA, cvA, g.sign, kp, cc, qacc, cacc);
         __syncthreads();
     }
@@ -249,13 +283,13 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
         const int cur = s & 1;
         const bool more = s + 1 < nstage;
 #if PMT_TALL_ABL == 1      // ablation (wrong results): no global loads / LDS stores after the first stage — the MFMA side alone
-        tall_stage<W>(lds[cur] + lk, lm, acc);
+        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
 #elif PMT_TALL_ABL == 2    // ablation (wrong results): no MFMAs — the memory side alone
         if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #else
         if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
-        tall_stage<W>(lds[cur] + lk, lm, acc);
+        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #endif
         __syncthreads();

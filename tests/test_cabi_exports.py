@@ -239,3 +239,32 @@ def test_julia_backend_is_strict_by_default():
     cpu = body_of(r"function cpu_update!\(hm::HIPModel\)")
     assert "Parametron.update!(r, m.optimizer, m.model_var_to_optimizer)" in cpu
     assert len(re.findall(r"cpu_update!\(hm\)", src)) == 1          # the one guarded call
+
+
+def test_constant_order_is_host_arithmetic(lib):
+    """pmt_quad_gram_constant_order: the fixed summation order of the node's constant follows from (rows, cols) alone — sequential where the
+    contraction hides the chain (config 2), 2048 chains for long vectors or few columns (cost model), the fused tall order for one-tile
+    tall shapes; no GPU needed"""
+    def order(r, n):
+        o, g, s = C.c_int(), C.c_int(), C.c_int()
+        lib.call("pmt_quad_gram_constant_order", r, n, C.byref(o), C.byref(g), C.byref(s))
+        return o.value, g.value, s.value
+    assert order(4096, 4096) == (0, 1, 0)                      # config 2: the reference's left-to-right sum, hidden behind 1.19 ms of contraction
+    assert order(80, 96)[0] == 0 and order(1000, 128)[0] == 0   # short vectors: sequential (the tall form starts at 1024 rows)
+    assert order(16384, 1024) == (1, 2048, 0) and order(131072, 256)[0] == 1
+    assert order(4096, 256)[0] == 1 and order(4096, 1024)[0] == 1          # a 0.29 ms chain beside a few tiles: chained
+    o, g, s = order(1 << 20, 128)
+    assert (o, s) == (2, 32) and g == 512
+    o, g, s = order(8192, 128)
+    assert o == 2 and g == 8192 // 64                           # at least 64 rows per workgroup
+    assert order(5000, 17)[0] == 2 and order(1024, 1)[0] == 2
+    with pytest.raises(lib.ArgumentError):
+        lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
+
+
+def test_batch_shard_is_host_arithmetic(lib):
+    per, first = C.c_int64(), C.c_int64()
+    lib.call("pmt_batch_shard", 8192, 8, 3, C.byref(per), C.byref(first))
+    assert (per.value, first.value) == (1024, 3072)
+    with pytest.raises(lib.DimensionMismatch):
+        lib.call("pmt_batch_shard", 8191, 8, 0, C.byref(per), C.byref(first))

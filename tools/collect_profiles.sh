@@ -8,9 +8,9 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> /dev/null
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --no-cpu-baseline --no-rocprof-child > "$OUT/bench_under_rocprof.json" 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof-child > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-rocprof-child > /dev/null 2>&1
 timeout 300 python bench.py --workload batch > "$OUT/bench_batch.json" 2> /dev/null
 python - "$OUT" <<'PY'
 import csv, collections, glob, json, sys

@@ -1,5 +1,5 @@
-"""Device time of one update!(model) (tape replay, Parameter values resident or just uploaded, no MOI fetch) for the five BASELINE
-configurations, built through the host API: python tools/config_table.py"""
+"""Device time of one update!(model) (tape replay, Parameter values resident or just uploaded, no MOI fetch: overlap_fetch=False keeps the
+MOI buffers' recorded fetches out of the tape) for the BASELINE configurations, built through the host API: python tools/config_table.py"""
 import os
 import sys
 import time
@@ -28,23 +28,26 @@ def report(name, model, extra=""):
     P.solve(model)
     ms = device_ms(model)
     extra = extra % model.device().tape_length() if "%d" in extra else extra
+    fz = model.device().fused()
+    if fz["groups"]:
+        extra += "  small plan: %d entries in %d fused run(s), %d launches / copies per replay" % (fz["nodes"], fz["groups"], fz["exec_length"])
     print("%-64s %9.4f ms  %10.1f re-evaluations/s  %s" % (name, ms, 1e3 / ms, extra), flush=True)
 
 
 def config1(mode, graph=False):
     n, m = 8, 2
-    model = P.Model(P.MockOptimizer(), quadratic_mode=mode, use_graph=graph)
+    model = P.Model(P.MockOptimizer(), quadratic_mode=mode, use_graph=graph, overlap_fetch=False)
     x = [P.Variable(model) for _ in range(n)]
     A = P.DeviceUniformParameter((n, n), 1, model); b = P.DeviceUniformParameter((n,), 2, model)
     C = P.DeviceUniformParameter((m, n), 3, model); d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
     r = A * x - b
     P.objective(model, P.Minimize, P.dot(r, r)); P.constraint(model, C * x == d)
-    report("C1 README Example 1 (n=8, m=2), %s objective%s" % (mode, ", hipGraph replay" if graph else ""), model, "launch-latency bound (%d launches)")
+    report("C1 README Example 1 (n=8, m=2), %s objective%s" % (mode, ", hipGraph replay" if graph else ""), model, "launch-latency bound (%d tape entries)")
 
 
 def config2():
     n, r_, m = 4096, 4096, 512
-    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", overlap_fetch=False)
     x = [P.Variable(model) for _ in range(n)]
     A = P.DeviceUniformParameter((r_, n), 1, model); b = P.DeviceUniformParameter((r_,), 2, model)
     C = P.DeviceUniformParameter((m, n), 3, model); d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
@@ -56,7 +59,7 @@ def config2():
 def config3():
     n, r_, mi = 4096, 4096, 512
     rng = np.random.default_rng(5)
-    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical", overlap_fetch=False)
     x = [P.Variable(model) for _ in range(n)]
     A = P.DeviceUniformParameter((r_, n), 1, model); b = P.DeviceUniformParameter((r_,), 2, model)
     G = P.Parameter(model, val=np.asfortranarray(rng.random((mi, n)))); h = P.Parameter(model, val=rng.random(mi))
@@ -74,7 +77,7 @@ def config5():
     indptr = np.arange(0, (n + 1) * k, k, dtype=np.int64)
     indices = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for _ in range(n)]).astype(np.int64)
     Cs = sp.csc_matrix((rng.random(indices.size) + 0.1, indices, indptr), shape=(m, n))
-    model = P.Model(P.MockOptimizer())
+    model = P.Model(P.MockOptimizer(), overlap_fetch=False)
     x = [P.Variable(model) for _ in range(n)]
     Cp = P.Parameter(model, val=Cs); d = P.Parameter(model, val=rng.random(m))
     P.constraint(model, Cp * x == d)
