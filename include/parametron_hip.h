@@ -597,7 +597,9 @@ int64_t pmt_plan_tape_length(const pmt_plan *plan);
  * re-evaluates in ~15 us on a CPU core, README.md:132-136); a tape replay pays one kernel launch (~5 us) per hop whatever its size.
  * pmt_plan_end_record therefore replaces every run of two or more consecutive SMALL entries of the tape (lane 0; pmt_fill_uniform_*,
  * pmt_affine_assemble_f64, pmt_affine_pack_vector_f64, pmt_quad_expand_f64, pmt_vars_addsub_f64, pmt_consts_f64, pmt_pack_*_f64,
- * pmt_copy_bytes, each writing at most 32768 elements, a run at most 65536) by ONE launch of an interpreter kernel that executes the
+ * pmt_copy_bytes, pmt_transpose_f64, pmt_affvec_combine_f64 (uniform rows), pmt_affvec_scale_f64, pmt_matvecmul_affs_f64, the pmt_vecdot_*
+ * forms, pmt_bilinear_f64, pmt_quad_combine_f64, pmt_quad_scale_f64, pmt_scale_*_f64, and pmt_quad_gram_f64 for tiny shapes — each writing
+ * at most 32768 elements, a run at most 65536) by ONE launch of an interpreter kernel that executes the
  * run's nodes in tape order with a workgroup barrier between them (csrc/small.hip).  Every element is computed by the same expression
  * as in the entry's own kernel: outputs are bit-identical.  Automatic; larger entries and everything else replay as recorded.
  *   pmt_plan_set_fusion  0: replay the tape as recorded (A/B and tests); 1 (default): fuse.  Not while recording / after graph capture.

@@ -40,13 +40,15 @@ int dispatch(void *stream, Launch launch);
 // closure; pmt_plan_end_record then replaces every run of consecutive small nodes by ONE launch of an interpreter kernel that executes
 // them in tape order with a workgroup barrier between dependent nodes.  Outputs are bit-identical to the separate kernels.
 enum SmallOp : int {
-    SOP_FILL = 1, SOP_AFFINE_LT, SOP_AFFINE_VAT, SOP_QUAD_EXPAND, SOP_VARS_ADDSUB, SOP_CONSTS, SOP_PACK_SA, SOP_PACK_SQ, SOP_PACK_VA, SOP_COPY8, SOP_GRAM
+    SOP_FILL = 1, SOP_AFFINE_LT, SOP_AFFINE_VAT, SOP_QUAD_EXPAND, SOP_VARS_ADDSUB, SOP_CONSTS, SOP_PACK_SA, SOP_PACK_SQ, SOP_PACK_VA, SOP_COPY8, SOP_GRAM,
+    SOP_AFFVEC_COMBINE, SOP_AFFVEC_SCALE, SOP_MATVEC_AFFS, SOP_VECDOT_NUM_VARS, SOP_VECDOT_NUM_AFFS, SOP_TRANSPOSE, SOP_QUAD_COMBINE,
+    SOP_QUAD_SCALE, SOP_SCALE_VARS, SOP_SCALE_NUMBERS, SOP_BILINEAR, SOP_VECDOT_TERMS, SOP_VECDOT_AFFS_VARS
 };
 struct SmallNode {
     int op = 0, sign = 0, moi = 0;
     int dyn = -1;                   // slot of the launch's dynamic-seed table (SOP_FILL with a host seed word), or -1
     int64_t d[4] = {0, 0, 0, 0};
-    const void *in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const void *in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *out[3] = {nullptr, nullptr, nullptr};
     double scale = 0.0;
     uint64_t seed = 0;

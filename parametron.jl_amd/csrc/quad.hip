@@ -331,11 +331,14 @@ extern "C" int pmt_bilinear_f64(const double *Q, int64_t ldq, int64_t rows, int6
     PMT_REQUIRE(ldq >= rows, PMT_DIMENSION_MISMATCH, "bilinear: ldq < rows");
     if (rows == 0 || cols == 0) return PMT_OK;
     PMT_REQUIRE(Q && xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "bilinear: null pointer");
+    SmallNode nd;
+    nd.op = SOP_BILINEAR; nd.moi = moi; nd.d[0] = ldq; nd.d[1] = rows; nd.d[2] = cols; nd.in[0] = Q; nd.in[1] = xvar; nd.in[2] = yvar; nd.in[3] = varmap;
+    nd.out[0] = out_quad; nd.work = rows * cols;
     return dispatch(stream, [=](hipStream_t s) {
         dim3 grid((unsigned)cdiv(cols, QE_BT), (unsigned)std::min<int64_t>(rows, 65535));
         PMT_LAUNCH(bilinear_kernel, grid, dim3(256), 0, s, Q, ldq, rows, cols, xvar, yvar, moi, varmap, reinterpret_cast<u64 *>(out_quad));
         return check_launch("bilinear_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_vecdot_terms_f64(int64_t n, const double *xc, const int64_t *xvar, const double *yc, const int64_t *yvar, int moi,
@@ -343,10 +346,13 @@ extern "C" int pmt_vecdot_terms_f64(int64_t n, const double *xc, const int64_t *
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vecdot_terms: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(xvar && yvar && out_quad, PMT_INVALID_ARGUMENT, "vecdot_terms: null pointer");
+    SmallNode nd;
+    nd.op = SOP_VECDOT_TERMS; nd.moi = moi; nd.d[0] = n; nd.in[0] = xc; nd.in[1] = xvar; nd.in[2] = yc; nd.in[3] = yvar; nd.in[4] = varmap;
+    nd.out[0] = out_quad; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(vecdot_terms_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, xc, xvar, yc, yvar, moi, varmap, out_quad);
         return check_launch("vecdot_terms_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_vecdot_affs_vars_f64(int64_t rows, const pmt_linear_term *x_terms, int64_t L, const double *x_consts, const int64_t *yvar,
@@ -355,10 +361,13 @@ extern "C" int pmt_vecdot_affs_vars_f64(int64_t rows, const pmt_linear_term *x_t
     PMT_REQUIRE(rows >= 0 && L >= 0, PMT_DIMENSION_MISMATCH, "vecdot_affs_vars: negative dimension");
     if (rows == 0) return PMT_OK;
     PMT_REQUIRE(x_consts && yvar && out_lin && (L == 0 || (x_terms && out_quad)), PMT_INVALID_ARGUMENT, "vecdot_affs_vars: null pointer");
+    SmallNode nd;
+    nd.op = SOP_VECDOT_AFFS_VARS; nd.moi = moi; nd.d[0] = rows; nd.d[1] = L; nd.in[0] = x_terms; nd.in[1] = x_consts; nd.in[2] = yvar; nd.in[3] = varmap;
+    nd.out[0] = out_quad; nd.out[1] = out_lin; nd.work = rows * L + rows;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * L + rows, 256), 256 * 8);
         PMT_LAUNCH(vecdot_affs_vars_kernel, dim3(blocks), dim3(256), 0, s, rows, x_terms, L, x_consts, yvar, moi, varmap, out_quad,
                            out_lin);
         return check_launch("vecdot_affs_vars_kernel");
-    });
+    }, nd);
 }

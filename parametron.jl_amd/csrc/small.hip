@@ -29,7 +29,7 @@ struct SmallDyn { uint64_t v[SMALL_MAX_DYN]; };
 struct SmallDev {
     int op, sign, moi, dyn;
     int64_t d[4];
-    const void *in[6];
+    const void *in[8];
     void *out[3];
     double scale;
     uint64_t seed;
@@ -208,6 +208,194 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         }
         break;
     }
+    case SOP_AFFVEC_COMBINE: {            // terms.hip: copyto!/add!/subtract!/vcat! on affine vectors, UNIFORM rows (functions.jl:422-427,455,477-485,969-994)
+        const int64_t rows = n.d[0], la = n.d[1], lb = n.d[2], lo = n.d[3];
+        const LT *xa = static_cast<const LT *>(n.in[0]);
+        const double *ca = static_cast<const double *>(n.in[1]);
+        const LT *xb = static_cast<const LT *>(n.in[2]);
+        const double *cb = static_cast<const double *>(n.in[3]);
+        LT *o = static_cast<LT *>(n.out[0]);
+        double *oc = static_cast<double *>(n.out[1]);
+        const int64_t na = xa ? la : 0, nb = xb ? lb : 0;
+        for (int64_t e = tid; e < rows * lo; e += nt) {
+            const int64_t row = e / lo, k = e - row * lo;
+            if (k < na) o[e] = xa[row * la + k];
+            else if (k - na < nb) {
+                LT t = xb[row * lb + (k - na)];
+                if (n.sign < 0) t.coeff = -t.coeff;                          // -x.linear[i]  (functions.jl:481, :158)
+                o[e] = t;
+            }
+        }
+        if (oc)
+            for (int64_t row = tid; row < rows; row += nt) {
+                double c = ca ? ca[row] : 0.0;
+                if (cb) c = n.sign < 0 ? c - cb[row] : c + cb[row];
+                oc[row] = c;
+            }
+        break;
+    }
+    case SOP_AFFVEC_SCALE: {               // terms.hip: scale!/mul! of an affine vector by a number (functions.jl:515-523)
+        const int64_t rows = n.d[0], nterms = n.d[1];
+        const LT *y = static_cast<const LT *>(n.in[0]);
+        const double *yc = static_cast<const double *>(n.in[1]);
+        const double *sdev = static_cast<const double *>(n.in[2]);
+        const double sc = sdev ? *sdev : n.scale;
+        LT *o = static_cast<LT *>(n.out[0]);
+        double *oc = static_cast<double *>(n.out[1]);
+        for (int64_t i = tid; i < nterms + rows; i += nt) {
+            if (i < nterms) { LT t = y[i]; t.coeff = sc * t.coeff; o[i] = t; }
+            else { const int64_t r = i - nterms; oc[r] = 0.0 + yc[r] * sc; }
+        }
+        break;
+    }
+    case SOP_MATVEC_AFFS: {                // terms.hip: matvecmul!(y, A, ::Vector{AffineFunction}) (functions.jl:800-822)
+        const int64_t lda = n.d[0], rows = n.d[1], cols = n.d[2], L = n.d[3];
+        const double *A = static_cast<const double *>(n.in[0]);
+        const LT *x = static_cast<const LT *>(n.in[1]);
+        const double *xc = static_cast<const double *>(n.in[2]);
+        LT *o = static_cast<LT *>(n.out[0]);
+        double *oc = static_cast<double *>(n.out[1]);
+        const int64_t per_row = cols * L;
+        for (int64_t e = tid; e < rows * per_row; e += nt) {
+            const int64_t row = e / per_row, rem = e - row * per_row, col = rem / L;
+            LT t = x[rem];
+            t.coeff = A[col * lda + row] * t.coeff;
+            o[e] = t;
+        }
+        for (int64_t row = tid; row < rows; row += nt) {
+            double acc = 0.0;
+            for (int64_t col = 0; col < cols; ++col) { const double p = xc[col] * A[col * lda + row]; acc = acc + p; }
+            oc[row] = acc;
+        }
+        break;
+    }
+    case SOP_VECDOT_NUM_VARS: {            // terms.hip: numbers . Vector{Variable} (functions.jl:684)
+        const double *v = static_cast<const double *>(n.in[0]);
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[1]);
+        LT *o = static_cast<LT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) { LT t; t.coeff = v[i]; t.var = xvar[i]; o[i] = t; }
+        if (tid == 0 && n.out[1]) *static_cast<double *>(n.out[1]) = 0.0;
+        break;
+    }
+    case SOP_VECDOT_NUM_AFFS: {            // terms.hip: numbers . Vector{AffineFunction} (functions.jl:524 -> :519, :521)
+        const int64_t cnt = n.d[0], L = n.d[1];
+        const double *v = static_cast<const double *>(n.in[0]);
+        const LT *x = static_cast<const LT *>(n.in[1]);
+        const double *xc = static_cast<const double *>(n.in[2]);
+        LT *o = static_cast<LT *>(n.out[0]);
+        for (int64_t e = tid; e < cnt * L; e += nt) { LT t = x[e]; t.coeff = v[e / L] * t.coeff; o[e] = t; }
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int64_t i = 0; i < cnt; ++i) acc = acc + xc[i] * v[i];        // launch_seq_dot(x_consts, v): left to right
+            *static_cast<double *>(n.out[1]) = acc;
+        }
+        break;
+    }
+    case SOP_TRANSPOSE: {                  // terms.hip: the adjoint rule's closure, dest[j, i] = A[i, j] (lazyexpression.jl:206-217)
+        const int64_t lds_ = n.d[0], rows = n.d[1], cols = n.d[2], ldd = n.d[3];
+        const double *src = static_cast<const double *>(n.in[0]);
+        double *dst = static_cast<double *>(n.out[0]);
+        for (int64_t e = tid; e < rows * cols; e += nt) {
+            const int64_t c = e / rows, r = e - c * rows;
+            dst[r * ldd + c] = src[c * lds_ + r];
+        }
+        break;
+    }
+    case SOP_QUAD_COMBINE: {               // terms.hip: [qa ; sb * qb] (functions.jl:434-439,459,492-500)
+        const int64_t na = n.d[0], nb = n.d[1];
+        const QT *qa = static_cast<const QT *>(n.in[0]);
+        const QT *qb = static_cast<const QT *>(n.in[1]);
+        QT *o = static_cast<QT *>(n.out[0]);
+        for (int64_t i = tid; i < na + nb; i += nt) {
+            QT t = i < na ? qa[i] : qb[i - na];
+            if (i >= na && n.sign < 0) t.coeff = -t.coeff;
+            o[i] = t;
+        }
+        break;
+    }
+    case SOP_QUAD_SCALE: {                 // terms.hip: s * q (functions.jl:526-534)
+        const QT *q = static_cast<const QT *>(n.in[0]);
+        const double *sdev = static_cast<const double *>(n.in[1]);
+        const double sc = sdev ? *sdev : n.scale;
+        QT *o = static_cast<QT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) { QT t = q[i]; t.coeff = sc * t.coeff; o[i] = t; }
+        break;
+    }
+    case SOP_SCALE_VARS: {                 // terms.hip: scale!(dest::Vector{LinearTerm}, x, y::Vector{Variable}) (functions.jl:873-893)
+        const int64_t *yvar = static_cast<const int64_t *>(n.in[0]);
+        const double *sdev = static_cast<const double *>(n.in[1]);
+        const double sc = sdev ? *sdev : n.scale;
+        LT *o = static_cast<LT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) { LT t; t.coeff = sc; t.var = yvar[i]; o[i] = t; }
+        break;
+    }
+    case SOP_SCALE_NUMBERS: {              // terms.hip: dest .= x .* y (functions.jl:917-925)
+        const double *y = static_cast<const double *>(n.in[0]);
+        const double *sdev = static_cast<const double *>(n.in[1]);
+        const double sc = sdev ? *sdev : n.scale;
+        double *o = static_cast<double *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) o[i] = sc * y[i];
+        break;
+    }
+    case SOP_BILINEAR: {                   // quad.hip: bilinearmul! (functions.jl:840-858): term r * ny + k = (Q[lin], x[r], y[k]), lin = r * ny + k column-major
+        const int64_t ldq = n.d[0], nxr = n.d[1], ny = n.d[2];
+        const double *Q = static_cast<const double *>(n.in[0]);
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[1]);
+        const int64_t *yvar = static_cast<const int64_t *>(n.in[2]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
+        QT *o = static_cast<QT *>(n.out[0]);
+        for (int64_t e = tid; e < nxr * ny; e += nt) {
+            const int64_t r = e / ny, k = e - r * ny;
+            const int64_t qrow = e % nxr, qcol = e / nxr;                   // column-major linear index of the nxr x ny matrix (:853)
+            double c = Q[qcol * ldq + qrow];
+            const int64_t xv = xvar[r], yv = yvar[k];
+            if (n.moi && xv == yv) c = 2 * c;
+            QT t; t.coeff = c; t.row = n.moi ? map_var(varmap, xv) : xv; t.col = n.moi ? map_var(varmap, yv) : yv;
+            o[e] = t;
+        }
+        break;
+    }
+    case SOP_VECDOT_TERMS: {               // quad.hip: Variable/LinearTerm . Variable/LinearTerm (functions.jl:689-700, :146-149)
+        const double *xc = static_cast<const double *>(n.in[0]);
+        const int64_t *xvar = static_cast<const int64_t *>(n.in[1]);
+        const double *yc = static_cast<const double *>(n.in[2]);
+        const int64_t *yvar = static_cast<const int64_t *>(n.in[3]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[4]);
+        QT *o = static_cast<QT *>(n.out[0]);
+        for (int64_t i = tid; i < n.d[0]; i += nt) {
+            const double a = xc ? xc[i] : 1.0, b = yc ? yc[i] : 1.0;
+            double c = a * b;
+            const int64_t xv = xvar[i], yv = yvar[i];
+            if (n.moi && xv == yv) c = 2 * c;
+            QT t; t.coeff = c; t.row = n.moi ? map_var(varmap, xv) : xv; t.col = n.moi ? map_var(varmap, yv) : yv;
+            o[i] = t;
+        }
+        break;
+    }
+    case SOP_VECDOT_AFFS_VARS: {           // quad.hip: Vector{AffineFunction} . Vector{Variable} (functions.jl:702-709 over :537-546)
+        const int64_t rows = n.d[0], L = n.d[1];
+        const LT *x = static_cast<const LT *>(n.in[0]);
+        const double *xc = static_cast<const double *>(n.in[1]);
+        const int64_t *yvar = static_cast<const int64_t *>(n.in[2]);
+        const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
+        QT *oq = static_cast<QT *>(n.out[0]);
+        LT *ol = static_cast<LT *>(n.out[1]);
+        for (int64_t e = tid; e < rows * L + rows; e += nt) {
+            if (e < rows * L) {
+                const int64_t i = e / L;
+                const LT t = x[e];
+                const int64_t yv = yvar[i];
+                QT q; q.coeff = (n.moi && t.var == yv) ? 2 * t.coeff : t.coeff;
+                q.row = n.moi ? map_var(varmap, t.var) : t.var; q.col = n.moi ? map_var(varmap, yv) : yv;
+                oq[e] = q;
+            } else {
+                const int64_t i = e - rows * L;
+                LT l; l.coeff = xc[i]; l.var = n.moi ? map_var(varmap, yvar[i]) : yvar[i];
+                ol[i] = l;
+            }
+        }
+        break;
+    }
     case SOP_COPY8: {
         const u64 *src = static_cast<const u64 *>(n.in[0]);
         u64 *dst = static_cast<u64 *>(n.out[0]);
@@ -244,7 +432,7 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
         const SmallNode &s = nodes[i];
         d[i].op = s.op; d[i].sign = s.sign; d[i].moi = s.moi; d[i].dyn = s.dyn;
         for (int k = 0; k < 4; ++k) d[i].d[k] = s.d[k];
-        for (int k = 0; k < 6; ++k) d[i].in[k] = s.in[k];
+        for (int k = 0; k < 8; ++k) d[i].in[k] = s.in[k];
         for (int k = 0; k < 3; ++k) d[i].out[k] = s.out[k];
         d[i].scale = s.scale; d[i].seed = s.seed;
     }

@@ -165,10 +165,12 @@ extern "C" int pmt_transpose_f64(const double *src, int64_t lds_, int64_t rows, 
     PMT_REQUIRE(lds_ >= rows && ldd >= cols, PMT_DIMENSION_MISMATCH, "transpose: leading dimension too small");
     if (rows == 0 || cols == 0) return PMT_OK;
     PMT_REQUIRE(src && dst, PMT_INVALID_ARGUMENT, "transpose: null pointer");
+    SmallNode nd;
+    nd.op = SOP_TRANSPOSE; nd.d[0] = lds_; nd.d[1] = rows; nd.d[2] = cols; nd.d[3] = ldd; nd.in[0] = src; nd.out[0] = dst; nd.work = rows * cols;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(transpose_kernel, dim3((unsigned)cdiv(rows, 32), (unsigned)cdiv(cols, 32)), dim3(256), 0, s, src, lds_, rows, cols, dst, ldd);
         return check_launch("transpose_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_quad_combine_f64(const pmt_quadratic_term *qa, int64_t na, const pmt_quadratic_term *qb, int64_t nb, int sb,
@@ -177,11 +179,13 @@ extern "C" int pmt_quad_combine_f64(const pmt_quadratic_term *qa, int64_t na, co
     PMT_REQUIRE(sb == 1 || sb == -1, PMT_INVALID_ARGUMENT, "quad_combine: sb must be +1 or -1");
     if (na + nb == 0) return PMT_OK;
     PMT_REQUIRE(out && (na == 0 || qa) && (nb == 0 || qb), PMT_INVALID_ARGUMENT, "quad_combine: null pointer");
+    SmallNode nd;
+    nd.op = SOP_QUAD_COMBINE; nd.sign = sb; nd.d[0] = na; nd.d[1] = nb; nd.in[0] = qa; nd.in[1] = qb; nd.out[0] = out; nd.work = na + nb;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(na + nb, 256), 256 * 8);
         PMT_LAUNCH(quad_combine_kernel, dim3(blocks), dim3(256), 0, s, qa, na, qb, nb, sb, out);
         return check_launch("quad_combine_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_quad_scale_f64(const pmt_quadratic_term *q, int64_t n, const double *s_dev, double s_host, pmt_quadratic_term *out,
@@ -189,32 +193,38 @@ extern "C" int pmt_quad_scale_f64(const pmt_quadratic_term *q, int64_t n, const 
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "quad_scale: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(q && out, PMT_INVALID_ARGUMENT, "quad_scale: null pointer");
+    SmallNode nd;
+    nd.op = SOP_QUAD_SCALE; nd.d[0] = n; nd.in[0] = q; nd.in[1] = s_dev; nd.scale = s_host; nd.out[0] = out; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
         PMT_LAUNCH(quad_scale_kernel, dim3(blocks), dim3(256), 0, s, q, n, s_dev, s_host, out);
         return check_launch("quad_scale_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_scale_vars_f64(const int64_t *yvar, int64_t n, const double *s_dev, double s_host, pmt_linear_term *out, void *stream) {
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "scale_vars: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(yvar && out, PMT_INVALID_ARGUMENT, "scale_vars: null pointer");
+    SmallNode nd;
+    nd.op = SOP_SCALE_VARS; nd.d[0] = n; nd.in[0] = yvar; nd.in[1] = s_dev; nd.scale = s_host; nd.out[0] = out; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(scale_vars_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, yvar, n, s_dev, s_host, out);
         return check_launch("scale_vars_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_scale_numbers_f64(const double *y, int64_t n, const double *s_dev, double s_host, double *out, void *stream) {
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "scale_numbers: negative length");
     if (n == 0) return PMT_OK;
     PMT_REQUIRE(y && out, PMT_INVALID_ARGUMENT, "scale_numbers: null pointer");
+    SmallNode nd;
+    nd.op = SOP_SCALE_NUMBERS; nd.d[0] = n; nd.in[0] = y; nd.in[1] = s_dev; nd.scale = s_host; nd.out[0] = out; nd.work = n;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8);
         PMT_LAUNCH(scale_numbers_kernel, dim3(blocks), dim3(256), 0, s, y, n, s_dev, s_host, out);
         return check_launch("scale_numbers_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_copy_bytes(void *dst, const void *src, size_t bytes, void *stream) {
@@ -244,11 +254,16 @@ extern "C" int pmt_affvec_combine_f64(int64_t rows, const pmt_linear_term *xa_te
         PMT_REQUIRE((xa_terms ? xa_row_len : 0) + (xb_terms ? xb_row_len : 0) == out_row_len, PMT_DIMENSION_MISMATCH,
                     "affvec_combine: out_row_len != len(a) + len(b)");
     PMT_REQUIRE(out_terms || out_row_len == 0, PMT_INVALID_ARGUMENT, "affvec_combine: null out_terms");
+    SmallNode nd;
+    nd.op = SOP_AFFVEC_COMBINE; nd.sign = sb; nd.d[0] = rows; nd.d[1] = xa_row_len; nd.d[2] = xb_row_len; nd.d[3] = out_row_len;
+    nd.in[0] = xa_terms; nd.in[1] = xa_consts; nd.in[2] = xb_terms; nd.in[3] = xb_consts; nd.out[0] = out_terms; nd.out[1] = out_consts;
+    // (ragged rows — any row_ptr — keep their own kernel: the term count lives on the device)
+    nd.work = (xa_row_ptr || xb_row_ptr || out_row_ptr) ? SMALL_NODE_WORK_MAX + 1 : rows * out_row_len + rows;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(affvec_combine_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, rows, xa_terms, xa_row_ptr, xa_row_len,
                            xa_consts, xb_terms, xb_row_ptr, xb_row_len, xb_consts, sb, out_terms, out_row_ptr, out_row_len, out_consts);
         return check_launch("affvec_combine_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_linear_term *y_terms, const double *y_consts, const double *s_dev,
@@ -256,11 +271,14 @@ extern "C" int pmt_affvec_scale_f64(int64_t rows, int64_t nterms, const pmt_line
     PMT_REQUIRE(rows >= 0 && nterms >= 0, PMT_DIMENSION_MISMATCH, "affvec_scale: negative dimension");
     if (rows == 0 && nterms == 0) return PMT_OK;
     PMT_REQUIRE((nterms == 0 || (y_terms && out_terms)) && (rows == 0 || (y_consts && out_consts)), PMT_INVALID_ARGUMENT, "affvec_scale: null pointer");
+    SmallNode nd;
+    nd.op = SOP_AFFVEC_SCALE; nd.d[0] = rows; nd.d[1] = nterms; nd.in[0] = y_terms; nd.in[1] = y_consts; nd.in[2] = s_dev; nd.scale = s_host;
+    nd.out[0] = out_terms; nd.out[1] = out_consts; nd.work = nterms + rows;
     return dispatch(stream, [=](hipStream_t s) {
         const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(nterms + rows, 256), 256 * 8);
         PMT_LAUNCH(affvec_scale_kernel, dim3(blocks), dim3(256), 0, s, rows, nterms, y_terms, y_consts, s_dev, s_host, out_terms, out_consts);
         return check_launch("affvec_scale_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows, int64_t cols, const pmt_linear_term *x_terms,
@@ -271,6 +289,9 @@ extern "C" int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows
     if (rows == 0) return PMT_OK;
     PMT_REQUIRE(out_consts && (cols == 0 || (A && x_consts)), PMT_INVALID_ARGUMENT, "matvecmul_affs: null pointer");
     PMT_REQUIRE(cols * x_row_len == 0 || (x_terms && out_terms), PMT_INVALID_ARGUMENT, "matvecmul_affs: null terms");
+    SmallNode nd;
+    nd.op = SOP_MATVEC_AFFS; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols; nd.d[3] = x_row_len; nd.in[0] = A; nd.in[1] = x_terms; nd.in[2] = x_consts;
+    nd.out[0] = out_terms; nd.out[1] = out_consts; nd.work = rows * cols * x_row_len + rows * cols;
     return dispatch(stream, [=](hipStream_t s) {
         if (cols * x_row_len > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(rows * cols * x_row_len, 256), 256 * 16);
@@ -280,17 +301,19 @@ extern "C" int pmt_matvecmul_affs_f64(const double *A, int64_t lda, int64_t rows
         }
         PMT_LAUNCH(matvecmul_affs_consts_kernel, dim3((unsigned)cdiv(rows, 64)), dim3(64), 0, s, A, lda, rows, cols, x_consts, out_consts);
         return check_launch("matvecmul_affs_consts_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_vecdot_numbers_vars_f64(const double *v, const int64_t *xvar, int64_t n, pmt_linear_term *out_terms, double *out_const,
                                            void *stream) {
     PMT_REQUIRE(n >= 0, PMT_DIMENSION_MISMATCH, "vecdot_numbers_vars: negative length");
     PMT_REQUIRE(out_const && (n == 0 || (v && xvar && out_terms)), PMT_INVALID_ARGUMENT, "vecdot_numbers_vars: null pointer");
+    SmallNode nd;
+    nd.op = SOP_VECDOT_NUM_VARS; nd.d[0] = n; nd.in[0] = v; nd.in[1] = xvar; nd.out[0] = out_terms; nd.out[1] = out_const; nd.work = n + 1;
     return dispatch(stream, [=](hipStream_t s) {
         PMT_LAUNCH(vecdot_numbers_vars_kernel, dim3((unsigned)std::max<int64_t>(1, cdiv(n, 256))), dim3(256), 0, s, v, xvar, n, out_terms, out_const);
         return check_launch("vecdot_numbers_vars_kernel");
-    });
+    }, nd);
 }
 
 extern "C" int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n, const pmt_linear_term *x_terms, int64_t x_row_len, const double *x_consts,
@@ -298,6 +321,9 @@ extern "C" int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n, const pmt
     PMT_REQUIRE(n >= 0 && x_row_len >= 0, PMT_DIMENSION_MISMATCH, "vecdot_numbers_affs: negative dimension");
     PMT_REQUIRE(out_const && (n == 0 || (v && x_consts)), PMT_INVALID_ARGUMENT, "vecdot_numbers_affs: null pointer");
     PMT_REQUIRE(n * x_row_len == 0 || (x_terms && out_terms), PMT_INVALID_ARGUMENT, "vecdot_numbers_affs: null terms");
+    SmallNode nd;
+    nd.op = SOP_VECDOT_NUM_AFFS; nd.d[0] = n; nd.d[1] = x_row_len; nd.in[0] = v; nd.in[1] = x_terms; nd.in[2] = x_consts; nd.out[0] = out_terms;
+    nd.out[1] = out_const; nd.work = n > 2048 ? SMALL_NODE_WORK_MAX + 1 : n * x_row_len + 16 * n;      // (its constant: a chain on one thread)
     return dispatch(stream, [=](hipStream_t s) {
         if (n * x_row_len > 0) {
             const unsigned blocks = (unsigned)std::min<int64_t>(cdiv(n * x_row_len, 256), 256 * 8);
@@ -306,5 +332,5 @@ extern "C" int pmt_vecdot_numbers_affs_f64(const double *v, int64_t n, const pmt
             if (rc) return rc;
         }
         return launch_seq_dot(x_consts, 2, v, 2, n, out_const, s);   // dest.constant += x.constant * y (functions.jl:521)
-    });
+    }, nd);
 }

@@ -165,6 +165,80 @@ def test_every_node_kind_fused_equals_unfused():
     p.close()
 
 
+def test_algebra_node_kinds_fused_equals_unfused():
+    """the builders behind the other rewrite rules — adjoint, vcat!/add!/subtract! (uniform rows), scale!/mul! (host and device scalar),
+    matvecmul! over affine functions, the vecdot! forms, bilinearmul! — as small-plan nodes: ONE launch for the whole tape, identical
+    bytes to the tape replayed as recorded"""
+    import gpu_util as g
+    rng = np.random.default_rng(9)
+    n, rows, L = 6, 4, 6
+    vmh = rng.permutation(n + 3).astype(np.int64) + 1
+    xvar, yvar, vm = g.to_dev(np.arange(1, n + 1, dtype=np.int64)), g.to_dev(np.array([3, 1, 6, 2, 9, 4], dtype=np.int64)), g.to_dev(vmh)
+    A, At, b, w = g.empty_f64(rows * n), g.empty_f64(rows * n), g.empty_f64(rows), g.empty_f64(n)
+    sdev = g.to_dev(np.array([1.75]))
+    lt, cst = g.empty_terms(rows * n, g.LT), g.empty_f64(rows)               # A x + b
+    lt2, cst2 = g.empty_terms(n * rows, g.LT), g.empty_f64(n)                 # A' y4 (transpose feeding assemble)
+    comb, combc = g.empty_terms(rows * 2 * n, g.LT), g.empty_f64(rows)        # [r ; -r]
+    sc, scc = g.empty_terms(rows * n, g.LT), g.empty_f64(rows)                # 1.75 * r   (device scalar)
+    sc2, scc2 = g.empty_terms(rows * n, g.LT), g.empty_f64(rows)              # 0.5 * r    (host scalar)
+    B = g.empty_f64(3 * rows)
+    mv, mvc = g.empty_terms(3 * rows * n, g.LT), g.empty_f64(3)               # B (A x + b)
+    nv, nvc = g.empty_terms(n, g.LT), g.empty_f64(1)                          # w . x
+    na, nac = g.empty_terms(rows * n, g.LT), g.empty_f64(1)                   # b . r
+    q1 = g.empty_terms(n, g.QT)                                               # (w x) . y terms
+    q2, l2 = g.empty_terms(rows * n, g.QT), g.empty_terms(rows, g.LT)         # r . x[:rows]
+    Qm = g.empty_f64(n * n)
+    q3 = g.empty_terms(n * n, g.QT)                                           # x' Q y
+    qc, qs = g.empty_terms(n + rows * n, g.QT), g.empty_terms(n + rows * n, g.QT)
+    sv, sn = g.empty_terms(n, g.LT), g.empty_f64(n)
+    outs = [At, lt, cst, lt2, cst2, comb, combc, sc, scc, sc2, scc2, mv, mvc, nv, nvc, na, nac, q1, q2, l2, q3, qc, qs, sv, sn]
+    p = Plan()
+    with p:
+        g.call("pmt_fill_uniform_matrix_f64", g.ptr(A), rows, n, rows, C.c_uint64(31), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(b), rows, C.c_uint64(32), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(w), n, C.c_uint64(33), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(B), 3 * rows, C.c_uint64(34), 1.0, p.rec)
+        g.call("pmt_fill_uniform_f64", g.ptr(Qm), n * n, C.c_uint64(35), 1.0, p.rec)
+        g.call("pmt_transpose_f64", g.ptr(A), rows, rows, n, g.ptr(At), n, p.rec)
+        g.call("pmt_affine_assemble_f64", g.ptr(A), rows, rows, n, g.ptr(xvar), g.ptr(b), 1, g.ptr(lt), g.ptr(cst), p.rec)
+        g.call("pmt_affine_assemble_f64", g.ptr(At), n, n, rows, g.ptr(yvar), None, 0, g.ptr(lt2), g.ptr(cst2), p.rec)
+        g.call("pmt_affvec_combine_f64", rows, g.ptr(lt), None, n, g.ptr(cst), g.ptr(lt), None, n, g.ptr(cst), -1, g.ptr(comb), None, 2 * n, g.ptr(combc), p.rec)
+        g.call("pmt_affvec_scale_f64", rows, rows * n, g.ptr(lt), g.ptr(cst), g.ptr(sdev), 0.0, g.ptr(sc), g.ptr(scc), p.rec)
+        g.call("pmt_affvec_scale_f64", rows, rows * n, g.ptr(lt), g.ptr(cst), None, 0.5, g.ptr(sc2), g.ptr(scc2), p.rec)
+        g.call("pmt_matvecmul_affs_f64", g.ptr(B), 3, 3, rows, g.ptr(lt), n, g.ptr(cst), g.ptr(mv), g.ptr(mvc), p.rec)
+        g.call("pmt_vecdot_numbers_vars_f64", g.ptr(w), g.ptr(xvar), n, g.ptr(nv), g.ptr(nvc), p.rec)
+        g.call("pmt_vecdot_numbers_affs_f64", g.ptr(b), rows, g.ptr(lt), n, g.ptr(cst), g.ptr(na), g.ptr(nac), p.rec)
+        g.call("pmt_vecdot_terms_f64", n, g.ptr(w), g.ptr(xvar), None, g.ptr(yvar), 1, g.ptr(vm), g.ptr(q1), p.rec)
+        g.call("pmt_vecdot_affs_vars_f64", rows, g.ptr(lt), n, g.ptr(cst), g.ptr(xvar), 1, g.ptr(vm), g.ptr(q2), g.ptr(l2), p.rec)
+        g.call("pmt_bilinear_f64", g.ptr(Qm), n, n, n, g.ptr(xvar), g.ptr(yvar), 1, g.ptr(vm), g.ptr(q3), p.rec)
+        g.call("pmt_quad_combine_f64", g.ptr(q1), n, g.ptr(q2), rows * n, -1, g.ptr(qc), p.rec)
+        g.call("pmt_quad_scale_f64", g.ptr(qc), n + rows * n, g.ptr(sdev), 0.0, g.ptr(qs), p.rec)
+        g.call("pmt_scale_vars_f64", g.ptr(yvar), n, None, 2.5, g.ptr(sv), p.rec)
+        g.call("pmt_scale_numbers_f64", g.ptr(w), n, g.ptr(sdev), 0.0, g.ptr(sn), p.rec)
+    assert p.fused() == (1, 21, 1)
+    p.update()
+    torch.cuda.synchronize()
+    fused = [t.clone() for t in outs]
+    for t in outs:
+        t.fill_(-7) if t.dtype == torch.int64 else t.fill_(float("nan"))
+    p.fusion(False)
+    assert p.fused() == (0, 0, 21)
+    p.update()
+    torch.cuda.synchronize()
+    for k, (f_, t) in enumerate(zip(fused, outs)):
+        assert torch.equal(f_.view(torch.int64), t.view(torch.int64)), k
+    # a few values against their meaning (the oracle-level checks of these builders are tests/test_gpu_kernels.py and test_gpu_rules_vs_oracle.py)
+    Ah = g.f64_to_host(A, rows * n).reshape(n, rows).T
+    assert np.array_equal(g.f64_to_host(At, rows * n).reshape(rows, n), Ah)               # At is n x rows column-major = A row-major
+    q3h = g.terms_to_host(q3, n * n, g.QT)
+    Qh = g.f64_to_host(Qm, n * n)
+    xv, yv = np.arange(1, n + 1), np.array([3, 1, 6, 2, 9, 4])
+    want = np.array([Qh[e] * (2.0 if xv[e // n] == yv[e % n] else 1.0) for e in range(n * n)])   # Q[k] in column-major LINEAR order (functions.jl:853)
+    assert np.array_equal(q3h["coeff"], want) and np.array_equal(q3h["row"], vmh[xv[np.arange(n * n) // n] - 1])
+    assert np.array_equal(g.f64_to_host(sn, n), 1.75 * g.f64_to_host(w, n))
+    p.close()
+
+
 def test_large_nodes_keep_their_own_kernels():
     """the interpreter is one workgroup: an entry that writes more than 32768 elements is replayed by its own kernel, and a run is cut
     before it exceeds 65536"""
