@@ -32,9 +32,6 @@
 #ifndef PMT_TALL_ABL
 #define PMT_TALL_ABL 0
 #endif
-#ifndef PMT_TALL_PF
-#define PMT_TALL_PF 1          // stages the global loads run ahead of the MFMAs (1; 2 = two register sets: measured equal, profiles/r05_gram_tall.txt)
-#endif
 #ifndef PMT_TALL_MAXG
 #define PMT_TALL_MAXG 512
 #endif
@@ -247,31 +244,6 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
     for (int r = 0; r < TACC; ++r) acc[r] = 0.0;
     double qacc[4] = {0.0, 0.0, 0.0, 0.0}, cacc = 0.0;
     auto stage_row = [&](int s) { return (sbeg + (int64_t)s * sstep) * TBK; };
-#if PMT_TALL_PF == 2
-    // Loads run TWO stages ahead of the MFMAs: two register sets, the stage loop unrolled by two so that the sets are static.  One stage of
-    // matrix work (~1 us with two workgroups per CU) does not cover the ~2 us a 16 KB request round takes when the whole chip streams; with
-    // the loads of stage s + 2 issued before stage s is contracted, a request has two stages to return and the memory pipe never drains.
-    f64x2 regA[4][TSUB], cvA[TSUB], regB[4][TSUB], cvB[TSUB];
-    if (nstage > 0) {
-        tall_load<FAST>(g, stage_row(0), rend, kp, cc, regA, cvA);
-        tall_store(lds[0], regA, cvA, g.sign, kp, cc, qacc, cacc);
-    }
-    if (nstage > 1) tall_load<FAST>(g, stage_row(1), rend, kp, cc, regB, cvB);
-    __syncthreads();
-    for (int s = 0; s < nstage; s += 2) {
-        // even stage: reads LDS 0; set A is free (stored at the end of stage s - 1), set B holds stage s + 1
-        if (s + 2 < nstage) tall_load<FAST>(g, stage_row(s + 2), rend, kp, cc, regA, cvA);
-        tall_stage<W>(lds[0] + TLK * lk, lm, acc);
-        if (s + 1 < nstage) tall_store(lds[1], regB, cvB, g.sign, kp, cc, qacc, cacc);
-        __syncthreads();
-        if (s + 1 >= nstage) break;
-        // odd stage: reads LDS 1; set B is free, set A holds stage s + 2
-        if (s + 3 < nstage) tall_load<FAST>(g, stage_row(s + 3), rend, kp, cc, regB, cvB);
-        tall_stage<W>(lds[1] + TLK * lk, lm, acc);
-        if (s + 2 < nstage) tall_store(lds[0], regA, cvA, g.sign, kp, cc, qacc, cacc);
-        __syncthreads();
-    }
-#else
     f64x2 reg[4][TSUB], cv[TSUB];
 
     if (nstage > 0) {
@@ -287,6 +259,23 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
 #elif PMT_TALL_ABL == 2    // ablation (wrong results): no MFMAs — the memory side alone
         if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#elif PMT_TALL_ABL == 3    // ablation (wrong results): global loads + MFMAs, no register -> LDS phase (one add keeps the loads alive)
+        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) { cacc = cacc + reg[0][0].x; cacc = cacc + reg[3][TSUB - 1].y; cacc = cacc + cv[0].x; }
+#elif PMT_TALL_ABL == 4    // ablation (wrong results): MFMAs + the register -> LDS phase of stale registers, no global loads after the first stage
+        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#elif PMT_TALL_ABL == 5    // ablation (wrong results): everything but the q / c'c arithmetic (LDS stores only)
+        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < TSUB; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<f64x2 *>(lds[cur ^ 1] + (cc + 32 * p) * TGP + 16 * j + 2 * kp) = reg[p][j];
+            cacc = cacc + cv[0].x;
+        }
 #else
         if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
@@ -294,7 +283,6 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
 #endif
         __syncthreads();
     }
-#endif
 
     // partials -> workspace: [wave][accumulator][lane] (512-byte runs), then q and c'c
     double *w = g.ws + (int64_t)blockIdx.x * TSTRIDE;

@@ -231,7 +231,8 @@ extern "C" int pmt_copy_bytes(void *dst, const void *src, size_t bytes, void *st
     if (bytes == 0) return PMT_OK;
     PMT_REQUIRE(dst && src, PMT_INVALID_ARGUMENT, "copy_bytes: null pointer");
     Launch copy = [=](hipStream_t s) {
-        PMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+        // (hipMemcpyDefault: `src` may be page-locked HOST memory — a small model's Parameter mailbox, which the small-plan kernel reads directly)
+        PMT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s));
         return PMT_OK;
     };
     if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 7) == 0) {

@@ -117,6 +117,7 @@ class DeviceContext:
     def synchronize(self):
         _lib.call("pmt_plan_synchronize", self.plan)
         self._keep.clear()
+        self._replay_pending = False
 
     # ---- staged uploads (copy stream; include/parametron_hip.h "Staged (overlapped) uploads")
     def stage_upload(self, staging_ptr, host):
@@ -186,6 +187,7 @@ class DeviceContext:
 
     def replay(self):
         _lib.call("pmt_plan_update", self.plan)
+        self._replay_pending = True           # (a replay may still be reading host mailboxes: lazyexpression.device_value_of)
 
     def instantiate_graph(self):
         _lib.call("pmt_plan_instantiate_graph", self.plan)

@@ -136,6 +136,7 @@ def device_value_of(x, ctx=None):
             x._staged_pending = False
             x._dev_version = x.version
             ctx._staging_dirty = True
+            _sync_mailbox(ctx, x, getattr(x, "val", None))
             return x._dev
         val = Parameter.__call__(x)                 # evalarg(::Parameter) (src/lazyexpression.jl:51)
         if x._dev is None:
@@ -147,7 +148,10 @@ def device_value_of(x, ctx=None):
                 x._dev = _alloc_like(ctx, val)
         if x._dev_version != x.version and getattr(x, "_in_tape", False) and getattr(ctx, "_refreshing", False) and not ctx.recording:
             # the callback is an entry of the tape (a small model, Model._record_parameter_callbacks): the replay that follows draws the values
-            x._seed_word.value = x.current_seed() % (1 << 64)
+            if getattr(x, "_mailbox", None) is not None:
+                _sync_mailbox(ctx, x, val)
+            else:
+                x._seed_word.value = x.current_seed() % (1 << 64)
             x._dev_version = x.version
             return x._dev
         if x._dev_version != x.version:
@@ -169,11 +173,23 @@ def device_value_of(x, ctx=None):
                     ctx.synchronize()
             else:
                 _upload_value(ctx, x._dev, val)
+                _sync_mailbox(ctx, x, val)
                 if getattr(x, "_read_unordered_by_lane3", False) and not ctx.recording:
                     ctx.synchronize()                   # (a serial upload travels on the plan's stream as well)
             x._dev_version = x.version
         return x._dev
     return const_device_value(ctx, x)
+
+
+def _sync_mailbox(ctx, x, val):
+    """A host-updated Parameter of a small model has a page-locked MAILBOX the tape copies into its device buffer at every replay
+    (Model._record_parameter_callbacks): whatever path gives the Parameter a new value keeps the mailbox equal to it."""
+    if getattr(x, "_mailbox", None) is None or val is None:
+        return
+    if getattr(ctx, "_replay_pending", False):
+        ctx.synchronize()                                 # the previous replay may still be reading the mailbox
+    from .model import _write_mailbox
+    _write_mailbox(x, val)
 
 
 def _alloc_like(ctx, val):

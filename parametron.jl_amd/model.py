@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import moi
-from ._lib import ArgumentError, ErrorException
+from ._lib import ArgumentError, DimensionMismatch, ErrorException
 from .device import DeviceContext
 from .functions import AffineFunction, Variable, _isnum
 from .lazyexpression import DeviceNode, Relation, evaluate, lazy, schedule
@@ -116,6 +116,26 @@ class MockOptimizer(AbstractOptimizer):
 
     def dual_status(self):
         return "NO_SOLUTION"
+
+
+def _write_mailbox(x, val):
+    """the value of a host-updated Parameter into its page-locked mailbox, in the layout of the device buffer (padded leading dimension)"""
+    from .device import DMat, DVec
+    if val is None:
+        return
+    dv, mb = x._dev, x._mailbox
+    if isinstance(dv, DMat):
+        m = np.asarray(val, dtype=np.float64)
+        if m.shape != (dv.rows, dv.cols):
+            raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.rows, dv.cols), m.shape))
+        mb.reshape(dv.cols, dv.lda)[:, :dv.rows] = m.T
+    elif isinstance(dv, DVec):
+        v = np.asarray(val, dtype=np.float64)
+        if v.shape != (dv.n,):
+            raise DimensionMismatch("Parameter changed shape: %r -> %r" % ((dv.n,), v.shape))
+        mb[:dv.n] = v
+    else:
+        mb[0] = float(val)
 
 
 class _Backend:
@@ -365,8 +385,23 @@ class Model:
         if not getattr(self, "_small", False):
             return
         ps = [x for x in self._order if isinstance(x, Parameter)]
+        from .device import DNum
         for x in ps:
             dv = getattr(x, "_dev", None)
+            if not isinstance(x, DeviceUniformParameter) and isinstance(dv, (DMat, DVec, DNum)) and not getattr(x, "device_resident", False):
+                # a HOST-updated Parameter (callback f(val) or Parameter(model, val=buf), src/parameter.jl:57,88) of a small model: its value
+                # travels through a page-locked MAILBOX in the device layout, which the first entries of the tape copy into the Parameter's
+                # buffer — inside the one small-plan launch, read straight from host memory.  update! writes the mailbox (a numpy copy of a
+                # few hundred bytes) instead of issuing one hipMemcpyAsync per Parameter.
+                n_doubles = (dv.lda * dv.cols) if isinstance(dv, DMat) else (dv.padded if isinstance(dv, DVec) else 1)
+                if n_doubles <= 0:
+                    continue
+                x._mailbox = ctx.pinned_array(n_doubles, np.float64)
+                x._mailbox[:] = 0.0
+                _write_mailbox(x, x.val if getattr(x, "val", None) is not None else None)
+                ctx.call("pmt_copy_bytes", C.c_void_p(dv.buf), C.c_void_p(x._mailbox.ctypes.data), 8 * n_doubles)
+                x._in_tape = True
+                continue
             if not isinstance(x, DeviceUniformParameter) or getattr(x, "pattern", None) is not None or not isinstance(dv, (DMat, DVec)):
                 continue
             x._seed_word = C.c_uint64(x.current_seed() % (1 << 64))

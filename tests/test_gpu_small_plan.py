@@ -320,3 +320,62 @@ def test_model_selects_the_small_plan_by_itself(mode):
 def g_same(a, b):
     import gpu_util as g
     return g.same_bits(a, b)
+
+
+def test_host_callbacks_of_a_small_model_travel_through_mailboxes():
+    """README Example 1 as the reference writes it — HOST callbacks `rand!(A)` (src/parameter.jl:57, README.md:36-43): the values of a small
+    model's host-updated Parameters reach the device through page-locked mailboxes that the first entries of the tape copy from, inside the
+    one small-plan launch; update! issues no per-Parameter upload.  What the optimizer receives equals the oracle for every solve, also
+    when a value is read or changed outside update! in between."""
+    import parametron_jl_amd as P
+    from oracle import oracle as O
+    from qp_solver import DenseQPOptimizer
+    n, m = 8, 2
+    model = P.Model(DenseQPOptimizer(variable_offset=2, permute_seed=3), quadratic_mode="literal")
+    x = [P.Variable(model) for _ in range(n)]
+    rng = np.random.default_rng(4)
+
+    def randrng(a):
+        a[...] = rng.random(a.shape)
+    A = P.Parameter(randrng, np.zeros((n, n)), model)
+    b = P.Parameter(randrng, np.zeros(n), model)
+    Cm = P.Parameter(model, val=rng.random((m, n)))               # a manually updated work buffer (src/parameter.jl:88)
+    d = P.Parameter(randrng, np.zeros(m), model)
+    s = P.Parameter(lambda: 1.5, model)                            # an out-of-place scalar callback
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, s * (Cm * x) == d)
+
+    def check():
+        vm = model.model_var_to_optimizer
+        w = O.LsqWorkspace(n, n, m)
+        xi = np.arange(1, n + 1, dtype=np.int64)
+        w.eval_objective(np.asfortranarray(A()).reshape(-1, order="F"), b(), xi)
+        at, qt, const = w.objective.moi(vm)
+        f = model.objective.f
+        assert np.array_equal(f.quadratic_terms.view(np.int64), qt.view(np.int64)) and np.array_equal(f.affine_terms.view(np.int64), at.view(np.int64))
+        assert f.constant == const
+        cf = list(model.constraints)[0].f
+        ref = O.AffVec(m).vecsubtract(O.AffVec(m).scale_number_affs(1.5, O.AffVec(m).matvecmul_vars(Cm(), list(xi))), d())
+        ct, cc = ref.moi(vm)
+        assert np.array_equal(cf.terms.view(np.int64), ct.view(np.int64)) and np.array_equal(cf.constants, cc)
+
+    for it in range(5):
+        if it == 2:
+            Cm.val[...] = rng.random((m, n))                       # the user rewrites the buffer between solves
+        if it == 3:
+            model.setdirty(); res()                                # a lazy expression evaluated OUTSIDE update!: same values afterwards
+        P.solve(model)
+        check()
+        fz = model.device().fused()
+        assert fz["groups"] == 1 and fz["exec_length"] == 1, fz
+        for p_ in (A, b, Cm, d, s):
+            assert getattr(p_, "_mailbox", None) is not None and p_._in_tape
+    # the mailbox holds the device layout of the current value
+    assert np.array_equal(A._mailbox.reshape(n, A._dev.lda)[:, :n].T, A()) and s._mailbox[0] == 1.5
+    P.profile_enable(True)
+    model.setdirty(); model._run_tape(fetch=False); model.device().synchronize()
+    rep = P.profile_report()
+    P.profile_enable(False)
+    assert list(rep) == ["small_plan_kernel"], rep
+    model.close()
