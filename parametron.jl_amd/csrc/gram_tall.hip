@@ -1,6 +1,6 @@
 // Canonical least-squares objective for TALL matrices (rows >> columns, at most 128 columns): the usual least-squares shape
 // (README.md:34-38 with many more residual rows than variables).  ONE pass over A produces everything the node needs:
-//   upper triangle of A'A (f64 MFMA), q = A'c and c'c (c = 0.0 (+|-) b), as per-workgroup partials over contiguous row chunks,
+//   upper triangle of A'A (f64 MFMA), q = A'c and c'c (c = 0.0 (+|-) b), as per-workgroup partials over interleaved 32-row stages,
 // then one fix-up launch adds the partials in a fixed order and writes the MOI / native terms.
 //
 // Reference semantics replaced: _vecdot!/muladd! literal expansion (src/functions.jl:702-709,548-576) + canonicalize!
@@ -12,14 +12,20 @@
 //   * the triangle only: the 128 x 128 tile is 8 x 8 blocks of 16 x 16; the 36 blocks on and above the diagonal are dealt out NINE per
 //     wave to a 4-wave workgroup (one wave per SIMD; 36 accumulator registers per lane), each wave's set chosen so that it needs few
 //     distinct operand rows / columns from LDS.  Executed / needed flops = 36 * 256 / 8256 = 1.12 (the square: 1.98).
-//   * small workgroups (4 waves, ~35 KB LDS): several per CU, their barriers do not line up, the matrix pipes stay fed.
-//   * q and c'c ride along on the VALU: every thread adds c_i * A[i, j] for the 16-byte pieces it has just loaded, before they go to LDS.
-//   * A is read once.  At n = 128 the node needs 16 FLOP per byte of A, the chip delivers ~10: both pipes matter.
-// Summation order (fixed, restated by tests/test_gpu_fullsize_parity.py): rows in order inside a workgroup's chunk (MFMA k order for the
-// triangle; per-thread row pairs, then an 8-lane tree, for q and c'c), then the chunks in 16 interleaved slices, then the slices in order.
+//   * small workgroups (4 waves, 70 KB LDS): two per CU, their barriers do not line up, the matrix pipes stay fed.
+//   * q and c'c ride along on the VALU: every thread adds c_i * A[i, j] for the 16-byte pieces it has just loaded, on their way to LDS
+//     (free: the same kernel without that arithmetic takes the same time).
+//   * A is read once.  At n = 128 the node needs 16 FLOP per byte of A, the chip delivers ~10: both pipes matter, and with both busy the
+//     chip runs at its power limit (2.08 GHz, matrix pipe 72 % busy: profiles/r05_gram_tall_pmc_sq.txt).
+// 2^20 x 128: 0.39 ms kernel + 0.01 ms fix-up (was 1.06 ms); the measurement record, step by step, is profiles/r05_gram_tall.txt.
+// Summation order (fixed; pmt_quad_gram_constant_order reports it, tests/gpu_util.py restates the constant's bit for bit): workgroup g
+// takes the stages g, g + G, .. in order (MFMA k order for the triangle; per-thread row pairs, then an 8-lane tree, for q and c'c), the
+// workgroups are added in 16 interleaved slices, then the slices in order.
 #include "gram_common.h"
 
-// k-steps of a stage unrolled together: 1 = 156 VGPRs (three workgroups per CU), 4 = 220-226 (two)
+// Knobs of the measured sweep (profiles/r05_gram_tall.txt); the defaults are what ships.  UNROLL: k-steps of a stage unrolled together
+// (1: 197 VGPRs at 32-row stages); MR: rows per stage; WPS: waves per SIMD the register budget aims at; MAXG: workgroups at most;
+// K2: one 16-byte operand read for two k-steps; ABL: ablations (wrong results).
 #ifndef PMT_TALL_UNROLL
 #define PMT_TALL_UNROLL 1
 #endif
