@@ -122,3 +122,45 @@ class DenseQPOptimizer(P.AbstractOptimizer):
     def termination_status(self): return self.status
     def primal_status(self): return "FEASIBLE_POINT" if self.x is not None else "NO_SOLUTION"
     def dual_status(self): return "FEASIBLE_POINT" if self.x is not None else "NO_SOLUTION"
+
+
+class TinyMIPOptimizer(DenseQPOptimizer):
+    """Stands in for GLPK in the reference's boolean / integer tests (test/model.jl:222-267): variables with a ZeroOne or Integer
+    SingleVariable constraint are ENUMERATED (binary: {0, 1}; integer: -8..8), the others must not exist — a linear objective over a
+    handful of integer points, exactly what those tests need.  Third-party solver stand-in, test infrastructure only."""
+
+    def copy_to(self, backend):
+        self.domains = {}
+        kept = []
+        for c in backend.constraints:
+            if isinstance(c.f, moi.SingleVariable):
+                self.domains[c.f.variable.index] = (0, 1) if isinstance(c.set, moi.ZeroOne) else tuple(range(-8, 9))
+            else:
+                kept.append(c)
+        import types
+        out = super().copy_to(types.SimpleNamespace(nvars=backend.nvars, sense=backend.sense, objective=backend.objective, constraints=kept))
+        for c in backend.constraints:
+            if isinstance(c.f, moi.SingleVariable):
+                out["constraints"][c] = -1
+        return out
+
+    def optimize(self):
+        import itertools
+        Q, a, c = self._dense_objective()
+        assert not Q.any() and len(self.domains) == self.n, "TinyMIPOptimizer: linear objective, every variable integer or binary"
+        M, k, senses = self._rows()
+        # model Variable j (1-based) sits in dense column (varidx[j - 1] - offset - 1)
+        cols = [int(self.varidx[j - 1] - self.offset - 1) for j in sorted(self.domains)]
+        best, bestx = None, None
+        for point in itertools.product(*[self.domains[j] for j in sorted(self.domains)]):
+            x = np.zeros(self.n)
+            x[cols] = point
+            g = M @ x + k
+            ok = all((s == "==" and abs(v) < 1e-9) or (s == ">=" and v >= -1e-9) or (s == "<=" and v <= 1e-9) for s, v in zip(senses, g))
+            if not ok:
+                continue
+            val = a @ x + c
+            if best is None or (val < best if self.sense == P.Minimize else val > best):
+                best, bestx = val, x
+        self.x, self.objval = bestx, best
+        self.status = "OPTIMAL" if bestx is not None else "INFEASIBLE"

@@ -153,3 +153,17 @@ def test_vecdot_rule_variable_forms(setup):                          # :228-232 
     w = P.Parameter(lambda v: v.__setitem__(slice(None), rng.random(4)), np.zeros(4), model)
     for expr in (P.dot(w, x), P.dot(x, w)):
         assert aff(expr()) == O.vecdot_aff_numbers_vars(w(), xi).as_tuple()
+
+
+def test_convert_rule_is_an_alias(setup):                            # :280-282 — convert(Vector, A * x) -> copyto!(dest, src) of references
+    """test/lazyexpression.jl:265-277: `@expression convert(Vector, A * x)` equals `A() * x`; the reference's copyto! copies element
+    REFERENCES, so on the device the node is the argument's own buffers — nothing is launched for it"""
+    model, rng, x, xi, y, yi = setup
+    A = P.Parameter(lambda: np.ones((3, 4)), model)
+    inner = A * x
+    expr = P.lazy("convert", list, inner)
+    assert expr is inner or affvec(expr()) == affvec(inner())
+    assert affvec(expr()) == O.AffVec(3).matvecmul_vars(np.ones((3, 4)), xi).as_tuples()
+    before = model.device().bytes_allocated()
+    model.setdirty(); expr()
+    assert model.device().bytes_allocated() == before               # ↔ @allocated expr() == 0

@@ -72,3 +72,64 @@ def test_default_objective_and_vector_equality():                          # tes
     P.constraint(model2, xs, "==", (1.0, 2.0))
     P.solve(model2)
     np.testing.assert_allclose(P.value(model2, list(xs)), [1.0, 2.0], atol=1e-8)
+
+
+def test_moi_issue_426_vector_constraint_lists_by_set_type():              # test/model.jl:208-220
+    """the backend lists a model's VectorAffineFunction constraints by set type: none before, one per set after `[x] >= [0]`,
+    `[x] <= [1]`, `[x] == [0.5]` (src/moi_interop.jl:180-193: one typed vector per (function, set) pair)"""
+    model = P.Model(DenseQPOptimizer())
+    x = Variable(model)
+    specs = ("vectoraffinefunction_in_nonnegatives", "vectoraffinefunction_in_nonpositives", "vectoraffinefunction_in_zeros")
+    for s in specs:
+        assert len(model.constraints.by_spec[s]) == 0
+    P.constraint(model, [x], ">=", [0])
+    P.constraint(model, [x], "<=", [1])
+    P.constraint(model, [x], "==", [0.5])
+    for s in specs:
+        assert len(model.constraints.by_spec[s]) == 1
+    assert len(model.constraints) == 3
+    P.solve(model)
+    assert P.value(model, x) == pytest.approx(0.5, abs=1e-8)
+
+
+def test_boolean_basics():                                                 # test/model.jl:222-234 (GLPK there; an enumerating stand-in here)
+    from qp_solver import TinyMIPOptimizer
+    model = P.Model(TinyMIPOptimizer())
+    x = Variable(model)
+    P.constraint(model, x, "in", "{0, 1}")
+    P.objective(model, P.Maximize, x)
+    P.solve(model)
+    assert P.terminationstatus(model) == "OPTIMAL" and P.primalstatus(model) == "FEASIBLE_POINT"
+    assert P.value(model, x) == pytest.approx(1.0, abs=1e-8)
+    with pytest.raises(P.ArgumentError):
+        P.constraint(P.Model(TinyMIPOptimizer()), x, "in", "{0, 2}")       # src/model.jl:243
+
+
+@pytest.mark.parametrize("form", ["scalar", "vector"])
+def test_integer_basics(form):                                             # test/model.jl:236-267
+    from qp_solver import TinyMIPOptimizer
+    model = P.Model(TinyMIPOptimizer(variable_offset=3))
+    x = Variable(model)
+    P.constraint(model, x, "∈", "ℤ")
+    if form == "scalar":
+        P.constraint(model, x >= 0.5)
+    else:
+        P.constraint(model, [x], ">=", [0.5])
+    P.objective(model, P.Minimize, x)
+    P.solve(model)
+    assert P.terminationstatus(model) == "OPTIMAL" and P.primalstatus(model) == "FEASIBLE_POINT"
+    assert P.value(model, x) == pytest.approx(1.0, abs=1e-8)
+
+
+def test_nested_expression_of_a_scalar_parameter():                        # test/lazyexpression.jl:39-49
+    model = P.mock_model()
+    a, b = 3, 4.0
+    cval = [5]
+    c = P.Parameter(lambda: cval[0], model)
+    expr1 = a + b * c
+    expr2 = 4 * expr1
+    assert expr2() == 4 * expr1() == 4 * (3 + 4.0 * 5)
+    cval[0] = 6
+    model.setdirty()
+    assert expr2() == 4 * (3 + 4.0 * 6)
+    repr(expr1)
