@@ -606,6 +606,10 @@ int64_t pmt_plan_tape_length(const pmt_plan *plan);
  *   pmt_plan_fused       number of fused runs, tape entries they replace, and launches-or-entries one replay executes */
 int pmt_plan_set_fusion(pmt_plan *plan, int on);
 int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_length);
+/* Inside a fused run a workgroup barrier stands only in front of a node that touches what an earlier node since the last barrier wrote
+ * (or writes what one read): independent nodes — the Parameter callbacks; the objective's chain and a constraint's — share a PHASE.
+ * Number of phases over all fused runs (README Example 1: 7 entries, 3 phases). */
+int pmt_plan_fused_phases(const pmt_plan *plan);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
  * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */
 int pmt_plan_update(pmt_plan *plan);

@@ -47,6 +47,7 @@ enum SmallOp : int {
 struct SmallNode {
     int op = 0, sign = 0, moi = 0;
     int dyn = -1;                   // slot of the launch's dynamic-seed table (SOP_FILL with a host seed word), or -1
+    int sync = 1;                   // a barrier in front of the node (set by small_plan_phases, small.hip)
     int64_t d[4] = {0, 0, 0, 0};
     const void *in[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *out[3] = {nullptr, nullptr, nullptr};

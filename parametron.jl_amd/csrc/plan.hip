@@ -43,7 +43,7 @@ struct pmt_plan {
     std::vector<int> node_of;         // per tape entry: index into `nodes`, or -1 (an entry only its closure can execute)
     std::vector<pmt::SmallNode> nodes;
     bool fusion = true;
-    int fused_groups = 0, fused_nodes = 0;
+    int fused_groups = 0, fused_nodes = 0, fused_phases = 0;
     std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
                                       // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
     char record_lane = 0;
@@ -546,14 +546,18 @@ extern "C" int pmt_plan_begin_record(pmt_plan *plan) {
 namespace pmt {
 size_t small_table_bytes(int count);
 void small_table_image(const SmallNode *nodes, int count, void *image);
-int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, hipStream_t s);
+int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
+                      unsigned long long narrowmask, hipStream_t s);
+void small_plan_masks(const SmallNode *nodes, int count, unsigned long long *syncmask, unsigned long long *narrowmask);
+int small_plan_phases(SmallNode *nodes, int count);
+int small_max_nodes();
 }
 
 // exec := tape, with every run of >= 2 consecutive small nodes on the plan's own lane replaced by one interpreter launch (small.hip).  The
 // node tables live in plan-owned device memory, written here once (setup, not the solve path).
 static int build_exec(pmt_plan *plan) {
     plan->exec.clear(); plan->exec_lanes.clear();
-    plan->fused_groups = 0; plan->fused_nodes = 0;
+    plan->fused_groups = 0; plan->fused_nodes = 0; plan->fused_phases = 0;
     const size_t n = plan->tape.size();
     auto small = [&](size_t i) {
         return plan->fusion && plan->node_of[i] >= 0 && plan->lanes[i] == 0 && plan->nodes[(size_t)plan->node_of[i]].work <= pmt::SMALL_NODE_WORK_MAX;
@@ -567,6 +571,7 @@ static int build_exec(pmt_plan *plan) {
             const pmt::SmallNode &nd = plan->nodes[(size_t)plan->node_of[j]];
             if (work + nd.work > pmt::SMALL_GROUP_WORK_MAX && j > i) break;
             if (nd.seed_host && ndyn == pmt::SMALL_MAX_DYN) break;
+            if ((int)(j - i) == pmt::small_max_nodes()) break;
             work += nd.work;
             ndyn += nd.seed_host ? 1 : 0;
             ++j;
@@ -586,6 +591,7 @@ static int build_exec(pmt_plan *plan) {
             if (nd.seed_host) { nd.dyn = (int)words.size(); words.push_back(nd.seed_host); }
             group.push_back(nd);
         }
+        plan->fused_phases += pmt::small_plan_phases(group.data(), count);
         std::vector<char> image(pmt::small_table_bytes(count));
         pmt::small_table_image(group.data(), count, image.data());
         void *table = nullptr;
@@ -594,7 +600,9 @@ static int build_exec(pmt_plan *plan) {
         plan->allocations.push_back(table);
         plan->bytes += image.size();
         PMT_HIP_CHECK(hipMemcpy(table, image.data(), image.size(), hipMemcpyHostToDevice));
-        plan->exec.push_back([=](hipStream_t s) { return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), s); });
+        unsigned long long syncmask = 0, narrowmask = 0;
+        pmt::small_plan_masks(group.data(), count, &syncmask, &narrowmask);
+        plan->exec.push_back([=](hipStream_t s) { return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, s); });
         plan->exec_lanes.push_back(0);
         plan->fused_groups += 1;
         plan->fused_nodes += count;
@@ -620,6 +628,8 @@ extern "C" int pmt_plan_set_fusion(pmt_plan *plan, int on) {
     PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
     return build_exec(plan);
 }
+
+extern "C" int pmt_plan_fused_phases(const pmt_plan *plan) { return plan ? plan->fused_phases : 0; }
 
 extern "C" int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_length) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fused: null plan");

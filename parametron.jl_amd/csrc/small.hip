@@ -7,6 +7,8 @@
 // tape order — a grid-stride loop per node, a workgroup barrier between nodes (a later node reads what an earlier one wrote through the
 // CU's own L1 / L2: workgroup-scope visibility is enough) — and one launch replaces the run.  Every element is computed by the same
 // expression as in the node's stand-alone kernel (affine.hip, quad.hip, rng.hip): outputs are bit-identical, tests/test_gpu_small_plan.py.
+#include <vector>
+
 #include "common.h"
 
 namespace pmt {
@@ -28,6 +30,11 @@ struct SmallDyn { uint64_t v[SMALL_MAX_DYN]; };
 // the device view of a node (the host-only tail of SmallNode is not uploaded)
 struct SmallDev {
     int op, sign, moi, dyn;
+    int sync, narrow;               // narrow != 0: a node of at most 256 elements — inside a phase such nodes are dealt out to the 16 waves (each
+                                    // runs its node with its 64 lanes) instead of being walked one after the other by all 1024 threads: the
+                                    // four Parameter callbacks of README Example 1 are four concurrent waves.  sync != 0: a workgroup barrier in front of this node (it touches what a node since the last barrier wrote, or
+                                    // writes what one read); independent nodes — the four Parameter callbacks, the objective's and a constraint's
+                                    // chains — share a phase
     int64_t d[4];
     const void *in[8];
     void *out[3];
@@ -156,7 +163,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
                 o[e] = r;
             }
         } else {
-            const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;     // (scalar: a wave BRANCHES around the nodes of others)
             for (int64_t row = wave; row < rows; row += nw)
                 for (int64_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
                     const LT t = in[e];
@@ -406,20 +413,112 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
     }
 }
 
-__global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__restrict__ table, int count, SmallDyn dyn) {
-    __shared__ SmallDev node;
+constexpr int SMALL_MAX_NODES = 48;          // nodes of one launch (their descriptions are fetched into LDS in one round trip)
+
+// syncmask / narrowmask: bit k = node k's `sync` / `narrow` flag, as kernel arguments (scalar registers): a wave skips the nodes that are
+// not its own without touching their descriptions (an LDS read and a wait per skipped node was ~0.3 us)
+__global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__restrict__ table, int count, SmallDyn dyn, unsigned long long syncmask,
+                                                          unsigned long long narrowmask) {
+    __shared__ SmallDev nodes[SMALL_MAX_NODES];
     __shared__ uint64_t sdyn[SMALL_MAX_DYN];
     const int tid = threadIdx.x, nt = blockDim.x;
     // (static indices: a kernel argument array indexed by a register would be copied to scratch)
 #pragma unroll
     for (int i = 0; i < SMALL_MAX_DYN; ++i)
         if (tid == i) sdyn[i] = dyn.v[i];
+    // every node description in ONE round trip (a description per node and barrier was a dependent global load per hop: 9 hops of README
+    // Example 1 took 10.6 us of kernel time for ~700 terms of work)
+    constexpr int W8 = (int)(sizeof(SmallDev) / 8);
+    for (int i = tid; i < count * W8; i += nt) reinterpret_cast<u64 *>(nodes)[i] = reinterpret_cast<const u64 *>(table)[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;     // (scalar: a wave BRANCHES around the nodes of others)
+    int slot = 0;                                  // narrow nodes of the current phase seen so far
     for (int k = 0; k < count; ++k) {
-        // the node description goes through LDS: one read of the table per node instead of one per thread
-        if (tid < (int)(sizeof(SmallDev) / 8)) reinterpret_cast<u64 *>(&node)[tid] = reinterpret_cast<const u64 *>(table + k)[tid];
-        __syncthreads();
-        sp_node(node, sdyn, tid, nt);
-        __syncthreads();                   // what this node wrote is visible to the next one (same workgroup), and `node` may be rewritten
+        if ((syncmask >> k) & 1) { __syncthreads(); slot = 0; }   // (uniform: what the previous phase wrote is visible — same workgroup — before this one reads it)
+        if ((narrowmask >> k) & 1) {
+            if (slot % nw == wave) sp_node(nodes[k], sdyn, lane, 64);
+            ++slot;
+        } else {
+            sp_node(nodes[k], sdyn, tid, nt);
+        }
+    }
+}
+
+int small_max_nodes() { return SMALL_MAX_NODES; }
+
+// ---- host: which nodes need a barrier in front of them -----------------------------------------------------------------------------------
+// Byte ranges a node reads / writes, from its shapes (the static index arrays — xvar, varmap, row_ptr — are never written by a node and are
+// left out).  An op this function does not know makes every later node synchronise (conservative).
+struct SmallRange { const char *p; size_t n; };
+static bool small_node_io(const SmallNode &s, std::vector<SmallRange> &rd, std::vector<SmallRange> &wr) {
+    auto R = [&](const void *p, int64_t bytes) { if (p && bytes > 0) rd.push_back({static_cast<const char *>(p), (size_t)bytes}); };
+    auto W = [&](void *p, int64_t bytes) { if (p && bytes > 0) wr.push_back({static_cast<const char *>(p), (size_t)bytes}); };
+    auto mat = [](int64_t ld, int64_t rows, int64_t cols) { return cols > 0 ? ((cols - 1) * ld + rows) * 8 : 0; };
+    const int64_t *d = s.d;
+    switch (s.op) {
+    case SOP_FILL: W(s.out[0], mat(d[2], d[0], d[1])); return true;
+    case SOP_AFFINE_LT: case SOP_AFFINE_VAT:
+        R(s.in[0], mat(d[0], d[1], d[2])); R(s.in[2], d[1] * 8);
+        W(s.out[0], d[1] * d[2] * (s.op == SOP_AFFINE_LT ? 16 : 24)); W(s.out[1], d[1] * 8); return true;
+    case SOP_QUAD_EXPAND:
+        R(s.in[0], d[0] * d[1] * 16); R(s.in[1], d[0] * 8); R(s.in[2], d[0] * d[2] * 16); R(s.in[3], d[0] * 8);
+        W(s.out[0], d[0] * d[1] * d[2] * 24); W(s.out[1], d[0] * (d[1] + d[2]) * 16); W(s.out[2], 8); return true;
+    case SOP_VARS_ADDSUB: R(s.in[1], d[0] * 8); W(s.out[0], d[0] * 16); W(s.out[1], d[0] * 24); W(s.out[2], d[0] * 8); return true;
+    case SOP_CONSTS: R(s.in[0], d[0] * 8); W(s.out[0], d[0] * 8); return true;
+    case SOP_PACK_SA: R(s.in[0], d[0] * 16); W(s.out[0], d[0] * 16); return true;
+    case SOP_PACK_SQ: R(s.in[0], d[0] * 24); W(s.out[0], d[0] * 24); return true;
+    case SOP_PACK_VA: if (s.in[1]) return false; R(s.in[0], d[0] * d[1] * 16); W(s.out[0], d[0] * d[1] * 24); return true;
+    case SOP_COPY8: R(s.in[0], d[0] * 8); W(s.out[0], d[0] * 8); return true;
+    case SOP_GRAM: R(s.in[0], mat(d[0], d[1], d[2])); R(s.in[2], d[1] * 8);
+        W(s.out[0], d[2] * (d[2] + 1) / 2 * 24); W(s.out[1], d[2] * 16); W(s.out[2], 8); return true;
+    case SOP_AFFVEC_COMBINE: R(s.in[0], d[0] * d[1] * 16); R(s.in[1], d[0] * 8); R(s.in[2], d[0] * d[2] * 16); R(s.in[3], d[0] * 8);
+        W(s.out[0], d[0] * d[3] * 16); W(s.out[1], d[0] * 8); return true;
+    case SOP_AFFVEC_SCALE: R(s.in[0], d[1] * 16); R(s.in[1], d[0] * 8); R(s.in[2], 8); W(s.out[0], d[1] * 16); W(s.out[1], d[0] * 8); return true;
+    case SOP_MATVEC_AFFS: R(s.in[0], mat(d[0], d[1], d[2])); R(s.in[1], d[2] * d[3] * 16); R(s.in[2], d[2] * 8);
+        W(s.out[0], d[1] * d[2] * d[3] * 16); W(s.out[1], d[1] * 8); return true;
+    case SOP_VECDOT_NUM_VARS: R(s.in[0], d[0] * 8); W(s.out[0], d[0] * 16); W(s.out[1], 8); return true;
+    case SOP_VECDOT_NUM_AFFS: R(s.in[0], d[0] * 8); R(s.in[1], d[0] * d[1] * 16); R(s.in[2], d[0] * 8); W(s.out[0], d[0] * d[1] * 16); W(s.out[1], 8); return true;
+    case SOP_TRANSPOSE: R(s.in[0], mat(d[0], d[1], d[2])); W(s.out[0], mat(d[3], d[2], d[1])); return true;
+    case SOP_QUAD_COMBINE: R(s.in[0], d[0] * 24); R(s.in[1], d[1] * 24); W(s.out[0], (d[0] + d[1]) * 24); return true;
+    case SOP_QUAD_SCALE: R(s.in[0], d[0] * 24); R(s.in[1], 8); W(s.out[0], d[0] * 24); return true;
+    case SOP_SCALE_VARS: R(s.in[1], 8); W(s.out[0], d[0] * 16); return true;
+    case SOP_SCALE_NUMBERS: R(s.in[0], d[0] * 8); R(s.in[1], 8); W(s.out[0], d[0] * 8); return true;
+    case SOP_BILINEAR: R(s.in[0], mat(d[0], d[1], d[2])); W(s.out[0], d[1] * d[2] * 24); return true;
+    case SOP_VECDOT_TERMS: R(s.in[0], d[0] * 8); R(s.in[2], d[0] * 8); W(s.out[0], d[0] * 24); return true;
+    case SOP_VECDOT_AFFS_VARS: R(s.in[0], d[0] * d[1] * 16); R(s.in[1], d[0] * 8); W(s.out[0], d[0] * d[1] * 24); W(s.out[1], d[0] * 16); return true;
+    default: return false;
+    }
+}
+
+// sets nodes[k].sync: 0 for the first node and for a node that neither touches what a node of the current phase wrote nor writes what one
+// read; 1 otherwise (and a new phase begins).  Returns the number of phases.
+int small_plan_phases(SmallNode *nodes, int count) {
+    std::vector<SmallRange> prd, pwr;          // reads / writes of the current phase
+    auto overlap = [](const SmallRange &a, const SmallRange &b) { return a.p < b.p + b.n && b.p < a.p + a.n; };
+    auto any = [&](const std::vector<SmallRange> &x, const std::vector<SmallRange> &y) {
+        for (auto &a : x) for (auto &b : y) if (overlap(a, b)) return true;
+        return false;
+    };
+    int phases = count > 0 ? 1 : 0;
+    for (int k = 0; k < count; ++k) {
+        std::vector<SmallRange> rd, wr;
+        const bool known = small_node_io(nodes[k], rd, wr);
+        const bool dep = !known || any(rd, pwr) || any(wr, pwr) || any(wr, prd);
+        nodes[k].sync = (k > 0 && dep) ? 1 : 0;
+        if (nodes[k].sync) { prd.clear(); pwr.clear(); ++phases; }
+        if (!known) { nodes[k].sync = k > 0 ? 1 : 0; prd.push_back({nullptr, ~(size_t)0}); pwr.push_back({nullptr, ~(size_t)0}); }   // everything after it synchronises too
+        prd.insert(prd.end(), rd.begin(), rd.end());
+        pwr.insert(pwr.end(), wr.begin(), wr.end());
+    }
+    return phases;
+}
+
+// the flag masks of a group (after small_plan_phases)
+void small_plan_masks(const SmallNode *nodes, int count, unsigned long long *syncmask, unsigned long long *narrowmask) {
+    *syncmask = *narrowmask = 0;
+    for (int k = 0; k < count && k < 64; ++k) {
+        if (nodes[k].sync) *syncmask |= 1ull << k;
+        if (nodes[k].work <= 256) *narrowmask |= 1ull << k;
     }
 }
 
@@ -430,7 +529,7 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
     SmallDev *d = static_cast<SmallDev *>(image);
     for (int i = 0; i < count; ++i) {
         const SmallNode &s = nodes[i];
-        d[i].op = s.op; d[i].sign = s.sign; d[i].moi = s.moi; d[i].dyn = s.dyn;
+        d[i].op = s.op; d[i].sign = s.sign; d[i].moi = s.moi; d[i].dyn = s.dyn; d[i].sync = s.sync; d[i].narrow = (s.work <= 256) ? 1 : 0;
         for (int k = 0; k < 4; ++k) d[i].d[k] = s.d[k];
         for (int k = 0; k < 8; ++k) d[i].in[k] = s.in[k];
         for (int k = 0; k < 3; ++k) d[i].out[k] = s.out[k];
@@ -438,10 +537,11 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
     }
 }
 
-int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, hipStream_t s) {
+int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
+                      unsigned long long narrowmask, hipStream_t s) {
     SmallDyn dyn;
     for (int i = 0; i < SMALL_MAX_DYN; ++i) dyn.v[i] = (i < ndyn && seed_words[i]) ? *seed_words[i] : 0;
-    PMT_LAUNCH(small_plan_kernel, dim3(1), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn);
+    PMT_LAUNCH(small_plan_kernel, dim3(1), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn, syncmask, narrowmask);
     return check_launch("small_plan_kernel");
 }
 

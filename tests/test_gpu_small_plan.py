@@ -69,6 +69,8 @@ def test_config1_update_is_one_launch_and_matches_golden_and_oracle():
         g.call("pmt_quad_expand_f64", r, g.ptr(lt), n, g.ptr(cst), g.ptr(lt), n, g.ptr(cst), 1, g.ptr(vm), g.ptr(oq), g.ptr(ol), g.ptr(oc), p.rec)
         g.call("pmt_affine_pack_vector_f64", g.ptr(Cm), m, m, n, g.ptr(xvar), g.ptr(d), -1, g.ptr(vm), 0, g.ptr(vt), g.ptr(vc), p.rec)
     assert p.fused() == (1, 7, 1)                                     # one run, seven tape entries, ONE launch per update!
+    # barriers only between dependent nodes: [four callbacks] | [residual] | [objective, constraint block]
+    assert int(g.lib().pmt_plan_fused_phases(p.plan)) == 3
     assert int(g.lib().pmt_plan_tape_length(p.plan)) == 7
 
     def outputs():
@@ -216,6 +218,7 @@ def test_algebra_node_kinds_fused_equals_unfused():
         g.call("pmt_scale_vars_f64", g.ptr(yvar), n, None, 2.5, g.ptr(sv), p.rec)
         g.call("pmt_scale_numbers_f64", g.ptr(w), n, g.ptr(sdev), 0.0, g.ptr(sn), p.rec)
     assert p.fused() == (1, 21, 1)
+    assert int(g.lib().pmt_plan_fused_phases(p.plan)) < 21
     p.update()
     torch.cuda.synchronize()
     fused = [t.clone() for t in outs]
