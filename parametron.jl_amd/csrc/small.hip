@@ -431,7 +431,8 @@ __global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__rest
     constexpr int W8 = (int)(sizeof(SmallDev) / 8);
     for (int i = tid; i < count * W8; i += nt) reinterpret_cast<u64 *>(nodes)[i] = reinterpret_cast<const u64 *>(table)[i];
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = nt >> 6;     // (scalar: a wave BRANCHES around the nodes of others)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;     // (scalar: a wave BRANCHES around the nodes of others)
+    constexpr int nw = 16;                         // (the launch is always 1024 threads)
     int slot = 0;                                  // narrow nodes of the current phase seen so far
     for (int k = 0; k < count; ++k) {
         if ((syncmask >> k) & 1) { __syncthreads(); slot = 0; }   // (uniform: what the previous phase wrote is visible — same workgroup — before this one reads it)
