@@ -27,7 +27,7 @@ namespace pmt {
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 void mark_no_graph(void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s, int chained);
-int gram_tall_groups(int64_t rows);
+int gram_tall_groups(int64_t rows, int64_t cols);
 int gram_tall_stage_rows();
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
@@ -37,8 +37,9 @@ int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t d
 void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s);
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0);
 bool gram_tall_applies(int64_t rows, int64_t cols);
+bool gram_tall_diag_applies(int64_t rows, int64_t cols);
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
                      const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
@@ -434,9 +435,9 @@ using namespace pmt;
 
 extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows) {
     PMT_REQUIRE(rows >= 0 && cols >= 0 && order, PMT_INVALID_ARGUMENT, "quad_gram_constant_order: bad argument");
-    const bool tall = cols > 0 && gram_tall_applies(rows, cols);
+    const bool tall = cols > 0 && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
     *order = tall ? 2 : (constant_chained(rows, cols) ? 1 : 0);
-    if (groups) *groups = tall ? gram_tall_groups(rows) : (*order == 1 ? 2048 : 1);
+    if (groups) *groups = tall ? gram_tall_groups(rows, cols) : (*order == 1 ? 2048 : 1);
     if (stage_rows) *stage_rows = tall ? gram_tall_stage_rows() : 0;
     return PMT_OK;
 }
@@ -584,6 +585,15 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     if (!deliver_host && cols > 0 && gram_tall_applies(rows, cols) && workspace)
         return dispatch(stream, [=](hipStream_t s) {
             return launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
+        });
+    // wide tall shapes: the diagonal tiles, q and c'c in one fused pass (gram_tall.hip), then the strictly upper tiles in ONE ranged launch
+    // of the stream-K kernel (SKArgs::strict: its tile sequence leaves the diagonal out).  The partials of both forms share the workspace
+    // in stream order.
+    if (!deliver_host && cols > 0 && gram_tall_diag_applies(rows, cols) && workspace)
+        return dispatch(stream, [=](hipStream_t s) {
+            if (int rc = launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s)) return rc;
+            const int64_t nt = cdiv(cols, GT);
+            return launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt - 1) / 2, nullptr, 0, nullptr, s, 1);
         });
     Launch node = [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while

@@ -35,6 +35,8 @@ struct SKArgs {
     unsigned flag_value;                       // what a first half stores into its tile's flag: `epoch` (anything else only under fault injection)
     int *error;                                // page-locked error word: a second half whose partner never showed up stores 2 here
     long long pair_timeout;                    // bound of the pair wait in 100 MHz ticks
+    int strict;                                // ranged launches: the sequence enumerates the STRICTLY upper tiles (jb < kb) only — the diagonal
+                                               // tiles of a wide tall matrix are computed by gram_tall.hip
 };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
@@ -116,6 +118,13 @@ __device__ __forceinline__ void sk_colseq_unrank(int idx, int nt, int w, int &jb
 __device__ __forceinline__ void sk_tile_unrank(const SKArgs &g, int idx, int &jb, int &kb) {
     if (g.order_w > 0) sk_colseq_unrank(idx, g.ntiles, g.order_w, jb, kb);
     else sk_seq_unrank(idx, g.ntiles, jb, kb);
+}
+
+// strictly upper tiles of the nt x nt grid = the upper-inclusive triangle of size nt - 1 shifted one tile column to the right (the same
+// L2-friendly super-row order)
+__device__ __forceinline__ void sk_tile_unrank_strict(const SKArgs &g, int idx, int &jb, int &kb) {
+    sk_seq_unrank(idx, g.ntiles - 1, jb, kb);
+    kb += 1;
 }
 
 // sequence index of the t-th whole tile of workgroup bid (phase A)

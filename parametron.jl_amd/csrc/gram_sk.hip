@@ -463,7 +463,8 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
             const int c0 = (int)(u - (int64_t)rtile * g.nchunk);
             const int c1 = (int)min((int64_t)g.nchunk, (int64_t)c0 + (u1 - u));
             int jb, kb;
-            sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * tile : tile, jb, kb);
+            if (RANGED && g.strict) sk_tile_unrank_strict(g, g.seq_begin + g.seq_step * tile, jb, kb);
+            else sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * tile : tile, jb, kb);
             const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
             const bool diag = (jb == kb);
             const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
@@ -608,7 +609,8 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
     // phase A: tfull whole tiles per workgroup (contiguous, so consecutive tiles share their row panel in L2), written directly
     for (int t = 0; t < g.tfull; ++t) {
         int jb, kb;
-        sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * sk_phase_a_index(g, bid, t) : sk_phase_a_index(g, bid, t), jb, kb);
+        if (RANGED && g.strict) sk_tile_unrank_strict(g, g.seq_begin + g.seq_step * sk_phase_a_index(g, bid, t), jb, kb);
+        else sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * sk_phase_a_index(g, bid, t) : sk_phase_a_index(g, bid, t), jb, kb);
         double acc[C::NACC];
         sk_accumulate<TN, BK, ABL>(g, (int64_t)jb * ST, (int64_t)kb * ST, jb == kb, 0, g.rows, acc, lds, tid);
         sk_epilogue<TN>(g, jb, kb, acc, &lds[0][0][0], tid);
@@ -670,7 +672,8 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
         for (int r = 0; r < APB; ++r) acc[r] = acc[r] + w[r * C::NT];
     }
     int jb, kb;
-    sk_tile_unrank(g, g.seq_begin + g.seq_step * tile, jb, kb);
+    if (g.strict) sk_tile_unrank_strict(g, g.seq_begin + g.seq_step * tile, jb, kb);
+    else sk_tile_unrank(g, g.seq_begin + g.seq_step * tile, jb, kb);
 #pragma unroll
     for (int r = 0; r < APB; ++r) {
         int row, col;
@@ -699,8 +702,9 @@ static int env_int(const char *name, int dflt) {
 // anything but `epoch`): tiles split exactly in two are summed inside the launch (see the kernel) instead of by the fix-up pass.
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s) {
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict) {
     SKArgs g;
+    g.strict = (strict && seq_count >= 0) ? 1 : 0;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
     g.ntiles = (int)cdiv(cols, ST);

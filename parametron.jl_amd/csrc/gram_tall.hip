@@ -317,6 +317,12 @@ __global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g
     __shared__ double lds[2][TCOLS * TGP];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blockIdx.y: the DIAGONAL tile this workgroup works on (wide tall matrices: every 128-column diagonal tile of A'A is this kernel's
+    // triangle problem on the tile's own columns; the off-diagonal tiles are the stream-K kernel's, gram.hip)
+    const int64_t tile = blockIdx.y;
+    g.A += tile * TCOLS * g.lda;
+    g.cols = min((int64_t)TCOLS, g.cols - tile * TCOLS);
+    g.ws += tile * (int64_t)gridDim.x * TSTRIDE;
     if (wave == 0) tall_body<0, FAST>(g, lds, tid);
     else if (wave == 1) tall_body<1, FAST>(g, lds, tid);
     else if (wave == 2) tall_body<2, FAST>(g, lds, tid);
@@ -336,9 +342,10 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
     __shared__ double part[TSLICES][64];
     const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
+    const int64_t tile = blockIdx.y, j0 = tile * TCOLS;          // (diagonal tile of a wide matrix: global indices j0 + ..)
     double sum = 0.0;
     if (e < TPART + TCOLS + 1) {
-        const double *p = f.ws + e;
+        const double *p = f.ws + tile * (int64_t)f.G * TSTRIDE + e;
         int gidx = slice;
         for (; gidx + 3 * TSLICES < f.G; gidx += 4 * TSLICES) {
             const double v0 = p[(int64_t)gidx * TSTRIDE], v1 = p[(int64_t)(gidx + TSLICES) * TSTRIDE];
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
         const int w = a / TACC, k = (a % TACC) >> 2, r = a & 3;
         const int tm = TALL_BLOCKS[w][k][0], tn = TALL_BLOCKS[w][k][1];
         const int i = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3;
-        const int64_t j = 16 * tm + 4 * b + i, kk = 16 * tn + 4 * ((b + r) & 3) + jj;
+        const int64_t j = j0 + 16 * tm + 4 * b + i, kk = j0 + 16 * tn + 4 * ((b + r) & 3) + jj;
         if (kk >= n || j > kk) return;
         double c = v;
         if (f.moi || j != kk) c = 2 * c;
@@ -372,40 +379,47 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
             o[2] = (u64)(f.moi ? map_var(f.varmap, kv) : kv);
         }
     } else if (e < TPART + TCOLS) {
-        const int64_t j = e - TPART;
+        const int64_t j = j0 + (e - TPART);
         if (j >= n) return;
         LT t;
         t.coeff = 2 * v;
         const int64_t xv = f.xvar[j];
         t.var = f.moi ? map_var(f.varmap, xv) : xv;
         f.out_lin[j] = t;
-    } else {
-        *f.out_const = v;
+    } else if (tile == 0) {
+        *f.out_const = v;                 // (every tile's workgroups sum the same c'c: the first tile's is the node's)
     }
 }
 
 // shapes the fused tall form takes: one 128-column tile, enough rows that the stream-K form's full square and its separate q / c'c
 // launches cost more than the partial sums (below, the stream-K node keeps the reference's sequential constant bit for bit)
 bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <= TCOLS && rows >= 1024; }
+// WIDE tall shapes (129 .. 1024 columns, rows >> columns): the diagonal tiles take this kernel — one launch over (row groups x tiles) —
+// and the off-diagonal tiles the stream-K kernel, column band by column band (gram.hip).  The stream-K form alone computes every diagonal
+// tile as a full square (17 % of the executed flops at 512 columns) and needs two more kernels for q and c'c.
+bool gram_tall_diag_applies(int64_t rows, int64_t cols) { return cols > TCOLS && cols <= 8 * TCOLS && rows >= 16384 && rows >= 16 * cols; }
 
-// stages per workgroup: at most TALL_MAX_G workgroups, at least TALL_MIN_CHUNK rows each
-static int64_t tall_chunk(int64_t rows) {
-    const int64_t nst = cdiv(rows, TBK);
-    return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, TALL_MAX_G));
+// stages per workgroup: at most TALL_MAX_G workgroups over all tiles, at least TALL_MIN_CHUNK rows each
+static int64_t tall_chunk(int64_t rows, int64_t cols) {
+    const int64_t nst = cdiv(rows, TBK), nt = std::max<int64_t>(1, cdiv(cols, TCOLS));
+    const int64_t maxg = nt == 1 ? TALL_MAX_G : std::max<int64_t>(64, 2 * TALL_MAX_G / nt);
+    return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, maxg));
 }
 int gram_tall_stage_rows() { return TBK; }
-int gram_tall_groups(int64_t rows) { return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows)); }
+int gram_tall_groups(int64_t rows, int64_t cols) { return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols)); }
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols) {
-    return gram_tall_applies(rows, cols) ? sizeof(double) * (size_t)gram_tall_groups(rows) * TSTRIDE : 0;
+    if (!gram_tall_applies(rows, cols) && !gram_tall_diag_applies(rows, cols)) return 0;
+    return sizeof(double) * (size_t)gram_tall_groups(rows, cols) * (size_t)cdiv(cols, TCOLS) * TSTRIDE;
 }
 
+// all diagonal tiles of A'A (one tile when cols <= 128), q = 2 A'c for every column and c'c
 int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
                      const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
                      double *out_const, void *workspace, hipStream_t s) {
     if (!workspace) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
     TallArgs g;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.b = (b && sign) ? b : nullptr; g.sign = g.b ? sign : 0;
-    g.chunk = tall_chunk(rows);
+    g.chunk = tall_chunk(rows, cols);
     g.nstages = cdiv(rows, TBK);
 #ifdef PMT_TUNING
     static const int inter = [] { const char *e = getenv("PMT_TALL_INTERLEAVE"); return e ? atoi(e) : 1; }();
@@ -415,16 +429,17 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
 #endif
     g.ws = reinterpret_cast<double *>(workspace);
     g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
-    const int G = gram_tall_groups(rows);
-    // whole stages, whole panel, aligned pieces (of A and of b): no bounds checks
-    const bool fast = g.vec_in && cols == TCOLS && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
-    if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G), dim3(256), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G), dim3(256), 0, s, g);
+    const int G = gram_tall_groups(rows, cols);
+    const unsigned nt = (unsigned)cdiv(cols, TCOLS);
+    // whole stages, whole panels, aligned pieces (of A and of b): no bounds checks
+    const bool fast = g.vec_in && cols % TCOLS == 0 && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
+    if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
     if (int rc = check_launch("gram_tall_kernel")) return rc;
     TallFixArgs f;
     f.ws = g.ws; f.G = G; f.cols = cols; f.xvar = xvar; f.varmap = varmap; f.moi = moi; f.out_quad = out_quad; f.out_csc = out_csc; f.alpha = alpha;
     f.out_lin = out_lin; f.out_const = out_const;
-    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64)), dim3(1024), 0, s, f);
+    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64), nt), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
 }
 

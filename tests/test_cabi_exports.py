@@ -243,15 +243,16 @@ def test_julia_backend_is_strict_by_default():
 
 def test_constant_order_is_host_arithmetic(lib):
     """pmt_quad_gram_constant_order: the fixed summation order of the node's constant follows from (rows, cols) alone — sequential where the
-    contraction hides the chain (config 2), 2048 chains for long vectors or few columns (cost model), the fused tall order for one-tile
-    tall shapes; no GPU needed"""
+    contraction hides the chain (config 2), 2048 chains for long vectors or few columns (cost model), the fused tall order for tall
+    shapes (one tile, or up to eight with rows >= 16 columns); no GPU needed"""
     def order(r, n):
         o, g, s = C.c_int(), C.c_int(), C.c_int()
         lib.call("pmt_quad_gram_constant_order", r, n, C.byref(o), C.byref(g), C.byref(s))
         return o.value, g.value, s.value
     assert order(4096, 4096) == (0, 1, 0)                      # config 2: the reference's left-to-right sum, hidden behind 1.19 ms of contraction
     assert order(80, 96)[0] == 0 and order(1000, 128)[0] == 0   # short vectors: sequential (the tall form starts at 1024 rows)
-    assert order(16384, 1024) == (1, 2048, 0) and order(131072, 256)[0] == 1
+    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2      # wide tall shapes: the diagonal tiles take the tall kernel, tile 0 the constant
+    assert order(8192, 1024) == (1, 2048, 0)                              # rows < 16 columns: stream-K alone, chained constant
     assert order(4096, 256)[0] == 1 and order(4096, 1024)[0] == 1          # a 0.29 ms chain beside a few tiles: chained
     o, g, s = order(1 << 20, 128)
     assert (o, s) == (2, 32) and g == 512
