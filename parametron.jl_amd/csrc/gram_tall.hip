@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g
 
 struct TallFixArgs {
     const double *ws; int G;
+    int nb;                               // 0: the 36-block layout of gram_tall_kernel; NB > 0: gram_narrow_kernel<NB>'s (blocks in packed upper order)
+    int part, pcols, stride;              // doubles of triangle partial, columns of the panel, doubles per workgroup
     int64_t cols; const int64_t *xvar; const int64_t *varmap; int moi;
     QT *out_quad; double *out_csc; double alpha; LT *out_lin; double *out_const;
 };
@@ -344,27 +346,37 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
     const int e = blockIdx.x * 64 + el;
     const int64_t tile = blockIdx.y, j0 = tile * TCOLS;          // (diagonal tile of a wide matrix: global indices j0 + ..)
     double sum = 0.0;
-    if (e < TPART + TCOLS + 1) {
-        const double *p = f.ws + tile * (int64_t)f.G * TSTRIDE + e;
+    const int nel = f.part + f.pcols + 1;
+    const int64_t stride = f.stride;
+    if (e < nel) {
+        const double *p = f.ws + tile * (int64_t)f.G * stride + e;
         int gidx = slice;
         for (; gidx + 3 * TSLICES < f.G; gidx += 4 * TSLICES) {
-            const double v0 = p[(int64_t)gidx * TSTRIDE], v1 = p[(int64_t)(gidx + TSLICES) * TSTRIDE];
-            const double v2 = p[(int64_t)(gidx + 2 * TSLICES) * TSTRIDE], v3 = p[(int64_t)(gidx + 3 * TSLICES) * TSTRIDE];
+            const double v0 = p[(int64_t)gidx * stride], v1 = p[(int64_t)(gidx + TSLICES) * stride];
+            const double v2 = p[(int64_t)(gidx + 2 * TSLICES) * stride], v3 = p[(int64_t)(gidx + 3 * TSLICES) * stride];
             sum = sum + v0; sum = sum + v1; sum = sum + v2; sum = sum + v3;
         }
-        for (; gidx < f.G; gidx += TSLICES) sum = sum + p[(int64_t)gidx * TSTRIDE];
+        for (; gidx < f.G; gidx += TSLICES) sum = sum + p[(int64_t)gidx * stride];
     }
     part[slice][el] = sum;
     __syncthreads();
-    if (slice != 0 || e >= TPART + TCOLS + 1) return;
+    if (slice != 0 || e >= nel) return;
     double v = part[0][el];
 #pragma unroll
     for (int t = 1; t < TSLICES; ++t) v = v + part[t][el];
     const int64_t n = f.cols;
-    if (e < TPART) {
-        const int lane = e & 63, a = e >> 6;              // a = wave * TACC + block * 4 + rotation
-        const int w = a / TACC, k = (a % TACC) >> 2, r = a & 3;
-        const int tm = TALL_BLOCKS[w][k][0], tn = TALL_BLOCKS[w][k][1];
+    if (e < f.part) {
+        const int lane = e & 63, a = e >> 6;              // a = wave * TACC + block * 4 + rotation  (narrow: block * 4 + rotation)
+        const int r = a & 3;
+        int tm, tn;
+        if (f.nb) {                                       // block k of the packed upper order: (tm, tn) = (k - tn (tn + 1) / 2, tn)
+            const int k = a >> 2;
+            tn = k >= 6 ? 3 : k >= 3 ? 2 : k >= 1 ? 1 : 0;
+            tm = k - tn * (tn + 1) / 2;
+        } else {
+            const int w = a / TACC, k = (a % TACC) >> 2;
+            tm = TALL_BLOCKS[w][k][0]; tn = TALL_BLOCKS[w][k][1];
+        }
         const int i = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3;
         const int64_t j = j0 + 16 * tm + 4 * b + i, kk = j0 + 16 * tn + 4 * ((b + r) & 3) + jj;
         if (kk >= n || j > kk) return;
@@ -378,8 +390,8 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
             o[1] = (u64)(f.moi ? map_var(f.varmap, jv) : jv);
             o[2] = (u64)(f.moi ? map_var(f.varmap, kv) : kv);
         }
-    } else if (e < TPART + TCOLS) {
-        const int64_t j = j0 + (e - TPART);
+    } else if (e < f.part + f.pcols) {
+        const int64_t j = j0 + (e - f.part);
         if (j >= n) return;
         LT t;
         t.coeff = 2 * v;
@@ -389,6 +401,213 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
     } else if (tile == 0) {
         *f.out_const = v;                 // (every tile's workgroups sum the same c'c: the first tile's is the node's)
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// NARROW tall matrices (at most 64 columns): 16 FLOP per byte of A at 128 columns become (n + 1) / 8 — 8 at 64 columns, 2 at 16 — and the
+// node is bound by the HBM stream alone; the 128-column kernel above spends the same 36 blocks of MFMAs on it whatever n is
+// (2^20 x 16: 0.34 ms for 134 MB).  Here the panel is 16 NB columns (NB = 1, 2, 4) and the stage 4096 / (16 NB) rows — the same 32 KB of A
+// per stage and workgroup, in pieces of 8 * R contiguous bytes per column —, there are only NB (NB + 1) / 2 blocks (1, 3, 10), and instead of
+// dealing blocks out to the four waves every wave takes ALL blocks over its own quarter of the stage's rows (a split of the contraction
+// index: the same operand reads per MFMA, a quarter of the accumulator traffic at the end, and the waves' sums are added in wave order
+// through LDS before the workgroup's partial is written).  Loads, LDS layout (pitch R + 2), q and c'c on the VALU, interleaved stages and
+// the fix-up are the tall kernel's.  NB = 1: 16 lanes (not 8) walk down a column, so that a column run is still >= 256 contiguous bytes.
+template <int NB> struct Narrow {
+    static constexpr int C = 16 * NB;                    // columns of the panel
+    static constexpr int LPC = NB == 1 ? 16 : 8;         // lanes per column run (row pairs 2 kp of a piece)
+    static constexpr int NCC = 256 / LPC;                // column runs per slot over the workgroup
+    static constexpr int R = 4096 / C;                   // rows per stage
+    static constexpr int PITCH = R + 2;                  // (2 mod 32, as TGP)
+    static constexpr int PIECE = 2 * LPC;                // rows per piece
+    static constexpr int NQ = C > NCC ? C / NCC : 1;     // distinct columns per thread
+    static constexpr int NJ = 8 / NQ;                    // pieces of a column per thread and stage (= R / PIECE)
+    static constexpr int NBLK = NB * (NB + 1) / 2;
+    static constexpr int NACC = NBLK * 4;
+    static constexpr int PART = NACC * 64;               // doubles of triangle partial per workgroup
+    static constexpr int STRIDE = PART + C + 8;
+    static constexpr int KSTEPS = R / 16;                // k-steps per wave and stage
+    static_assert(NJ * PIECE == R && NQ * NCC >= C, "narrow panel geometry");
+};
+
+template <int NB, bool FAST>
+__device__ __forceinline__ void narrow_load(const TallArgs &g, int64_t row0, int64_t rend, int kp, int cc,
+                                            f64x2 (&reg)[Narrow<NB>::NQ][Narrow<NB>::NJ], f64x2 (&cv)[Narrow<NB>::NJ]) {
+    using N = Narrow<NB>;
+#pragma unroll
+    for (int q = 0; q < N::NQ; ++q) {
+        const int64_t col = cc + N::NCC * q;
+#pragma unroll
+        for (int j = 0; j < N::NJ; ++j) {
+            const int64_t row = row0 + N::PIECE * j + 2 * kp;
+            const double *src = g.A + col * g.lda + row;
+            f64x2 v;
+            if (FAST) {
+                v = *reinterpret_cast<const f64x2 *>(src);
+            } else {
+                v.x = 0.0; v.y = 0.0;
+                if (col < g.cols) {
+                    if (g.vec_in && row + 1 < rend) v = *reinterpret_cast<const f64x2 *>(src);
+                    else {
+                        if (row < rend) v.x = src[0];
+                        if (row + 1 < rend) v.y = src[1];
+                    }
+                }
+            }
+            reg[q][j] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N::NJ; ++j) {                    // b comes in raw (see tall_load)
+        const int64_t row = row0 + N::PIECE * j + 2 * kp;
+        f64x2 v;
+        v.x = 0.0; v.y = 0.0;
+        if (g.b) {
+            if (FAST) {
+                v = *reinterpret_cast<const f64x2 *>(g.b + row);
+            } else {
+                if (row < rend) v.x = g.b[row];
+                if (row + 1 < rend) v.y = g.b[row + 1];
+            }
+        }
+        cv[j] = v;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void narrow_store(double *__restrict__ panel, const f64x2 (&reg)[Narrow<NB>::NQ][Narrow<NB>::NJ],
+                                             const f64x2 (&cv)[Narrow<NB>::NJ], int sign, int kp, int cc, double (&qacc)[Narrow<NB>::NQ], double &cacc) {
+    using N = Narrow<NB>;
+#pragma unroll
+    for (int j = 0; j < N::NJ; ++j) {
+        const double c0 = signed_const(cv[j].x, sign), c1 = signed_const(cv[j].y, sign);
+#pragma unroll
+        for (int q = 0; q < N::NQ; ++q) {
+            *reinterpret_cast<f64x2 *>(panel + (cc + N::NCC * q) * N::PITCH + N::PIECE * j + 2 * kp) = reg[q][j];
+            qacc[q] = qacc[q] + c0 * reg[q][j].x;
+            qacc[q] = qacc[q] + c1 * reg[q][j].y;
+        }
+        cacc = cacc + c0 * c0;
+        cacc = cacc + c1 * c1;
+    }
+}
+
+// this wave's quarter of a stage: every block, KSTEPS k-steps (`panel` points at the wave's first row + this lane's k offset)
+template <int NB>
+__device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, int lm, double (&acc)[Narrow<NB>::NACC]) {
+    using N = Narrow<NB>;
+#pragma unroll
+    for (int ks = 0; ks < N::KSTEPS; ++ks) {
+        double a[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) a[t] = panel[(t * 16 + lm) * N::PITCH + ks * 4];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            double bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);
+                bv[r] = panel[(c * 16 + rc) * N::PITCH + ks * 4];
+            }
+#pragma unroll
+            for (int tm = 0; tm <= c; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = c * (c + 1) / 2 + tm;
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], bv[r], acc[k * 4 + r], 0, 0, 0);
+                }
+        }
+    }
+}
+
+template <int NB, bool FAST>
+__global__ __launch_bounds__(256, 2) void gram_narrow_kernel(TallArgs g) {
+    using N = Narrow<NB>;
+    __shared__ double lds[2][N::C * N::PITCH];
+    static_assert(3 * N::NACC * 64 <= 2 * N::C * N::PITCH, "the waves' sums are folded through the panels");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, lk = lane >> 4;
+    const int kp = tid % N::LPC, cc = tid / N::LPC;
+    const int64_t G = gridDim.x, bid = blockIdx.x;
+    const int nstage = (int)(g.nstages > bid ? (g.nstages - bid + G - 1) / G : 0);      // stages bid, bid + G, ..
+    const int64_t rend = g.rows;
+
+    double acc[N::NACC];
+#pragma unroll
+    for (int r = 0; r < N::NACC; ++r) acc[r] = 0.0;
+    double qacc[N::NQ], cacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < N::NQ; ++q) qacc[q] = 0.0;
+    f64x2 reg[N::NQ][N::NJ], cv[N::NJ];
+    auto stage_row = [&](int s) { return (bid + (int64_t)s * G) * N::R; };
+
+    if (nstage > 0) {
+        narrow_load<NB, FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
+        narrow_store<NB>(lds[0], reg, cv, g.sign, kp, cc, qacc, cacc);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int cur = s & 1;
+        const bool more = s + 1 < nstage;
+        if (more) narrow_load<NB, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + lk, lm, acc);
+        if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+        __syncthreads();
+    }
+
+    // the four waves' sums over their quarters, added in wave order; then q (one LPC-lane tree per column) and c'c (the first column run's)
+    double *red = &lds[0][0];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < N::NACC; ++r) red[((wave - 1) * N::NACC + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    double *w = g.ws + (int64_t)blockIdx.x * N::STRIDE;
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < N::NACC; ++r) {
+            double v = acc[r];
+            v = v + red[(0 * N::NACC + r) * 64 + lane];
+            v = v + red[(1 * N::NACC + r) * 64 + lane];
+            v = v + red[(2 * N::NACC + r) * 64 + lane];
+            w[r * 64 + lane] = v;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < N::NQ; ++q) {
+        double v = qacc[q];
+#pragma unroll
+        for (int h = N::LPC / 2; h >= 1; h >>= 1) v = v + __shfl_down(v, h, N::LPC);
+        if (kp == 0) w[N::PART + cc + N::NCC * q] = v;
+    }
+    if (wave == 0) {
+        double v = cacc;
+#pragma unroll
+        for (int h = N::LPC / 2; h >= 1; h >>= 1) v = v + __shfl_down(v, h, N::LPC);
+        if (tid == 0) w[N::PART + N::C] = v;
+    }
+}
+
+static int narrow_nb(int64_t cols) { return cols <= 16 ? 1 : cols <= 32 ? 2 : cols <= 64 ? 4 : 0; }
+static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ? Narrow<2>::R : Narrow<4>::R; }
+static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
+static int narrow_groups(int64_t rows, int nb) {
+    const int64_t nst = cdiv(rows, narrow_stage_rows(nb));
+    return (int)cdiv(nst, cdiv(nst, TALL_MAX_G));
+}
+
+template <int NB>
+static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStream_t s) {
+    using N = Narrow<NB>;
+    g.nstages = cdiv(g.rows, N::R);
+    const int G = narrow_groups(g.rows, NB);
+    const bool fast = g.vec_in && g.cols == N::C && g.rows % N::R == 0 && b_aligned;
+    if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
+    if (int rc = check_launch("gram_narrow_kernel")) return rc;
+    f.G = G; f.nb = NB; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
+    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
+    return check_launch("gram_tall_fixup_kernel");
 }
 
 // shapes the fused tall form takes: one 128-column tile, enough rows that the stream-K form's full square and its separate q / c'c
@@ -405,10 +624,15 @@ static int64_t tall_chunk(int64_t rows, int64_t cols) {
     const int64_t maxg = nt == 1 ? TALL_MAX_G : std::max<int64_t>(64, 2 * TALL_MAX_G / nt);
     return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, maxg));
 }
-int gram_tall_stage_rows() { return TBK; }
-int gram_tall_groups(int64_t rows, int64_t cols) { return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols)); }
+int gram_tall_stage_rows(int64_t cols) { return narrow_nb(cols) ? narrow_stage_rows(narrow_nb(cols)) : TBK; }
+int gram_tall_run_lanes(int64_t cols) { return narrow_nb(cols) == 1 ? Narrow<1>::LPC : 8; }       // row-pair lanes per column run
+int gram_tall_groups(int64_t rows, int64_t cols) {
+    if (const int nb = narrow_nb(cols)) return narrow_groups(rows, nb);
+    return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols));
+}
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols) {
     if (!gram_tall_applies(rows, cols) && !gram_tall_diag_applies(rows, cols)) return 0;
+    if (const int nb = narrow_nb(cols)) return sizeof(double) * (size_t)narrow_groups(rows, nb) * (size_t)narrow_stride(nb);
     return sizeof(double) * (size_t)gram_tall_groups(rows, cols) * (size_t)cdiv(cols, TCOLS) * TSTRIDE;
 }
 
@@ -429,6 +653,13 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
 #endif
     g.ws = reinterpret_cast<double *>(workspace);
     g.vec_in = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0) ? 1 : 0;
+    TallFixArgs f;
+    f.ws = g.ws; f.cols = cols; f.xvar = xvar; f.varmap = varmap; f.moi = moi; f.out_quad = out_quad; f.out_csc = out_csc; f.alpha = alpha;
+    f.out_lin = out_lin; f.out_const = out_const;
+    if (const int nb = narrow_nb(cols)) {
+        const bool b_aligned = (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
+        return nb == 1 ? launch_gram_narrow<1>(g, f, b_aligned, s) : nb == 2 ? launch_gram_narrow<2>(g, f, b_aligned, s) : launch_gram_narrow<4>(g, f, b_aligned, s);
+    }
     const int G = gram_tall_groups(rows, cols);
     const unsigned nt = (unsigned)cdiv(cols, TCOLS);
     // whole stages, whole panels, aligned pieces (of A and of b): no bounds checks
@@ -436,9 +667,7 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
     else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
     if (int rc = check_launch("gram_tall_kernel")) return rc;
-    TallFixArgs f;
-    f.ws = g.ws; f.G = G; f.cols = cols; f.xvar = xvar; f.varmap = varmap; f.moi = moi; f.out_quad = out_quad; f.out_csc = out_csc; f.alpha = alpha;
-    f.out_lin = out_lin; f.out_const = out_const;
+    f.G = G; f.nb = 0; f.part = TPART; f.pcols = TCOLS; f.stride = TSTRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64), nt), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
 }

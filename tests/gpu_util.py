@@ -82,7 +82,7 @@ def assert_terms_equal(got, want):
 
 def constant_in_the_library_order(r, n, b, sign=-1):
     """c'c restated on the CPU in the fixed order the library reports for an r x n node (pmt_quad_gram_constant_order): the reference's
-    left-to-right sum, the 2048 chains, or the fused tall form's per-workgroup / slice order (include/parametron_hip.h)"""
+    left-to-right sum, the 2048 chains, or the fused tall forms' per-workgroup / slice order (2: eight row-pair lanes, 3: sixteen) (include/parametron_hip.h)"""
     order, groups, stage = C.c_int(), C.c_int(), C.c_int()
     call("pmt_quad_gram_constant_order", r, n, C.byref(order), C.byref(groups), C.byref(stage))
     nb = (0.0 - b) if sign < 0 else (0.0 + b)
@@ -101,18 +101,23 @@ def constant_in_the_library_order(r, n, b, sign=-1):
             seq = seq + v
         return order.value, seq
     G, MR = groups.value, stage.value
+    L = 16 if order.value == 3 else 8                                  # row-pair lanes walking down a column piece of 2 L rows
     nst = -(-r // MR)
     sq = np.zeros((nst + G) * MR)
     sq[:r] = nb * nb                                                   # (rows beyond the matrix add 0.0: exact)
-    lanes = np.zeros((G, 8))
+    lanes = np.zeros((G, L))
     gi = np.arange(G)
     for k in range(-(-nst // G)):                                      # workgroup g: stages g, g + G, g + 2G, ..
         base = (gi + k * G) * MR
         live = (gi + k * G) < nst
-        for j in range(MR // 16):
-            idx = base[:, None] + 16 * j + 2 * np.arange(8)[None, :]
+        for j in range(MR // (2 * L)):
+            idx = base[:, None] + 2 * L * j + 2 * np.arange(L)[None, :]
             lanes = np.where(live[:, None], (lanes + sq[idx]) + sq[idx + 1], lanes)
-    part = ((lanes[:, 0] + lanes[:, 4]) + (lanes[:, 2] + lanes[:, 6])) + ((lanes[:, 1] + lanes[:, 5]) + (lanes[:, 3] + lanes[:, 7]))
+    h = L // 2
+    while h >= 1:                                                      # __shfl_down tree: lane i += lane i + h
+        lanes = lanes[:, :h] + lanes[:, h:2 * h]
+        h //= 2
+    part = lanes[:, 0]
     slices = np.zeros(16)
     for g0 in range(0, G, 16):
         seg = part[g0:g0 + 16]

@@ -258,7 +258,8 @@ def test_constant_order_is_host_arithmetic(lib):
     assert (o, s) == (2, 32) and g == 512
     o, g, s = order(8192, 128)
     assert o == 2 and g == 8192 // 64                           # at least 64 rows per workgroup
-    assert order(5000, 17)[0] == 2 and order(1024, 1)[0] == 2
+    assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256)      # narrow panels: 32 columns x 128-row stages, 16 x 256 (16 row-pair lanes)
+    assert order(1 << 20, 64) == (2, 512, 64)
     with pytest.raises(lib.ArgumentError):
         lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
 

@@ -45,7 +45,10 @@ def _sample_pairs(rng, n, count):
 # a wide tall matrix, n <= 1024, r >= 16 n)
 @pytest.mark.parametrize("r,n,count,expect_order", [(4096, 4096, 10000, 0), (16384, 1024, 6000, 2), (4090, 1000, 4000, 1), (131072, 256, 3000, 2),
                                                      (1 << 20, 128, 1500, 2), (8192, 128, 3000, 2), (100003, 100, 2000, 2), (5000, 17, 150, 2),
-                                                     (1000, 128, 2000, 0)])
+                                                     (1000, 128, 2000, 0),
+                                                     # narrow tall shapes (gram_narrow_kernel<1 | 2 | 4>): whole panels and ragged ones
+                                                     (1 << 20, 64, 1200, 2), (262144, 32, 500, 2), (1 << 20, 16, 136, 3), (77777, 50, 900, 2),
+                                                     (33001, 9, 45, 3), (1024, 1, 1, 3), (4099, 33, 500, 2)])
 def test_canonical_objective_against_cpu_sampled_sums(r, n, count, expect_order, record_property):
     import gpu_util as g
     q, l, const = _gram(g, r, n)
