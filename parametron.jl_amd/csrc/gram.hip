@@ -40,6 +40,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
                    unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0);
 bool gram_tall_applies(int64_t rows, int64_t cols);
+bool gram_tiny(int64_t rows, int64_t cols);
 bool gram_tall_diag_applies(int64_t rows, int64_t cols);
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
@@ -576,26 +577,22 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     constexpr int deliver_w = DELIVER_ORDER_W;
 #endif
     const int deliver_order = host_quad ? 0 : -deliver_w;
+    // shapes of up to 2048 columns take the fused tall forms (gram_tall.hip) whatever the outputs: one 128-column tile — triangle, q and c'c in
+    // ONE pass over A, no side stream, no separate reductions —, or several — the diagonal tiles, q and c'c in one fused pass, then the strictly
+    // upper tiles in ONE ranged launch of the stream-K kernel (SKArgs::strict: its tile sequence leaves the diagonal out; the partials of both
+    // forms share the workspace in stream order).  A host delivery of such a node is ONE transfer of the whole array behind it: the staged
+    // contraction pays for hundreds of megabytes (config 2), not for the <= 50 MB of these shapes.
+    const bool tall_form = cols > 0 && workspace && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
     if (deliver_host && cols > 0) {
-        dplan = deliver_plan(rows, cols, ngroups, deliver_w, deliver_host, host_quad != nullptr);
+        if (tall_form) {
+            dplan.host = deliver_host;
+            dplan.nstages = 0; dplan.ngroups = 1; dplan.gbeg[0] = 0;
+            dplan.gend[0] = (host_quad ? 3 : 1) * (cols * (cols + 1) / 2);
+        } else dplan = deliver_plan(rows, cols, ngroups, deliver_w, deliver_host, host_quad != nullptr);
         dplan.host_dev = static_cast<double *>(host_device_pointer(deliver_host));
         PMT_REQUIRE(dplan.host_dev, PMT_INVALID_ARGUMENT, "quad_gram_csc_deliver: host_P_values must be page-locked host memory (pmt_host_alloc)");
         mark_no_graph(stream);
     }
-    // tall one-tile shapes: triangle, q and c'c in ONE pass over A (gram_tall.hip); no side stream, no separate reductions
-    if (!deliver_host && cols > 0 && gram_tall_applies(rows, cols) && workspace)
-        return dispatch(stream, [=](hipStream_t s) {
-            return launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
-        });
-    // wide tall shapes: the diagonal tiles, q and c'c in one fused pass (gram_tall.hip), then the strictly upper tiles in ONE ranged launch
-    // of the stream-K kernel (SKArgs::strict: its tile sequence leaves the diagonal out).  The partials of both forms share the workspace
-    // in stream order.
-    if (!deliver_host && cols > 0 && gram_tall_diag_applies(rows, cols) && workspace)
-        return dispatch(stream, [=](hipStream_t s) {
-            if (int rc = launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s)) return rc;
-            const int64_t nt = cdiv(cols, GT);
-            return launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt - 1) / 2, nullptr, 0, nullptr, s, 1);
-        });
     Launch node = [=](hipStream_t s) {
         // fork: the two small reductions of this node (q = 2 A'c, HBM-bound; c'c, a serial chain) run on a side stream while
         // the MFMA-bound contraction owns the main stream; join before returning control of `s`.  Legal under stream capture.
@@ -632,7 +629,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             }
         }
         hipStream_t s2 = s;
-        if (side) {
+        if (side && !tall_form) {
             PMT_HIP_CHECK(hipEventRecord(side->fork, s));
             PMT_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
             s2 = side->stream;
@@ -640,7 +637,8 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         int rc = PMT_OK;
         double *scratch = workspace ? reinterpret_cast<double *>(static_cast<char *>(workspace) + gram_sk_workspace_bytes(rows, cols)) : nullptr;
         const int nsplit = (scratch && b && sign) ? linear_splits(rows, cols) : 1;
-        if (cols > 0 && nsplit > 1) {
+        if (tall_form) {
+        } else if (cols > 0 && nsplit > 1) {
             const int64_t chunk = 64 * cdiv(cdiv(rows, nsplit), 64);
             PMT_LAUNCH(gram_linear_split_kernel, dim3((unsigned)cdiv(cols, 4), (unsigned)nsplit), dim3(256), 0, s2, A, lda, rows, cols, b, sign, chunk, scratch);
             PMT_LAUNCH(gram_linear_finish_kernel, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, s2, scratch, nsplit, cols, xvar, moi, varmap, out_lin);
@@ -663,11 +661,28 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             }
             return rc2;
         };
-        const bool defer_const = side && side->in_replay;
+        const bool defer_const = side && side->in_replay && !tall_form;
         if (!rc && defer_const) side->deferred.push_back(const_part);
-        if (side) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
+        if (side && !tall_form) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
-            if (!deliver) {
+            if (tall_form) {
+                rc = launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
+                // a plan's side-lane entries recorded behind this node may read its AFFINE part (the hand-off's q gather; plan.hip `replay`): with
+                // the stream-K form they queue behind gram_linear on the side stream — here the side stream is told to wait for the fix-up
+                // that has just written q and the constant (the strictly upper tiles below then run beside those entries)
+                if (!rc && side && side->in_replay) {
+                    PMT_HIP_CHECK(hipEventRecord(side->fork, s));
+                    PMT_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+                }
+                const int64_t nt = cdiv(cols, GT);
+                if (!rc && nt > 1)
+                    rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt - 1) / 2, nullptr, 0, nullptr, s, 1);
+                if (!rc && deliver) {                 // the whole array is in memory behind the node's last kernel: release its one transfer
+                    char *cb = static_cast<char *>(side->counters);
+                    dma::Signal word = use_engine ? sig->dep[0] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET)};
+                    rc = dma::launch_signal_store(word, s);
+                }
+            } else if (!deliver) {
                 rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, -1, nullptr, 0, nullptr, s);
             } else {
                 // stage by stage; behind a stage that completes column bands, one thread stores 0 into the word the transfer of those bands waits
@@ -715,13 +730,14 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
                 }
             }
         }
+        if (tall_form) return rc;
         if (side) PMT_HIP_CHECK(hipStreamWaitEvent(s, side->join, 0));
         if (!rc && !defer_const) rc = const_part();          // (behind the contraction's launch: its workgroups are placed first)
         return rc;
     };
     // tiny shapes (README Example 1 with the canonical objective: 8 x 8): also a small-plan node — row-order sums by the interpreter kernel
     // instead of four launches and a side-stream fork
-    if (!deliver_host && !out_csc && cols > 0 && rows * cols * (cols + 1) / 2 <= 16384 && rows <= 1024) {
+    if (!deliver_host && !out_csc && gram_tiny(rows, cols)) {
         SmallNode nd;
         nd.op = SOP_GRAM; nd.sign = (b && sign) ? sign : 0; nd.moi = moi; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols;
         nd.in[0] = A; nd.in[1] = xvar; nd.in[2] = b; nd.in[3] = varmap; nd.out[0] = out_quad; nd.out[1] = out_lin; nd.out[2] = out_const;

@@ -9,7 +9,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 constexpr int ST = 128;            // output tile edge
-constexpr int SKC = 256;           // contraction depth per work unit
+constexpr int SKC = 256;           // contraction depth per work unit (the most; SKArgs::skc)
 constexpr int MAXG = 512;          // upper bound on persistent workgroups
 constexpr int SLOT = ST * ST;      // doubles per partial-tile slot
 constexpr int MAXGROUPS = 16;     // stages (band ranges) of a host delivery
@@ -21,6 +21,7 @@ struct SKArgs {
     double *out_csc;  // solver form: alpha * (MOI coefficient) at k(k+1)/2 + j (CSC of the upper triangle, values only), or null
     double alpha;
     int ntiles, nchunk, G;
+    int skc;          // rows per (tile, chunk) work unit: SKC, or less where SKC-row units would leave most of the chip idle (launch_gram_sk)
     int tfull;        // whole tiles per workgroup (phase A); tiles [tfull*G, T) are split along the contraction (phase B)
     int64_t U;        // number of (tile, chunk) units of phase B = (T - tfull*G) * nchunk
     int vec_in;

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
             else sk_tile_unrank(g, RANGED ? g.seq_begin + g.seq_step * tile : tile, jb, kb);
             const int64_t j0 = (int64_t)jb * ST, k0 = (int64_t)kb * ST;
             const bool diag = (jb == kb);
-            const int64_t ibeg = (int64_t)c0 * SKC, iend = min(g.rows, (int64_t)c1 * SKC);
+            const int64_t ibeg = (int64_t)c0 * g.skc, iend = min(g.rows, (int64_t)c1 * g.skc);
 
             double acc[C::NACC];
             sk_accumulate<TN, BK, ABL>(g, j0, k0, diag, ibeg, iend, acc, lds, tid);
@@ -708,8 +708,14 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
     g.ntiles = (int)cdiv(cols, ST);
-    g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, SKC));
     const int64_t T = seq_count >= 0 ? seq_count : (int64_t)g.ntiles * (g.ntiles + 1) / 2;      // tiles of this launch
+    // Work units of SKC rows leave a small problem on a few CUs (512 x 512: 20 units, 42 us at one CU's rate each): where the units would
+    // not fill the chip they shrink, down to 64 rows (four stages).  Host deliveries plan their stages on SKC-row units (gram.hip) and
+    // keep them.
+    g.skc = SKC;
+    if (seq_count < 0 || g.strict)
+        while (g.skc > 64 && T * cdiv(rows, g.skc) < 256) g.skc >>= 1;
+    g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, g.skc));
     g.seq_begin = (int)seq_begin; g.seq_step = 1;
     if (order_w < 0) {                                // walked from the end: position p of the walk is tile T_all - 1 - p of the sequence
         order_w = -order_w;

@@ -412,15 +412,32 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
 // index: the same operand reads per MFMA, a quarter of the accumulator traffic at the end, and the waves' sums are added in wave order
 // through LDS before the workgroup's partial is written).  Loads, LDS layout (pitch R + 2), q and c'c on the VALU, interleaved stages and
 // the fix-up are the tall kernel's.  NB = 1: 16 lanes (not 8) walk down a column, so that a column run is still >= 256 contiguous bytes.
+#ifndef PMT_NARROW_STAGE
+#define PMT_NARROW_STAGE 4096      // doubles per stage and workgroup (NB = 4 always 4096: the waves' sums are folded through the panels)
+#endif
+#ifndef PMT_NARROW_NT
+#define PMT_NARROW_NT 0            // A loaded with the nontemporal policy
+#endif
+#ifndef PMT_NARROW_WPS
+#define PMT_NARROW_WPS 2
+#endif
+#ifndef PMT_NARROW_MAXG
+#define PMT_NARROW_MAXG 512
+#endif
+#ifndef PMT_NARROW_ABL
+#define PMT_NARROW_ABL 0           // ablations (wrong results): 1 no loads after the first stage, 2 no MFMAs
+#endif
 template <int NB> struct Narrow {
     static constexpr int C = 16 * NB;                    // columns of the panel
     static constexpr int LPC = NB == 1 ? 16 : 8;         // lanes per column run (row pairs 2 kp of a piece)
     static constexpr int NCC = 256 / LPC;                // column runs per slot over the workgroup
-    static constexpr int R = 4096 / C;                   // rows per stage
+    static constexpr int STAGE = NB == 4 ? 4096 : PMT_NARROW_STAGE;
+    static constexpr int SLOTS = STAGE / 512;            // 16-byte loads per thread and stage
+    static constexpr int R = STAGE / C;                  // rows per stage
     static constexpr int PITCH = R + 2;                  // (2 mod 32, as TGP)
     static constexpr int PIECE = 2 * LPC;                // rows per piece
     static constexpr int NQ = C > NCC ? C / NCC : 1;     // distinct columns per thread
-    static constexpr int NJ = 8 / NQ;                    // pieces of a column per thread and stage (= R / PIECE)
+    static constexpr int NJ = SLOTS / NQ;                // pieces of a column per thread and stage (= R / PIECE)
     static constexpr int NBLK = NB * (NB + 1) / 2;
     static constexpr int NACC = NBLK * 4;
     static constexpr int PART = NACC * 64;               // doubles of triangle partial per workgroup
@@ -442,7 +459,7 @@ __device__ __forceinline__ void narrow_load(const TallArgs &g, int64_t row0, int
             const double *src = g.A + col * g.lda + row;
             f64x2 v;
             if (FAST) {
-                v = *reinterpret_cast<const f64x2 *>(src);
+                v = PMT_NARROW_NT ? __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(src)) : *reinterpret_cast<const f64x2 *>(src);
             } else {
                 v.x = 0.0; v.y = 0.0;
                 if (col < g.cols) {
@@ -520,10 +537,11 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
 }
 
 template <int NB, bool FAST>
-__global__ __launch_bounds__(256, 2) void gram_narrow_kernel(TallArgs g) {
+__global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallArgs g) {
     using N = Narrow<NB>;
     __shared__ double lds[2][N::C * N::PITCH];
     static_assert(3 * N::NACC * 64 <= 2 * N::C * N::PITCH, "the waves' sums are folded through the panels");
+    static_assert(N::KSTEPS >= 1, "a stage holds at least 16 rows per wave");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, lk = lane >> 4;
@@ -549,9 +567,17 @@ __global__ __launch_bounds__(256, 2) void gram_narrow_kernel(TallArgs g) {
     for (int s = 0; s < nstage; ++s) {
         const int cur = s & 1;
         const bool more = s + 1 < nstage;
+#if PMT_NARROW_ABL == 1
+        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + lk, lm, acc);
+        if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#elif PMT_NARROW_ABL == 2
+        if (more) narrow_load<NB, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#else
         if (more) narrow_load<NB, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + lk, lm, acc);
         if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
+#endif
         __syncthreads();
     }
 
@@ -593,7 +619,7 @@ static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ?
 static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
 static int narrow_groups(int64_t rows, int nb) {
     const int64_t nst = cdiv(rows, narrow_stage_rows(nb));
-    return (int)cdiv(nst, cdiv(nst, TALL_MAX_G));
+    return (int)cdiv(nst, cdiv(nst, (int64_t)PMT_NARROW_MAXG));
 }
 
 template <int NB>
@@ -610,13 +636,30 @@ static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStre
     return check_launch("gram_tall_fixup_kernel");
 }
 
-// shapes the fused tall form takes: one 128-column tile, enough rows that the stream-K form's full square and its separate q / c'c
-// launches cost more than the partial sums (below, the stream-K node keeps the reference's sequential constant bit for bit)
-bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <= TCOLS && rows >= 1024; }
-// WIDE tall shapes (129 .. 1024 columns, rows >> columns): the diagonal tiles take this kernel — one launch over (row groups x tiles) —
-// and the off-diagonal tiles the stream-K kernel, column band by column band (gram.hip).  The stream-K form alone computes every diagonal
-// tile as a full square (17 % of the executed flops at 512 columns) and needs two more kernels for q and c'c.
-bool gram_tall_diag_applies(int64_t rows, int64_t cols) { return cols > TCOLS && cols <= 8 * TCOLS && rows >= 16384 && rows >= 16 * cols; }
+// shapes the fused tall form takes: one 128-column tile, any number of rows — the stream-K form's one workgroup per 256 rows of a tile works
+// at one CU's rate (>= 34 us for 100 x 100, measured), computes the full square, and needs two more kernels for q and c'c.  Tiny shapes
+// are the small-plan interpreter's (row-order sums, gram.hip) and keep the stream-K node as their stand-alone form.
+bool gram_tiny(int64_t rows, int64_t cols) {           // (what one interpreter node may cost: SMALL_NODE_WORK_MAX, common.h)
+    const int64_t t = rows * cols * (cols + 1) / 2;
+    return cols > 0 && t <= 16384 && t + 64 * rows <= SMALL_NODE_WORK_MAX;
+}
+bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <= TCOLS && rows >= 1 && !gram_tiny(rows, cols); }
+// WIDE shapes (129 .. 2048 columns, any number of rows): the diagonal tiles take this kernel — one launch over (row groups x tiles), which
+// also yields q for every column and c'c — and the strictly upper tiles the stream-K kernel in ONE ranged launch (gram.hip).  The stream-K
+// form alone computes every diagonal tile as a full square (17 % of the executed flops at 512 columns) and needs two more kernels and a
+// side-stream fork for q and c'c.  Measured (profiles/r05_gram_tall.txt) against the stream-K node: better at every row count from 100 to
+// 2^20 (300 x 300: 64 -> 37 us; 4096 x 512: 112 -> 69 us; 262144 x 512: 1.76 -> 1.44 ms; 65536 x 2048: 5.69 -> 5.37 ms), equal at
+// 8192 x 1024 and 4096 x 2048.  Config 2 (4096 columns) keeps the plain stream-K node.
+bool gram_tall_diag_applies(int64_t rows, int64_t cols) {
+#ifdef PMT_TUNING
+    static const int64_t minrows = [] { const char *e = getenv("PMT_TALL_DIAG_MINROWS"); return e ? atoll(e) : 1LL; }();
+    static const int64_t ratio = [] { const char *e = getenv("PMT_TALL_DIAG_RATIO"); return e ? atoll(e) : 0LL; }();
+    static const int64_t maxcols = [] { const char *e = getenv("PMT_TALL_DIAG_MAXCOLS"); return e ? atoll(e) : 16LL * TCOLS; }();
+    return cols > TCOLS && cols <= maxcols && rows >= minrows && rows >= ratio * cols;
+#else
+    return cols > TCOLS && cols <= 16 * TCOLS && rows >= 1;
+#endif
+}
 
 // stages per workgroup: at most TALL_MAX_G workgroups over all tiles, at least TALL_MIN_CHUNK rows each
 static int64_t tall_chunk(int64_t rows, int64_t cols) {

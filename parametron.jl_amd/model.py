@@ -336,7 +336,10 @@ class Model:
                 self._lane_records = []
                 # one small kernel on the lane does not pay (config 2: the co-resident pack slows the contraction by what it saves); several
                 # do (config 3: -0.15 ms), and so does the device hand-off, whose launches join them on the lane
-                eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane) else []
+                # (never in a SMALL model: its Parameter values arrive through entries at the FRONT of the tape — mailbox copies, seeded fills
+                # — while side-lane entries fork at the top of the replay and would read the buffers before those entries have run; and a
+                # lane would only cut the one-launch plan in pieces)
+                eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane and not self._small) else []
                 # (and with the overlapped MOI boundary a constraint on the lane is packed early: its terms cross PCIe during the contraction)
                 use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and (self.handoff != "moi" or self._overlap_moi))
                 for r, e in zip(records, emitters):

@@ -242,24 +242,26 @@ def test_julia_backend_is_strict_by_default():
 
 
 def test_constant_order_is_host_arithmetic(lib):
-    """pmt_quad_gram_constant_order: the fixed summation order of the node's constant follows from (rows, cols) alone — sequential where the
-    contraction hides the chain (config 2), 2048 chains for long vectors or few columns (cost model), the fused tall order for tall
-    shapes (one tile, or up to eight with rows >= 16 columns); no GPU needed"""
+    """pmt_quad_gram_constant_order: the fixed summation order of the node's constant follows from (rows, cols) alone — the fused tall forms' order up to 2048
+    columns; beyond, sequential where the contraction hides the chain (config 2) or 2048 chains (long vectors, cost model); no GPU needed"""
     def order(r, n):
         o, g, s = C.c_int(), C.c_int(), C.c_int()
         lib.call("pmt_quad_gram_constant_order", r, n, C.byref(o), C.byref(g), C.byref(s))
         return o.value, g.value, s.value
     assert order(4096, 4096) == (0, 1, 0)                      # config 2: the reference's left-to-right sum, hidden behind 1.19 ms of contraction
-    assert order(80, 96)[0] == 0 and order(1000, 128)[0] == 0   # short vectors: sequential (the tall form starts at 1024 rows)
-    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2      # wide tall shapes: the diagonal tiles take the tall kernel, tile 0 the constant
-    assert order(8192, 1024) == (1, 2048, 0)                              # rows < 16 columns: stream-K alone, chained constant
-    assert order(4096, 256)[0] == 1 and order(4096, 1024)[0] == 1          # a 0.29 ms chain beside a few tiles: chained
+    assert order(8, 8) == (0, 1, 0) and order(256, 1)[0] == 0   # tiny shapes (the small-plan node): sequential
+    assert order(1000, 2049)[0] == 0 and order(8192, 4096)[0] == 0 and order(4096, 2304)[0] == 1 and order(8193, 4096) == (1, 2048, 0)   # > 2048 columns: the cost model
+    # up to 2048 columns the fused tall forms, whatever the row count: one tile (order 2; 3 = sixteen row-pair lanes, <= 16 columns) ..
+    assert order(80, 96) == (2, 2, 32) and order(1000, 128)[0] == 2
     o, g, s = order(1 << 20, 128)
     assert (o, s) == (2, 32) and g == 512
     o, g, s = order(8192, 128)
     assert o == 2 and g == 8192 // 64                           # at least 64 rows per workgroup
-    assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256)      # narrow panels: 32 columns x 128-row stages, 16 x 256 (16 row-pair lanes)
+    assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256)      # narrow panels: 32 columns x 128-row stages, 16 x 256
     assert order(1 << 20, 64) == (2, 512, 64)
+    # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
+    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(300, 300)[0] == 2
+    assert order(4096, 256)[0] == 2 and order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32)
     with pytest.raises(lib.ArgumentError):
         lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
 

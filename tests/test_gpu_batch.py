@@ -40,11 +40,15 @@ def test_batch_slabs_match_single_instance_path_and_oracle():
         g.call("pmt_quad_gram_f64", g.ptr(A), r, r, n, g.ptr(xvar), g.ptr(b), -1, 1, g.ptr(varmap), g.ptr(sq), g.ptr(sl), g.ptr(sc), g.ptr(ws), g.stream())
         sv, svc = g.empty_terms(m * n, g.VAT), g.empty_f64(m)
         g.call("pmt_affine_pack_vector_f64", g.ptr(Cm), m, m, n, g.ptr(xvar), g.ptr(d), -1, g.ptr(varmap), 0, g.ptr(sv), g.ptr(svc), g.stream())
-        g.assert_terms_equal(g.terms_to_host(oq, nq, g.QT), g.terms_to_host(sq, nq, g.QT))
+        # (the single-instance node of a one-tile shape is the fused tall form, gram_tall.hip: its own fixed summation order — the batch
+        # kernel's sums agree with it to rounding, indices exactly)
+        bq, sq_h = g.terms_to_host(oq, nq, g.QT), g.terms_to_host(sq, nq, g.QT)
+        assert np.array_equal(bq["row"], sq_h["row"]) and np.array_equal(bq["col"], sq_h["col"])
+        np.testing.assert_allclose(bq["coeff"], sq_h["coeff"], rtol=1e-12, atol=0)
         bl, sl_h = g.terms_to_host(ol, n, g.LT), g.terms_to_host(sl, n, g.LT)
         assert np.array_equal(bl["var"], sl_h["var"])
         np.testing.assert_allclose(bl["coeff"], sl_h["coeff"], rtol=1e-12, atol=0)
-        assert g.same_bits(g.f64_to_host(oc, 1), g.f64_to_host(sc, 1))
+        np.testing.assert_allclose(g.f64_to_host(oc, 1), g.f64_to_host(sc, 1), rtol=1e-14, atol=0)
         g.assert_terms_equal(g.terms_to_host(ov, m * n, g.VAT), g.terms_to_host(sv, m * n, g.VAT))
         assert g.same_bits(g.f64_to_host(ovc, m), g.f64_to_host(svc, m))
         # and against numpy on the host copy (tolerance of north_star)

@@ -44,10 +44,9 @@ def test_gram_node_random_shapes(rows, n):
     c = 0.0 + sign * b
     assert np.array_equal(l["var"], vm_h)
     assert np.all(np.abs(l["coeff"] - 2 * A.T @ c) <= 1e-12 * (2 * np.abs(A).T @ np.abs(c)) + 1e-300)
-    seq = 0.0
-    for v in (0.0 + b if sign > 0 else 0.0 - b):
-        seq = seq + v * v
+    order, seq = g.constant_in_the_library_order(rows, n, b, sign)          # the library's fixed order for this shape, restated bit for bit
     assert g.f64_to_host(oc, 1)[0] == seq
+    assert seq == pytest.approx(float(c @ c), rel=1e-14)
     # the CSC epilogue writes the same coefficients
     px = g.empty_f64(nq)
     g.call("pmt_quad_gram_csc_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), sign, g.ptr(vm), 1.0, g.ptr(px), None, g.ptr(ol), g.ptr(oc),

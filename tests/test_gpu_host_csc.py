@@ -42,7 +42,8 @@ def assert_host_equals_device(model):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (300, 520, 7), (1024, 2048, 64)])
+# (up to 2048 columns the delivered node is the fused tall form + ONE transfer; beyond, the staged stream-K contraction: both are covered)
+@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (300, 520, 7), (1024, 2048, 64), (2200, 320, 9)])
 def test_host_arrays_equal_device_handoff_solve_after_solve(n, r, m, overlap):
     model = lsq_model(n, r, m, handoff="host_csc", overlap_fetch=overlap)
     prev = None
@@ -84,7 +85,8 @@ def test_host_csc_equals_moi_boundary():
     ref.close(); new.close()
 
 
-@pytest.mark.parametrize("rows,cols,ngroups", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 5)])
+@pytest.mark.parametrize("rows,cols,ngroups", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 5),
+                                                  (256, 2176, 0), (600, 2304, 5), (1030, 2500, 16)])
 def test_deliver_entry_point_matches_plain_csc(rows, cols, ngroups):
     """C ABI: pmt_quad_gram_csc_deliver_f64 — the host array equals the device array of the same call bit for bit, both equal
     pmt_quad_gram_csc_f64's values (1e-13: a stage splits its tiles along the contraction and adds two half sums), and q / constant are identical"""
@@ -288,7 +290,8 @@ def test_host_delivery_with_host_updated_parameters_and_several_constraint_block
     model.close()
 
 
-@pytest.mark.parametrize("rows,cols,nstages", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 0)])
+@pytest.mark.parametrize("rows,cols,nstages", [(64, 40, 0), (512, 384, 3), (2048, 1408, 0), (777, 1000, 16), (4096, 2048, 0),
+                                                  (256, 2176, 0), (600, 2304, 5), (1030, 2500, 16)])
 def test_deliver_quadratic_terms_matches_plain_node(rows, cols, nstages):
     """C ABI: pmt_quad_gram_deliver_f64 — the MOI quadratic terms (the reference's own boundary, src/moi_interop.jl:131-137) delivered row band
     by row band: the host array equals the device array of the same call bit for bit; indices equal pmt_quad_gram_f64's, coefficients to 1e-13
@@ -327,7 +330,7 @@ def test_deliver_quadratic_terms_matches_plain_node(rows, cols, nstages):
     _lib.call("pmt_host_free", hp)
 
 
-@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (700, 1100, 33)])
+@pytest.mark.parametrize("n,r,m", [(96, 80, 4), (700, 1100, 33), (2100, 260, 5)])
 def test_overlapped_moi_boundary_equals_the_serial_one(n, r, m):
     """handoff="moi" (the reference's boundary): with overlap_fetch the MOI buffers leave as recorded fetches and the objective's quadratic
     terms row band by row band out of the contraction; what the optimizer's function objects hold after every solve equals the serial

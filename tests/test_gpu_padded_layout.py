@@ -114,10 +114,10 @@ def test_row_counts_that_are_not_a_multiple_of_16_use_zero_padded_copies(r, n):
         iu = np.triu_indices(n)
         np.testing.assert_allclose(f.quadratic_terms["coeff"], (2 * Av.T @ Av)[iu], rtol=1e-12)
         np.testing.assert_allclose(f.affine_terms["coeff"], -2 * Av.T @ bv, rtol=1e-12)
-        # the constant in the library's fixed order for the PADDED shape (sequential, or chained where the cost model says so:
+        # the constant in the library's fixed order for the PADDED shape (the fused tall forms' here:
         # pmt_quad_gram_constant_order); the zero rows add 0.0 * 0.0
         import gpu_util as g
         rp = row_padded(r)
         order, seq = g.constant_in_the_library_order(rp, n, np.concatenate([bv, np.zeros(rp - r)]))
-        assert f.constant == seq and order == (1 if (r, n) == (4090, 256) else 0)
+        assert f.constant == seq and order == 2          # up to 2048 columns: the fused tall forms' order
         Av[...] = rng.random((r, n)); A.val[...] = Av; bv[...] = rng.random(r)      # overwrite: the padding must stay zero
