@@ -682,6 +682,57 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     }
 }
 
+// The same sum for tiles split MANY ways (one off-diagonal tile of a 262144 x 256 matrix: 256 partials of 128 KB): the kernel above adds
+// them as a chain of 16 rounds of 16 loads per thread with 32 workgroups per tile — 64 us for 33 MB.  Here a workgroup takes 64 elements of
+// one accumulator row and EIGHT interleaved slices of the partials (slice t: workgroups blo + t, blo + t + 8, .. in order; 512-byte runs),
+// the slices are added in order through LDS: 256 workgroups per tile, two rounds of loads each.  A fixed order, like the other one's.
+template <int TN>
+__global__ __launch_bounds__(512) void gram_sk_fixup_sliced_kernel(SKArgs g) {
+    using C = Cfg<TN>;
+    constexpr int NSL = 8;
+    __shared__ double part[NSL][64];
+    const int rtile = blockIdx.x;
+    const int tile = g.tfull * g.G + rtile;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = (int)blockIdx.z * 64 + el;                                  // the thread of the contraction whose accumulator this is
+    const int r0 = (int)blockIdx.y;
+    const int64_t ub = (int64_t)rtile * g.nchunk, ue = ub + g.nchunk - 1;
+    auto owner = [&](int64_t u) {
+        int b = (int)((u * g.G) / g.U);
+        if (b >= g.G) b = g.G - 1;
+        while (b + 1 < g.G && sk_unit_begin(g, b + 1) <= u) ++b;
+        while (b > 0 && sk_unit_begin(g, b) > u) --b;
+        return b;
+    };
+    const int blo = owner(ub), bhi = owner(ue);
+    if (blo == bhi) return;
+    auto slot_ptr = [&](int b) {
+        const int64_t bu0 = sk_unit_begin(g, b);
+        const int first_rtile = (int)(bu0 / g.nchunk);
+        const int slot = 2 * b + (first_rtile == rtile ? 0 : 1);
+        return g.ws + (int64_t)slot * SLOT + (int64_t)r0 * C::NT + e;
+    };
+    double acc = 0.0;
+    int b = blo + sl;
+    for (; b + 3 * NSL <= bhi; b += 4 * NSL) {
+        const double v0 = *slot_ptr(b), v1 = *slot_ptr(b + NSL), v2 = *slot_ptr(b + 2 * NSL), v3 = *slot_ptr(b + 3 * NSL);
+        acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+    }
+    for (; b <= bhi; b += NSL) acc = acc + *slot_ptr(b);
+    part[sl][el] = acc;
+    __syncthreads();
+    if (sl != 0) return;
+    double v = part[0][el];
+#pragma unroll
+    for (int t = 1; t < NSL; ++t) v = v + part[t][el];
+    int jb, kb;
+    if (g.strict) sk_tile_unrank_strict(g, g.seq_begin + g.seq_step * tile, jb, kb);
+    else sk_tile_unrank(g, g.seq_begin + g.seq_step * tile, jb, kb);
+    int row, col;
+    sk_acc_pos<TN>(e, r0, row, col);
+    sk_store_term(g, jb, kb, row, col, v);
+}
+
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols) {
     (void)rows; (void)cols;
     return (size_t)MAXG * 2 * SLOT * sizeof(double);
@@ -788,7 +839,9 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #else
         constexpr int apb = 0;
 #endif
-        if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < 64)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        // (tiles split more than 32 ways each — few tiles, many rows: the sliced form)
+        if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R, Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
+        else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < 64)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }

@@ -342,7 +342,15 @@ class Model:
                 eligible = [r for r in records if self._side_lane_ok(r)] if (gram and self._side_lane and not self._small) else []
                 # (and with the overlapped MOI boundary a constraint on the lane is packed early: its terms cross PCIe during the contraction)
                 use_lane = len(eligible) >= 2 or (len(eligible) >= 1 and (self.handoff != "moi" or self._overlap_moi))
-                for r, e in zip(records, emitters):
+                emit_order = list(zip(records, emitters))
+                if self._small and gram:
+                    # a SMALL model: the records are independent of each other, so the one whose MOI copy is not an interpreter node — the
+                    # canonical least-squares objective beyond tiny shapes (gram_tall.hip: two launches) — goes last; the constraints' packs
+                    # then join the run of small entries at the front of the tape (callbacks, residual) in its ONE launch
+                    def is_gram(r):
+                        return getattr(r, "mode", "").startswith("canonical") and r.kind == "quad" and getattr(r.expr, "gram_candidate", None) is not None
+                    emit_order = [re for re in emit_order if not is_gram(re[0])] + [re for re in emit_order if is_gram(re[0])]
+                for r, e in emit_order:
                     side = use_lane and any(r is x for x in eligible)
                     if side:
                         ctx.set_lane(1)
