@@ -167,11 +167,13 @@ int pmt_quad_expand_f64(int64_t rows,
  * (src/functions.jl:381-386 applied to the literal result above), then the MOI copy:
  *   out_quad[tri(j,k)] = (2 * sum_i A[i,j]*A[i,k], vm[xvar[j]], vm[xvar[k]])  for j <= k, row-major upper triangle
  *   out_lin[j]         = (2 * sum_i c_i*A[i,j], vm[xvar[j]])   with c_i = 0.0 (+|-) b[i]
- *   out_const          = sum_i c_i^2, left to right (bit for bit src/functions.jl:574) up to 8192 rows; longer vectors are summed in
- *                        2048 interleaved chains (chain t: rows t, t + 2048, ... in order) whose totals are added left to right —
- *                        a fixed order too, within (rows / 2048 + 2048) * eps / 2 of the exact sum, instead of rows * 25 cycles of
- *                        one dependent chain (15 ms at 10^6 rows).  Tall matrices likewise split the column sums of out_lin into
- *                        row chunks added in chunk order.
+ *   out_const          = sum_i c_i^2 in a FIXED order that (rows, cols) alone determine (pmt_quad_gram_constant_order below): the
+ *                        reference's left-to-right sum (src/functions.jl:574, bit for bit), 2048 interleaved chains, or the fused
+ *                        forms' per-workgroup order — every one within (rows / 2048 + 2048) * eps / 2 of the exact sum.
+ * Shapes of up to 2048 columns take the fused forms of csrc/gram_tall.hip whatever the row count (the triangle of every diagonal
+ * 128-column tile, out_lin and out_const from ONE pass over A; the strictly upper tiles from one stream-K launch); tiny shapes recorded
+ * into a plan are nodes of its one-launch interpreter (csrc/small.hip); wider shapes (config 2) the stream-K node with the two
+ * reductions on a side stream.
  * Requires xvar strictly increasing (distinct variables in sorted order — what Variable(model) yields);
  * moi == 0 keeps native indices (no varmap) but the same coefficients as the MOI form are NOT produced:
  *   native canonical form has diagonal coefficient (A'A)[j,j] and off-diagonal 2*(A'A)[j,k].
@@ -179,12 +181,15 @@ int pmt_quad_expand_f64(int64_t rows,
 size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
 /* The summation order of the node's constant c'c for an r x n problem — fixed by (rows, cols) alone, reported so that a caller (and the
  * parity tests) can restate it:
- *   order 0  sequential, the reference's left-to-right sum (src/functions.jl:574), bit for bit
- *   order 1  `groups` = 2048 interleaved chains (chain t adds rows t, t + 2048, .. in order), chain totals added left to right: rows > 8192,
- *            or a sequential chain that would take half as long as the contraction beside it or longer (few columns; cost model in gram.hip)
- *   order 2  the fused tall form (cols <= 128, rows >= 1024; csrc/gram_tall.hip): `groups` workgroups, workgroup g takes the stages
- *            g, g + groups, .. of `stage_rows` rows; per stage eight row-pair lanes (rows 16 j + 2 p, + 1) add their squares in row order,
- *            an 8-lane tree ((0+4)+(2+6))+((1+5)+(3+7)) closes a workgroup, the workgroups are added in 16 interleaved slices, then the slices
+ *   order 0  sequential, the reference's left-to-right sum (src/functions.jl:574), bit for bit: tiny shapes, and beyond 2048 columns
+ *            where the contraction hides the one-wave chain (config 2)
+ *   order 1  `groups` = 2048 interleaved chains (chain t adds rows t, t + 2048, .. in order), chain totals added left to right: beyond 2048
+ *            columns with rows > 8192, or a sequential chain that would take half as long as the contraction beside it or longer
+ *   order 2  the fused forms (cols <= 2048; csrc/gram_tall.hip): `groups` workgroups, workgroup g takes the stages g, g + groups, .. of
+ *            `stage_rows` rows; per stage eight row-pair lanes (rows 16 j + 2 p, + 1) add their squares in row order, an 8-lane tree
+ *            ((0+4)+(2+6))+((1+5)+(3+7)) closes a workgroup, the workgroups are added in 16 interleaved slices, then the slices
+ *   order 3  the same with SIXTEEN row-pair lanes (rows 32 j + 2 p, + 1; a 16-lane tree): the 16-column panel, cols <= 16
+ * (tests/gpu_util.py restates every order bit for bit.)
  * Every order is within (rows / 2048 + 2048) * eps / 2 relative of the exact sum for same-signed terms: far inside the 1e-12 parity bar. */
 int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows);
 int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
