@@ -406,12 +406,12 @@ def config_c1(torch, P, _lib, steps=400):
     return out
 
 
-TALL_SHAPES = ((1 << 20, 128), (262144, 512), (65536, 1024), (8192, 128))
+TALL_SHAPES = [(1 << 20, 128), (262144, 512), (65536, 1024), (8192, 128), (1 << 20, 16), (1 << 20, 64), (4096, 512), (100, 100)]
 
 
 def config_tall(torch, _lib, steps=20):
-    """The Gram node (pmt_quad_gram_f64: Q, q, constant) on tall least-squares shapes — rows >> columns, the usual shape of README.md:34-38
-    with real data.  Per shape: node time, the algorithmic flops r n (n + 1) against the f64 MFMA peak and the algorithmic bytes
+    """The Gram node (pmt_quad_gram_f64: Q, q, constant) on the shapes beside config 2 — tall (rows >> columns, the usual shape of
+    README.md:34-38 with real data), narrow, mid-size and the reference's own sizes.  Per shape: node time, the algorithmic flops r n (n + 1) against the f64 MFMA peak and the algorithmic bytes
     (8 r n read + 24 n (n + 1) / 2 written) against HBM; `binding` names the roofline whose algorithmic time is longer."""
     dev = torch.device("cuda", torch.cuda.current_device())
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -440,7 +440,9 @@ def config_tall(torch, _lib, steps=20):
         _lib.call("pmt_profile_enable", 0)
         flops, nbytes = float(r) * n * (n + 1), 8.0 * r * n + 24.0 * nq
         t_mfma, t_hbm = flops / (F64_MFMA_PEAK_TFLOPS * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
-        out["%dx%d" % (r, n)] = {"node_ms": t * 1e3, "mfma_frac": t_mfma / t, "hbm_frac": t_hbm / t, "binding": "mfma" if t_mfma >= t_hbm else "hbm",
+        # (a node whose algorithmic time on BOTH rooflines is under 5 us is bound by its launches: two or four kernels, ~6 us each in-stream)
+        binding = "launch latency" if max(t_mfma, t_hbm) < 5e-6 else ("mfma" if t_mfma >= t_hbm else "hbm")
+        out["%dx%d" % (r, n)] = {"node_ms": t * 1e3, "mfma_frac": t_mfma / t, "hbm_frac": t_hbm / t, "binding": binding, "launches": len(kern),
                                  "frac": max(t_mfma, t_hbm) / t, "tflops": flops / t / 1e12, "A_TBps": 8.0 * r * n / t / 1e12, "kernels_ms": kern}
         del A, b, Q, q, ws
     return out
@@ -1130,7 +1132,10 @@ def summary_of(out):
         "pack_in_step_frac": _get(pack, "in_step", "device_clock", "frac") or _get(pack, "in_step", "rocprofv3", "frac") or _get(pack, "in_step", "hip_events", "frac"),
         "pack_in_step_frac_rocprof_replayed": _get(pack, "in_step", "rocprofv3_replayed", "frac"),
         "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
-        "tall_frac": {k: round(v["frac"], 3) for k, v in (c.get("tall") or {}).items() if isinstance(v, dict) and "frac" in v} or None,
+        "tall_frac": {k: round(v["frac"], 3) for k, v in (c.get("tall") or {}).items()
+                      if isinstance(v, dict) and "frac" in v and v.get("binding") != "launch latency"} or None,
+        "node_us_launch_bound": {k: round(v["node_ms"] * 1e3, 1) for k, v in (c.get("tall") or {}).items()
+                                 if isinstance(v, dict) and v.get("binding") == "launch latency"} or None,
         "affine_warm_frac": _get(out, "roofline_affine", "frac"), "affine_cold_frac": _get(out, "roofline_affine", "cold", "frac"),
         "cpu_baseline_value": _get(out, "cpu_baseline", "value"), "ranks_seen": out.get("ranks_seen"),
     }

@@ -108,6 +108,31 @@ struct TallArgs {
     int vec_in;                           // A 16-byte aligned and lda even
 };
 
+// PMT_TALL_DPP (off; an experiment kept as a knob): the B operand of the r-th rotation of a 16 x 16 block is the value that the lane 4 r
+// further up its 16-lane row holds for r = 0 (column group (b + r) & 3 instead of b), and the r = 0 value of block column t IS the A
+// operand of block row t — so ONE LDS read per block column and k-step would do, the rotations being DPP row rotations (row_ror) of it:
+// NB reads instead of 5 NB.  Correct, and SLOWER (2^20 rows; 16 / 32 / 64 columns: 34 -> 36, 65 -> 74, 157 -> 171 us): two v_mov_dpp per
+// rotated double in the issue stream of the wave that also issues the MFMAs cost more than the LDS reads they replace, which the LDS
+// pipe serves beside the matrix pipe.  profiles/r05_gram_shapes.txt.
+#ifndef PMT_TALL_DPP
+#define PMT_TALL_DPP 0
+#endif
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffLL), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// value of the lane (lane + 4 r) mod 16 of the same row: row_ror by 16 - 4 r
+template <int R>
+__device__ __forceinline__ double rot_blocks(double v) {
+    if (R == 0) return v;
+    if (R == 1) return dpp_row<0x12C>(v);
+    if (R == 2) return dpp_row<0x128>(v);
+    return dpp_row<0x124>(v);
+}
+
 // one stage of one wave from the panel in LDS (`panel` already points at this lane's k offset).
 // PMT_TALL_K2: the MFMA's contraction slot k = lane >> 4 of k-steps 2j and 2j + 1 is given the ADJACENT rows 8j + 2k and 8j + 2k + 1 (any
 // assignment of rows to slots is a valid contraction as long as both operands use it), so ONE 16-byte LDS read per operand serves two
@@ -520,11 +545,15 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
             double bv[4];
+#if PMT_TALL_DPP
+            bv[0] = a[c]; bv[1] = rot_blocks<1>(a[c]); bv[2] = rot_blocks<2>(a[c]); bv[3] = rot_blocks<3>(a[c]);
+#else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);
                 bv[r] = panel[(c * 16 + rc) * N::PITCH + ks * 4];
             }
+#endif
 #pragma unroll
             for (int tm = 0; tm <= c; ++tm)
 #pragma unroll
