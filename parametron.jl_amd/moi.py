@@ -193,10 +193,20 @@ class _Record:
         self.varmap_hooks = []                                            # called with the new host varmap whenever it changes
         self.side_lane_ok = False
         self.on_side_lane = False
+        # A SMALL model (Model.initialize: launch-bound on the device) has no device twin of its MOI buffers: the kernels store straight into
+        # the page-locked host arrays of the function object (a few KB over PCIe from inside the one launch), and update! ends with ONE stream
+        # synchronisation instead of a D2H copy per buffer (~10 us each: five of them were half of solve! at n = 100)
+        zero_copy = bool(getattr(self.model, "_small", False))
+
+        def twin(host, nbytes):
+            if zero_copy and nbytes > 0 and host.nbytes >= nbytes:
+                return host.ctypes.data
+            return ctx.alloc(max(nbytes, 16))
+        self._cbuf = ctx.pinned_array(1, np.float64)                      # the scalar functions' constant lands here
         if self.kind == "aff":
             n = out.nterms
             self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
-            dev_terms = ctx.alloc(16 * max(n, 1))
+            dev_terms = twin(self.f.terms, 16 * n)
             self.dev = {"terms": dev_terms, "const": out.const}
 
             def emit(c):
@@ -235,7 +245,7 @@ class _Record:
                 n = gram.mat.cols
                 nq = n * (n + 1) // 2
                 self.f = ScalarQuadraticFunction(n, nq, alloc=ctx.pinned_array)
-                dq, dl, dc = ctx.alloc(24 * max(nq, 1)), ctx.alloc(16 * max(n, 1)), ctx.alloc(8)
+                dq, dl, dc = twin(self.f.quadratic_terms, 24 * nq), twin(self.f.affine_terms, 16 * n), twin(self._cbuf, 8)
                 ws = ctx.alloc(max(16, int(ctx.lib.pmt_quad_gram_workspace_bytes(_gram_rows(gram), n))))
                 self.dev = {"quad": dq, "lin": dl, "const": dc}
                 self.mode = "canonical"
@@ -256,7 +266,7 @@ class _Record:
             self.mode = "literal"
             out.materialize()
             self.f = ScalarQuadraticFunction(out.nl, out.nq, alloc=ctx.pinned_array)
-            dq, dl = ctx.alloc(24 * max(out.nq, 1)), ctx.alloc(16 * max(out.nl, 1))
+            dq, dl = twin(self.f.quadratic_terms, 24 * out.nq), twin(self.f.affine_terms, 16 * out.nl)
             self.dev = {"quad": dq, "lin": dl, "const": out.const}
 
             def emit(c):
@@ -292,9 +302,9 @@ class _Record:
                         c.call("pmt_consts_f64", P(out.vec.buf), out.rows, out.sign, P(dc))
                 return emit
         self.f = VectorAffineFunction(out.nterms, out.rows, alloc=ctx.pinned_array)
-        dt = ctx.alloc(24 * max(out.nterms, 1))
+        dt = twin(self.f._terms, 24 * out.nterms)
         if isinstance(out, DDenseAff) and not out.need_terms:
-            dc = ctx.alloc(8 * max(out.rows, 1))
+            dc = twin(self.f.constants, 8 * out.rows)
             self.dev = {"terms": dt, "consts": dc}
             self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
             vec = out.vec.buf if out.vec is not None else None
@@ -306,7 +316,7 @@ class _Record:
                        out.mat.rows, out.mat.cols, P(out.xvars.buf), P(vec), out.sign if vec else 0, P(varmap_buf), 0, P(dt), P(dc))
             return emit
         if isinstance(out, DVarsAff) and not out.need_terms:
-            dc = ctx.alloc(8 * max(out.rows, 1))
+            dc = twin(self.f.constants, 8 * out.rows)
             self.dev = {"terms": dt, "consts": dc}
             self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
 
@@ -314,7 +324,7 @@ class _Record:
                 c.call("pmt_vars_addsub_f64", P(out.xvars.buf), out.rows, P(out.vec.buf), out.sign, P(varmap_buf), 0, None, P(dt), P(dc))
             return emit
         if isinstance(out, DSparseAff) and not out.need_terms:
-            dc = ctx.alloc(8 * max(out.rows, 1))
+            dc = twin(self.f.constants, 8 * out.rows)
             self.dev = {"terms": dt, "consts": dc}
             self.side_lane_ok = True          # reads Parameter values only, writes its own MOI buffers (Model.initialize: side lane)
             sp = out.spmat
@@ -383,22 +393,25 @@ class _Record:
         self._fetch_recorded = True
 
     def fetch(self, ctx):
-        """D2H of the MOI buffers into the host function object (asynchronous; caller synchronises)."""
+        """D2H of the MOI buffers into the host function object (asynchronous; caller synchronises).  A buffer whose device twin IS the
+        host array (a small model, compile) needs no copy."""
         if getattr(self, "_fetch_recorded", False):
             return
         f, d = self.f, self.dev
+
+        def get(host, key):
+            if key in d and d[key] != host.ctypes.data:
+                ctx.fetch(host, d[key], host.nbytes)
         if self.kind == "aff":
-            ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
-            self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
+            get(f.terms, "terms")
+            self._c = self._cbuf; get(self._c, "const")
         elif self.kind == "quad":
-            if "quad" in d:                                               # absent when P's CSC values are written directly
-                ctx.fetch(f.quadratic_terms, d["quad"], f.quadratic_terms.nbytes)
-            ctx.fetch(f.affine_terms, d["lin"], f.affine_terms.nbytes)
-            self._c = np.empty(1); ctx.fetch(self._c, d["const"], 8)
+            get(f.quadratic_terms, "quad")                                # (absent when P's CSC values are written directly)
+            get(f.affine_terms, "lin")
+            self._c = self._cbuf; get(self._c, "const")
         else:
-            if "terms" in d:                                              # absent for a host_csc record whose terms are static (compile)
-                ctx.fetch(f.terms, d["terms"], f.terms.nbytes)
-            ctx.fetch(f.constants, d["consts"], f.constants.nbytes)
+            get(f._terms, "terms")                                        # (absent for a host_csc record whose terms are static, compile)
+            get(f.constants, "consts")
 
     def finish_fetch(self):
         if self.kind in ("aff", "quad"):
