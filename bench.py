@@ -400,6 +400,16 @@ def config_c1(torch, P, _lib, steps=400):
     ctx.set_fusion(False)
     out["unfused"] = {"update_us": wall(upd, steps), "plan_update_us": wall(ctx.replay, steps), "kernel_us": kernel_us(), "launches": ctx.fused()["exec_length"]}
     ctx.set_fusion(True)
+    # the whole solve!(model) through the Python host with a do-nothing optimizer and the results ON THE HOST at the end (callbacks, one
+    # launch whose kernels store the MOI buffers into the function objects' page-locked arrays, one synchronisation, MOI.set calls)
+    def solve_wall(k):
+        for _ in range(30):
+            P.solve(model)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            P.solve(model)
+        return (time.perf_counter() - t0) / k * 1e6
+    out["solve_us_python_host_mock_optimizer"] = solve_wall(steps)
     out["reference"] = {"solve_us_incl_osqp": 51.863, "update_us_estimate": 15.0,
                         "source": "README.md:132-136 (BenchmarkTools median of solve!, other hardware); the update! share per BASELINE.md section 1"}
     model.close()
@@ -1131,7 +1141,7 @@ def summary_of(out):
         # measured in this run only: the device-clock figure, else the HIP-event lower bound; the replay of a committed profile has its own key
         "pack_in_step_frac": _get(pack, "in_step", "device_clock", "frac") or _get(pack, "in_step", "rocprofv3", "frac") or _get(pack, "in_step", "hip_events", "frac"),
         "pack_in_step_frac_rocprof_replayed": _get(pack, "in_step", "rocprofv3_replayed", "frac"),
-        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
+        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"), "C1_solve_us": _get(c, "C1", "solve_us_python_host_mock_optimizer"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
         "tall_frac": {k: round(v["frac"], 3) for k, v in (c.get("tall") or {}).items()
                       if isinstance(v, dict) and "frac" in v and v.get("binding") != "launch latency"} or None,
         "node_us_launch_bound": {k: round(v["node_ms"] * 1e3, 1) for k, v in (c.get("tall") or {}).items()
