@@ -382,3 +382,46 @@ def test_host_callbacks_of_a_small_model_travel_through_mailboxes():
     P.profile_enable(False)
     assert list(rep) == ["small_plan_kernel"], rep
     model.close()
+
+
+def test_small_model_with_several_constraints_follows_every_update():
+    """A small model whose constraints are built straight from host-updated Parameters (the records a large model puts on the plan's side
+    lane): its Parameter values arrive through mailbox copies at the FRONT of the tape, so every record stays on the plan's own lane, in the
+    one-launch run, behind those copies — and what the function objects hold after each solve! (stored by the kernels into their page-locked
+    arrays: no device twin, no D2H copy) is THIS solve's data, checked against numpy on the host buffers.  (With the constraints on the
+    side lane they forked at the top of the replay, in front of the copies: stale by one solve whenever the objective's node was fast.)"""
+    import parametron_jl_amd as P
+    rng = np.random.default_rng(9)
+    n, r, m = 60, 90, 12
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    x = [P.Variable(model) for _ in range(n)]
+    bufs = {"A": np.zeros((r, n), order="F"), "b": np.zeros(r), "G": np.zeros((m, n), order="F"), "h": np.zeros(m), "l": np.zeros(n)}
+    A, b, G, h, lo = (P.Parameter(model, val=bufs[k]) for k in ("A", "b", "G", "h", "l"))
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    cG = P.constraint(model, G * x, "<=", h)
+    cl = P.constraint(model, x, ">=", lo)
+    P.solve(model)
+    assert model._small and not getattr(model, "_lane_records", [])
+    fz = model.device().fused()
+    assert fz["groups"] == 1 and fz["exec_length"] == 2, fz            # the run of small entries + the objective's node (emitted last)
+    recs = sorted((c for c in model.constraints), key=lambda c: len(c.f.constants))
+    assert [len(c.f.constants) for c in recs] == [m, n]
+    for rec in list(recs) + [model.objective]:                           # no device twin: the "device" address of every MOI buffer is the host array
+        for key, host in (("terms", getattr(rec.f, "_terms", None)), ("consts", getattr(rec.f, "constants", None)),
+                          ("quad", getattr(rec.f, "quadratic_terms", None)), ("lin", getattr(rec.f, "affine_terms", None))):
+            if host is not None and key in rec.dev:
+                assert rec.dev[key] == host.ctypes.data, (type(rec.f).__name__, key)
+    for it in range(25):
+        for v in bufs.values():
+            v[...] = rng.random(v.shape)
+        P.solve(model)
+        f = model.objective.f
+        iu = np.triu_indices(n)
+        np.testing.assert_allclose(f.quadratic_terms["coeff"], (2 * bufs["A"].T @ bufs["A"])[iu], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(f.affine_terms["coeff"], -2 * bufs["A"].T @ bufs["b"], rtol=1e-12, atol=0)
+        assert f.constant == pytest.approx(bufs["b"] @ bufs["b"], rel=1e-13)
+        assert np.array_equal(recs[0].f.constants, 0.0 - bufs["h"]) and np.array_equal(recs[1].f.constants, 0.0 - bufs["l"])
+        t = recs[0].f.terms                                              # VectorAffineTerms of G x: row-major (src/moi_interop.jl:64-81)
+        assert np.array_equal(t["coeff"].reshape(m, n), bufs["G"]) and np.all(recs[1].f.terms["coeff"] == 1.0)
+    model.close()

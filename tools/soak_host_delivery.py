@@ -80,5 +80,34 @@ for it in range(N):
             print("MISMATCH config-3 shape solve %d: A / u do not follow the host buffers" % it, flush=True)
 model.close()
 print("config-3 shape: %d solves checked in %.1f s" % (N, time.perf_counter() - t0), flush=True)
+# a SMALL model (one-launch plan): host-updated Parameters through mailboxes, MOI buffers stored by the kernels straight into the function
+# objects' page-locked arrays — every solve's results must be THIS solve's values (a stale mailbox / an early read shows up at once)
+t0 = time.perf_counter()
+n, r, m = 60, 90, 12
+model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+x = [P.Variable(model) for _ in range(n)]
+bufs = {"A": np.zeros((r, n), order="F"), "b": np.zeros(r), "G": np.zeros((m, n), order="F"), "h": np.zeros(m), "l": np.zeros(n)}
+A, b, G, h, lo = (P.Parameter(model, val=bufs[k]) for k in ("A", "b", "G", "h", "l"))
+res = A * x - b
+P.objective(model, P.Minimize, P.dot(res, res))
+P.constraint(model, G * x, "<=", h)
+P.constraint(model, x, ">=", lo)
+P.solve(model)
+assert getattr(model, "_small", False)
+for it in range(N):
+    for v in bufs.values():
+        v[...] = rng.random(v.shape)
+    P.solve(model)
+    f = model.objective.f
+    cs = sorted(model.constraints, key=lambda c: len(c.f.constants))        # (G x <= h: 12 rows, x >= l: 60 rows)
+    oks = (np.allclose(f.affine_terms["coeff"], -2 * bufs["A"].T @ bufs["b"], rtol=1e-12, atol=0), abs(f.constant - bufs["b"] @ bufs["b"]) <= 1e-12 * f.constant,
+           np.array_equal(cs[0].f.constants, 0.0 - bufs["h"]), np.array_equal(cs[1].f.constants, 0.0 - bufs["l"]),
+           np.array_equal(np.sort(cs[0].f.terms["coeff"]), np.sort(bufs["G"].reshape(-1))))
+    if not all(oks):
+        bad += 1
+        if bad < 6:
+            print("MISMATCH small model solve %d: q %s const %s -h %s -l %s G %s" % ((it,) + oks), flush=True)
+model.close()
+print("small model: %d solves checked in %.1f s" % (N, time.perf_counter() - t0), flush=True)
 print("soak: %d mismatches" % bad, flush=True)
 sys.exit(1 if bad else 0)
