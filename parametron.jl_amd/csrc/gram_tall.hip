@@ -354,101 +354,6 @@ __global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g
     else tall_body<3, FAST>(g, lds, tid);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// WAVE-SPECIALISED form (PMT_TALL_WS): the same workgroup's work split by ROLE over eight waves — waves 0..3 only run the MFMA stream of
-// their nine blocks (consumers), waves 4..7 only move the panel (producers: global -> registers -> LDS, q and c'c on the VALU on the
-// way) — one barrier per stage for all eight.  In the four-wave form a wave's register -> LDS phase and its matrix phase alternate, and
-// the two workgroups of a CU fall into step (memory side alone 0.264 ms, matrix side alone 0.334 ms, together 0.39 ms at 2^20 x 128); here
-// the producers' phase of stage s + 1 runs beside the consumers' MFMAs of stage s on the same SIMDs.  Same stage order, same per-thread
-// sums, same partial layout: bit-identical results.
-#ifndef PMT_TALL_WS
-#define PMT_TALL_WS 0
-#endif
-#ifndef PMT_TALL_WS_WPS
-#define PMT_TALL_WS_WPS 4          // waves per SIMD the register budget aims at (4: two 8-wave workgroups per CU, 128 registers)
-#endif
-
-struct TallSpan { int64_t sbeg, sstep; int nstage; };
-__device__ __forceinline__ TallSpan tall_span(const TallArgs &g) {
-    const int64_t G = gridDim.x, bid = blockIdx.x;
-    TallSpan t;
-    t.sbeg = g.interleave ? bid : bid * g.chunk;
-    t.sstep = g.interleave ? G : 1;
-    t.nstage = (int)(g.interleave ? (g.nstages > bid ? (g.nstages - bid + G - 1) / G : 0) : max((int64_t)0, min(g.chunk, g.nstages - t.sbeg)));
-    return t;
-}
-
-template <int W>
-__device__ __forceinline__ void tall_consumer(const TallArgs &g, double (&lds)[2][TCOLS * TGP], int tid) {
-    const int lane = tid & 63;
-    const int lm = lane & 15, lk = lane >> 4;
-    const TallSpan sp = tall_span(g);
-    double acc[TACC];
-#pragma unroll
-    for (int r = 0; r < TACC; ++r) acc[r] = 0.0;
-    __syncthreads();                                   // stage 0 is in LDS
-    for (int s = 0; s < sp.nstage; ++s) {
-        tall_stage<W>(lds[s & 1] + TLK * lk, lm, acc);
-        __syncthreads();                               // stage s + 1 is in LDS, stage s may be overwritten
-    }
-    double *w = g.ws + (int64_t)blockIdx.x * TSTRIDE;
-#pragma unroll
-    for (int r = 0; r < TACC; ++r) w[(W * TACC + r) * 64 + lane] = acc[r];
-}
-
-template <bool FAST>
-__device__ __forceinline__ void tall_producer(const TallArgs &g, double (&lds)[2][TCOLS * TGP], int ptid) {
-    const int kp = ptid & 7, cc = ptid >> 3;
-    const TallSpan sp = tall_span(g);
-    const int64_t rend = g.rows;
-    double qacc[4] = {0.0, 0.0, 0.0, 0.0}, cacc = 0.0;
-    auto stage_row = [&](int s) { return (sp.sbeg + (int64_t)s * sp.sstep) * TBK; };
-    f64x2 reg[4][TSUB], cv[TSUB];
-    if (sp.nstage > 0) {
-        tall_load<FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
-        tall_store(lds[0], reg, cv, g.sign, kp, cc, qacc, cacc);
-    }
-    if (sp.nstage > 1) tall_load<FAST>(g, stage_row(1), rend, kp, cc, reg, cv);
-    __syncthreads();
-    for (int s = 0; s < sp.nstage; ++s) {
-        if (s + 1 < sp.nstage) tall_store(lds[(s + 1) & 1], reg, cv, g.sign, kp, cc, qacc, cacc);
-        if (s + 2 < sp.nstage) tall_load<FAST>(g, stage_row(s + 2), rend, kp, cc, reg, cv);
-        __syncthreads();
-    }
-    double *w = g.ws + (int64_t)blockIdx.x * TSTRIDE;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        double v = qacc[p];
-        v = v + __shfl_down(v, 4, 8);
-        v = v + __shfl_down(v, 2, 8);
-        v = v + __shfl_down(v, 1, 8);
-        if (kp == 0) w[TPART + cc + 32 * p] = v;
-    }
-    if (ptid < 64) {
-        double v = cacc;
-        v = v + __shfl_down(v, 4, 8);
-        v = v + __shfl_down(v, 2, 8);
-        v = v + __shfl_down(v, 1, 8);
-        if (ptid == 0) w[TPART + TCOLS] = v;
-    }
-}
-
-template <bool FAST>
-__global__ __launch_bounds__(512, PMT_TALL_WS_WPS) void gram_tall_ws_kernel(TallArgs g) {
-    __shared__ double lds[2][TCOLS * TGP];
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t tile = blockIdx.y;
-    g.A += tile * TCOLS * g.lda;
-    g.cols = min((int64_t)TCOLS, g.cols - tile * TCOLS);
-    g.ws += tile * (int64_t)gridDim.x * TSTRIDE;
-    if (wave == 0) tall_consumer<0>(g, lds, tid);
-    else if (wave == 1) tall_consumer<1>(g, lds, tid);
-    else if (wave == 2) tall_consumer<2>(g, lds, tid);
-    else if (wave == 3) tall_consumer<3>(g, lds, tid);
-    else tall_producer<FAST>(g, lds, tid - 256);
-}
-
 struct TallFixArgs {
     const double *ws; int G;
     int nb;                               // 0: the 36-block layout of gram_tall_kernel; NB > 0: gram_narrow_kernel<NB>'s (blocks in packed upper order)
@@ -629,10 +534,10 @@ __device__ __forceinline__ void narrow_store(double *__restrict__ panel, const f
 }
 
 // this wave's quarter of a stage: every block, KSTEPS k-steps (`panel` points at the wave's first row + this lane's k offset)
-template <int NB, int UNR = 64>
+template <int NB>
 __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, int lm, double (&acc)[Narrow<NB>::NACC]) {
     using N = Narrow<NB>;
-#pragma unroll UNR
+#pragma unroll
     for (int ks = 0; ks < N::KSTEPS; ++ks) {
         double a[NB];
 #pragma unroll
@@ -738,83 +643,6 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
     }
 }
 
-// the wave-specialised form of the narrow kernel (PMT_NARROW_WS; see gram_tall_ws_kernel): waves 0..3 take the MFMAs of their quarter
-// of every stage, waves 4..7 move the panel and carry q and c'c
-#ifndef PMT_NARROW_WS
-#define PMT_NARROW_WS 1
-#endif
-template <int NB, bool FAST>
-__global__ __launch_bounds__(512, 4) void gram_narrow_ws_kernel(TallArgs g) {
-    using N = Narrow<NB>;
-    __shared__ double lds[2][N::C * N::PITCH];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t G = gridDim.x, bid = blockIdx.x;
-    const int nstage = (int)(g.nstages > bid ? (g.nstages - bid + G - 1) / G : 0);
-    auto stage_row = [&](int s) { return (bid + (int64_t)s * G) * N::R; };
-    double *w = g.ws + (int64_t)blockIdx.x * N::STRIDE;
-    if (wave < 4) {
-        const int lm = lane & 15, lk = lane >> 4;
-        double acc[N::NACC];
-#pragma unroll
-        for (int r = 0; r < N::NACC; ++r) acc[r] = 0.0;
-        __syncthreads();
-        for (int s = 0; s < nstage; ++s) {
-            narrow_stage<NB, (NB == 2 ? 2 : 64)>(lds[s & 1] + wave * (N::R / 4) + lk, lm, acc);
-            __syncthreads();
-        }
-        double *red = &lds[0][0];
-        if (wave > 0) {
-#pragma unroll
-            for (int r = 0; r < N::NACC; ++r) red[((wave - 1) * N::NACC + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int r = 0; r < N::NACC; ++r) {
-                double v = acc[r];
-                v = v + red[(0 * N::NACC + r) * 64 + lane];
-                v = v + red[(1 * N::NACC + r) * 64 + lane];
-                v = v + red[(2 * N::NACC + r) * 64 + lane];
-                w[r * 64 + lane] = v;
-            }
-        }
-    } else {
-        const int ptid = tid - 256;
-        const int kp = ptid % N::LPC, cc = ptid / N::LPC;
-        const int64_t rend = g.rows;
-        double qacc[N::NQ], cacc = 0.0;
-#pragma unroll
-        for (int q = 0; q < N::NQ; ++q) qacc[q] = 0.0;
-        f64x2 reg[N::NQ][N::NJ], cv[N::NJ];
-        if (nstage > 0) {
-            narrow_load<NB, FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
-            narrow_store<NB>(lds[0], reg, cv, g.sign, kp, cc, qacc, cacc);
-        }
-        if (nstage > 1) narrow_load<NB, FAST>(g, stage_row(1), rend, kp, cc, reg, cv);
-        __syncthreads();
-        for (int s = 0; s < nstage; ++s) {
-            if (s + 1 < nstage) narrow_store<NB>(lds[(s + 1) & 1], reg, cv, g.sign, kp, cc, qacc, cacc);
-            if (s + 2 < nstage) narrow_load<NB, FAST>(g, stage_row(s + 2), rend, kp, cc, reg, cv);
-            __syncthreads();
-        }
-        __syncthreads();                               // (the consumers' fold through the panels)
-#pragma unroll
-        for (int q = 0; q < N::NQ; ++q) {
-            double v = qacc[q];
-#pragma unroll
-            for (int h = N::LPC / 2; h >= 1; h >>= 1) v = v + __shfl_down(v, h, N::LPC);
-            if (kp == 0) w[N::PART + cc + N::NCC * q] = v;
-        }
-        if (ptid < 64) {
-            double v = cacc;
-#pragma unroll
-            for (int h = N::LPC / 2; h >= 1; h >>= 1) v = v + __shfl_down(v, h, N::LPC);
-            if (ptid == 0) w[N::PART + N::C] = v;
-        }
-    }
-}
-
 static int narrow_nb(int64_t cols) { return cols <= 16 ? 1 : cols <= 32 ? 2 : cols <= 64 ? 4 : 0; }
 static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ? Narrow<2>::R : Narrow<4>::R; }
 static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
@@ -829,17 +657,8 @@ static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStre
     g.nstages = cdiv(g.rows, N::R);
     const int G = narrow_groups(g.rows, NB);
     const bool fast = g.vec_in && g.cols == N::C && g.rows % N::R == 0 && b_aligned;
-#if PMT_NARROW_WS
-    if (NB <= 2) {                // (64 columns: 40 accumulators + 20 operands per k-step do not fit the 128 registers of two 8-wave workgroups per CU)
-        constexpr int WB = NB <= 2 ? NB : 1;
-        if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_ws_kernel<WB, true>), dim3((unsigned)G), dim3(512), 0, s, g);
-        else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_ws_kernel<WB, false>), dim3((unsigned)G), dim3(512), 0, s, g);
-    } else if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
-#else
     if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
     else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
-#endif
     if (int rc = check_launch("gram_narrow_kernel")) return rc;
     f.G = G; f.nb = NB; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
@@ -917,13 +736,8 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     const unsigned nt = (unsigned)cdiv(cols, TCOLS);
     // whole stages, whole panels, aligned pieces (of A and of b): no bounds checks
     const bool fast = g.vec_in && cols % TCOLS == 0 && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
-#if PMT_TALL_WS
-    if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_ws_kernel<true>, dim3((unsigned)G, nt), dim3(512), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_ws_kernel<false>, dim3((unsigned)G, nt), dim3(512), 0, s, g);
-#else
     if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
     else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
-#endif
     if (int rc = check_launch("gram_tall_kernel")) return rc;
     f.G = G; f.nb = 0; f.part = TPART; f.pcols = TCOLS; f.stride = TSTRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64), nt), dim3(1024), 0, s, f);
