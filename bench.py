@@ -1023,7 +1023,7 @@ def main():
             "step_algorithmic_bytes": wl.step_bytes(), "step_flops": wl.gram_flops(), "ranks_seen": ranks_seen,
         }
         g = kernels.get("gram_sk_kernel")
-        out["roofline"] = mfma_roofline("gram_sk_kernel", g["avg_ms"], wl.gram_flops(), "pmt::gram_sk_kernel") if g else None
+        out["roofline"] = mfma_roofline("gram_sk_kernel", g["avg_ms"], wl.gram_flops(), "pmt::gram_sk_kernel<2, 16, 2, 0, false>") if g else None
         v = kernels.get("affine_tile_kernel<VAT>")
         bg = kernels.get("affine_pack_background_kernel")
         if v:

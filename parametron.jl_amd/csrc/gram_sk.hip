@@ -840,7 +840,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         constexpr int apb = 0;
 #endif
         // (tiles split more than 32 ways each — few tiles, many rows: the sliced form)
-        if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R, Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
+        if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_sliced_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R, Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
         else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < 64)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");

@@ -21,10 +21,20 @@ for r in csv.DictReader(open(glob.glob(out + "/pmc_fetch/*/*counter_collection.c
 for r in csv.DictReader(open(glob.glob(out + "/pmc_write/*/*counter_collection.csv")[0])):
     w[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
 res = {"_note": "per-launch HBM-side bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); FETCH_SIZE x2 (gfx950 correction) x1024, "
-                "WRITE_SIZE x1024; `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; tag " + out}
+                "WRITE_SIZE x1024; `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; per kernel the launches of its largest workload; tag " + out}
+# a kernel is launched at several sizes in one bench process (the configurations, the small model of config 1, the shapes of `tall`): the
+# record is the average over the launches of the LARGEST workload (per-launch read + write within a factor two of the maximum; both
+# passes run the same launches in the same order)
 for k in f:
     if "pmt::" in k and k in w:
-        res[k] = {"read_bytes": 2 * 1024 * sum(f[k]) / len(f[k]), "write_bytes": 1024 * sum(w[k]) / len(w[k]), "launches": len(f[k])}
+        rd, wr = [2 * 1024 * v for v in f[k]], [1024 * v for v in w[k]]
+        if len(rd) == len(wr):
+            tot = [a + b for a, b in zip(rd, wr)]
+            keep = [i for i, t in enumerate(tot) if t >= 0.5 * max(tot)] or list(range(len(tot)))
+        else:
+            keep = None
+        sel = (lambda x: [x[i] for i in keep]) if keep is not None else (lambda x: x)
+        res[k] = {"read_bytes": sum(sel(rd)) / len(sel(rd)), "write_bytes": sum(sel(wr)) / len(sel(wr)), "launches": len(sel(rd)), "launches_in_process": len(rd)}
 json.dump(res, open(out + "/pmc_traffic.json", "w"), indent=1)
 # per-launch durations of the timed region only (the stats CSV averages over spin-up and warm-up launches too)
 tr = sorted(csv.DictReader(open(glob.glob(out + "/stats/*/*kernel_trace.csv")[0])), key=lambda r: int(r["Start_Timestamp"]))
