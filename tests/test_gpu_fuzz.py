@@ -56,6 +56,44 @@ def test_gram_node_random_shapes(rows, n):
     assert g.same_bits(g.f64_to_host(px, nq), want)
 
 
+@pytest.mark.parametrize("rows,n", [(1, 1), (3, 16), (70, 7), (700, 9), (2049, 16), (100, 17), (1000, 32), (515, 33), (4097, 64), (31, 65), (640, 128),
+                                    (33, 129), (2000, 200), (130, 600), (64, 2048), (50, 2049)])
+@pytest.mark.parametrize("moi", [0, 1])
+def test_gram_node_without_affine_part_and_in_native_form(rows, n, moi):
+    """b = null / sign = 0 (the objective (A x) . (A x): q = 0, constant = 0) and the NATIVE canonical form (moi = 0: diagonal coefficient
+    (A'A)_jj, off-diagonal 2 (A'A)_jk, model variable indices) across the node's forms — tiny, the 16 / 32 / 64-column panels, one tile,
+    diagonal tiles + strict stream-K up to 2048 columns, the stream-K node beyond — with 8-byte misaligned and odd-pitched A"""
+    import gpu_util as g
+    rng = np.random.default_rng(rows * 31 + n + moi)
+    lda = rows + int(rng.integers(0, 4))
+    shift = int(rng.integers(0, 2))
+    A = rng.random((rows, n)) - 0.3
+    buf = np.zeros(shift + lda * n)
+    buf[shift:].reshape(n, lda)[:, :rows] = A.T
+    dbuf = g.to_dev(buf)
+    dA = dbuf[shift:]
+    xv = np.cumsum(rng.integers(1, 4, size=n)).astype(np.int64)             # strictly increasing, with gaps
+    vm_h = rng.permutation(int(xv[-1])).astype(np.int64) + 1
+    xvar, vm = g.to_dev(xv), g.to_dev(vm_h)
+    nq = n * (n + 1) // 2
+    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    ws = g.empty_f64(max(1, g.lib().pmt_quad_gram_workspace_bytes(rows, n) // 8))
+    g.call("pmt_quad_gram_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), None, 0, moi, g.ptr(vm) if moi else None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws),
+           g.stream())
+    q, l = g.terms_to_host(oq, nq, g.QT), g.terms_to_host(ol, n, g.LT)
+    iu = np.triu_indices(n)
+    G = A.T @ A
+    want = 2 * G[iu]
+    if not moi:
+        want = np.where(iu[0] == iu[1], G[iu], want)
+    idx = (lambda v: vm_h[v - 1]) if moi else (lambda v: v)
+    assert np.array_equal(q["row"], idx(xv[iu[0]])) and np.array_equal(q["col"], idx(xv[iu[1]]))
+    scale = 2 * (np.abs(A).T @ np.abs(A))[iu]
+    assert np.all(np.abs(q["coeff"] - want) <= 1e-12 * scale + 1e-300)
+    assert np.array_equal(l["var"], idx(xv)) and np.all(l["coeff"] == 0.0)
+    assert g.f64_to_host(oc, 1)[0] == 0.0
+
+
 @pytest.mark.parametrize("rows,n", _shapes(12, 20, 300, 300))
 def test_affine_nodes_random_shapes(rows, n):
     import gpu_util as g
