@@ -59,7 +59,7 @@ constexpr int TPART = 4 * TACC * 64;        // doubles of triangle partial per w
 constexpr int TSTRIDE = TPART + TCOLS + 8;  // + q partial + c'c partial (padded to 64 bytes)
 constexpr int TSLICES = 16;                 // interleaved slices of the fix-up sum
 constexpr int TALL_MAX_G = PMT_TALL_MAXG;             // workgroups (row chunks) at most
-constexpr int TALL_MIN_CHUNK = 64;          // rows per chunk at least
+constexpr int TALL_MIN_CHUNK = 64;          // rows per chunk at least (one stage for one-tile shapes of up to 2048 rows: tall_chunk)
 
 // the 36 upper-triangular blocks (tm <= tn) of the 8 x 8 block grid, nine per wave:
 //   wave 0: rows {0,1,2} x cols {5,6,7}
@@ -694,7 +694,10 @@ bool gram_tall_diag_applies(int64_t rows, int64_t cols) {
 static int64_t tall_chunk(int64_t rows, int64_t cols) {
     const int64_t nst = cdiv(rows, TBK), nt = std::max<int64_t>(1, cdiv(cols, TCOLS));
     const int64_t maxg = nt == 1 ? TALL_MAX_G : std::max<int64_t>(64, 2 * TALL_MAX_G / nt);
-    return std::max<int64_t>(TALL_MIN_CHUNK / TBK, cdiv(nst, maxg));
+    // (up to 2048 rows of one tile a workgroup takes ONE stage: the launch is latency-bound, a second stage per workgroup costs 2 us —
+    // 500 x 100: 15 -> 11.5 us; beyond, and for several tiles, more groups only make the fix-up longer: 4096 x 512 65 -> 70 us)
+    const int64_t minst = (nt == 1 && rows <= 2048) ? 1 : TALL_MIN_CHUNK / TBK;
+    return std::max<int64_t>(minst, cdiv(nst, maxg));
 }
 int gram_tall_stage_rows(int64_t cols) { return narrow_nb(cols) ? narrow_stage_rows(narrow_nb(cols)) : TBK; }
 int gram_tall_run_lanes(int64_t cols) { return narrow_nb(cols) == 1 ? Narrow<1>::LPC : 8; }       // row-pair lanes per column run

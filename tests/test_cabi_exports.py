@@ -252,7 +252,7 @@ def test_constant_order_is_host_arithmetic(lib):
     assert order(8, 8) == (0, 1, 0) and order(256, 1)[0] == 0   # tiny shapes (the small-plan node): sequential
     assert order(1000, 2049)[0] == 0 and order(8192, 4096)[0] == 0 and order(4096, 2304)[0] == 1 and order(8193, 4096) == (1, 2048, 0)   # > 2048 columns: the cost model
     # up to 2048 columns the fused tall forms, whatever the row count: one tile (order 2; 3 = sixteen row-pair lanes, <= 16 columns) ..
-    assert order(80, 96) == (2, 2, 32) and order(1000, 128)[0] == 2
+    assert order(80, 96) == (2, 3, 32) and order(1000, 128) == (2, 32, 32) and order(4096, 128) == (2, 64, 32)
     o, g, s = order(1 << 20, 128)
     assert (o, s) == (2, 32) and g == 512
     o, g, s = order(8192, 128)
