@@ -42,6 +42,10 @@ struct SmallDev {
     uint64_t seed;
 };
 
+// element indices and extents inside a small node are far below 2^31 (SMALL_NODE_WORK_MAX elements per node): 32-bit unsigned division — the
+// 64-bit one is a ~200-instruction routine per element on this hardware, and most nodes divide once or twice per element
+__device__ __forceinline__ int64_t qdiv(int64_t e, int64_t d) { return (int64_t)((uint32_t)e / (uint32_t)d); }
+
 __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, int tid, int nt) {
     switch (n.op) {
     case SOP_FILL: {                       // rng.hip: dst[c * lda + i] = scale * U(seed, c * rows + i)
@@ -49,7 +53,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         const uint64_t base = (n.dyn >= 0 ? dyn[n.dyn] : n.seed) * 0x9E3779B97F4A7C15ull;
         double *dst = static_cast<double *>(n.out[0]);
         for (int64_t e = tid; e < rows * cols; e += nt) {
-            const int64_t c = e / rows, i = e - c * rows;
+            const int64_t c = qdiv(e, rows), i = e - c * rows;
             dst[c * lda + i] = sp_uniform_at(base, (uint64_t)e, n.scale);
         }
         break;
@@ -63,7 +67,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
         double *consts = static_cast<double *>(n.out[1]);
         for (int64_t e = tid; e < rows * cols; e += nt) {
-            const int64_t c = e / rows, r = e - c * rows;              // walk A column-major (coalesced reads)
+            const int64_t c = qdiv(e, rows), r = e - c * rows;              // walk A column-major (coalesced reads)
             const double v = A[c * lda + r];
             if (n.op == SOP_AFFINE_LT) {
                 LT t; t.coeff = v; t.var = xvar[c];
@@ -87,7 +91,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         QT *oq = static_cast<QT *>(n.out[0]);
         LT *ol = static_cast<LT *>(n.out[1]);
         for (int64_t e = tid; e < rows * nx * ny; e += nt) {
-            const int64_t ia = e / ny, k = e - ia * ny, i = ia / nx;
+            const int64_t ia = qdiv(e, ny), k = e - ia * ny, i = qdiv(ia, nx);
             const LT xa = x[ia], yk = y[i * ny + k];
             double c = xa.coeff * yk.coeff;                                   // functions.jl:149
             if (n.moi && xa.var == yk.var) c = 2 * c;                        // moi_interop.jl:58
@@ -96,7 +100,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         }
         const int64_t w = nx + ny;
         for (int64_t e = tid; e < rows * w; e += nt) {
-            const int64_t i = e / w, k = e - i * w;
+            const int64_t i = qdiv(e, w), k = e - i * w;
             LT t; double c;
             if (k < nx) { t = x[i * nx + k]; c = yc[i]; }                    // xlinear[i] * yconst  (:567)
             else { t = y[i * ny + (k - nx)]; c = xc[i]; }                    // ylinear[i] * xconst  (:571)
@@ -159,7 +163,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         if (!row_ptr) {
             for (int64_t e = tid; e < rows * row_len; e += nt) {
                 const LT t = in[e];
-                VAT r; r.output_index = row_offset + e / row_len + 1; r.coeff = t.coeff; r.var = map_var(varmap, t.var);
+                VAT r; r.output_index = row_offset + qdiv(e, row_len) + 1; r.coeff = t.coeff; r.var = map_var(varmap, t.var);
                 o[e] = r;
             }
         } else {
@@ -225,7 +229,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         double *oc = static_cast<double *>(n.out[1]);
         const int64_t na = xa ? la : 0, nb = xb ? lb : 0;
         for (int64_t e = tid; e < rows * lo; e += nt) {
-            const int64_t row = e / lo, k = e - row * lo;
+            const int64_t row = qdiv(e, lo), k = e - row * lo;
             if (k < na) o[e] = xa[row * la + k];
             else if (k - na < nb) {
                 LT t = xb[row * lb + (k - na)];
@@ -264,7 +268,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         double *oc = static_cast<double *>(n.out[1]);
         const int64_t per_row = cols * L;
         for (int64_t e = tid; e < rows * per_row; e += nt) {
-            const int64_t row = e / per_row, rem = e - row * per_row, col = rem / L;
+            const int64_t row = qdiv(e, per_row), rem = e - row * per_row, col = qdiv(rem, L);
             LT t = x[rem];
             t.coeff = A[col * lda + row] * t.coeff;
             o[e] = t;
@@ -290,7 +294,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         const LT *x = static_cast<const LT *>(n.in[1]);
         const double *xc = static_cast<const double *>(n.in[2]);
         LT *o = static_cast<LT *>(n.out[0]);
-        for (int64_t e = tid; e < cnt * L; e += nt) { LT t = x[e]; t.coeff = v[e / L] * t.coeff; o[e] = t; }
+        for (int64_t e = tid; e < cnt * L; e += nt) { LT t = x[e]; t.coeff = v[qdiv(e, L)] * t.coeff; o[e] = t; }
         if (tid == 0) {
             double acc = 0.0;
             for (int64_t i = 0; i < cnt; ++i) acc = acc + xc[i] * v[i];        // launch_seq_dot(x_consts, v): left to right
@@ -303,7 +307,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         const double *src = static_cast<const double *>(n.in[0]);
         double *dst = static_cast<double *>(n.out[0]);
         for (int64_t e = tid; e < rows * cols; e += nt) {
-            const int64_t c = e / rows, r = e - c * rows;
+            const int64_t c = qdiv(e, rows), r = e - c * rows;
             dst[r * ldd + c] = src[c * lds_ + r];
         }
         break;
@@ -352,8 +356,8 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         const int64_t *varmap = static_cast<const int64_t *>(n.in[3]);
         QT *o = static_cast<QT *>(n.out[0]);
         for (int64_t e = tid; e < nxr * ny; e += nt) {
-            const int64_t r = e / ny, k = e - r * ny;
-            const int64_t qrow = e % nxr, qcol = e / nxr;                   // column-major linear index of the nxr x ny matrix (:853)
+            const int64_t r = qdiv(e, ny), k = e - r * ny;
+            const int64_t qcol = qdiv(e, nxr), qrow = e - qcol * nxr;                   // column-major linear index of the nxr x ny matrix (:853)
             double c = Q[qcol * ldq + qrow];
             const int64_t xv = xvar[r], yv = yvar[k];
             if (n.moi && xv == yv) c = 2 * c;
@@ -389,7 +393,7 @@ __device__ __forceinline__ void sp_node(const SmallDev &n, const uint64_t *dyn, 
         LT *ol = static_cast<LT *>(n.out[1]);
         for (int64_t e = tid; e < rows * L + rows; e += nt) {
             if (e < rows * L) {
-                const int64_t i = e / L;
+                const int64_t i = qdiv(e, L);
                 const LT t = x[e];
                 const int64_t yv = yvar[i];
                 QT q; q.coeff = (n.moi && t.var == yv) ? 2 * t.coeff : t.coeff;
