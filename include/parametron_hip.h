@@ -605,7 +605,8 @@ int64_t pmt_plan_tape_length(const pmt_plan *plan);
  * pmt_copy_bytes, pmt_transpose_f64, pmt_affvec_combine_f64 (uniform rows), pmt_affvec_scale_f64, pmt_matvecmul_affs_f64, the pmt_vecdot_*
  * forms, pmt_bilinear_f64, pmt_quad_combine_f64, pmt_quad_scale_f64, pmt_scale_*_f64, and pmt_quad_gram_f64 for tiny shapes — each writing
  * at most 32768 elements, a run at most 65536) by ONE launch of an interpreter kernel that executes the
- * run's nodes in tape order with a workgroup barrier between them (csrc/small.hip).  Every element is computed by the same expression
+ * run's nodes in tape order with a barrier between dependent ones (csrc/small.hip; one workgroup, or up to 32 with a grid barrier for
+ * runs of tens of thousands of elements: pmt_plan_fused_workgroups).  Every element is computed by the same expression
  * as in the entry's own kernel: outputs are bit-identical.  Automatic; larger entries and everything else replay as recorded.
  *   pmt_plan_set_fusion  0: replay the tape as recorded (A/B and tests); 1 (default): fuse.  Not while recording / after graph capture.
  *   pmt_plan_fused       number of fused runs, tape entries they replace, and launches-or-entries one replay executes */
@@ -615,6 +616,9 @@ int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_
  * (or writes what one read): independent nodes — the Parameter callbacks; the objective's chain and a constraint's — share a PHASE.
  * Number of phases over all fused runs (README Example 1: 7 entries, 3 phases). */
 int pmt_plan_fused_phases(const pmt_plan *plan);
+/* workgroups of the plan's largest fused run (1 .. 32: one per 4096 elements of work beyond 8192; the barrier in front of a dependent node
+ * is then a grid barrier on a counter the plan owns; a hipGraph replays every run with ONE workgroup) */
+int pmt_plan_fused_workgroups(const pmt_plan *plan);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
  * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */
 int pmt_plan_update(pmt_plan *plan);

@@ -66,6 +66,7 @@ end_record!(plan::Plan) = check(ccall((:pmt_plan_end_record, lib), Cint, (Ptr{Cv
 fusion!(plan::Plan, on::Bool) = check(ccall((:pmt_plan_set_fusion, lib), Cint, (Ptr{Cvoid}, Cint), plan.handle, on ? 1 : 0))
 "barrier-separated phases over all fused runs (independent nodes share a phase)"
 fused_phases(plan::Plan) = Int(ccall((:pmt_plan_fused_phases, lib), Cint, (Ptr{Cvoid},), plan.handle))
+fused_workgroups(plan::Plan) = Int(ccall((:pmt_plan_fused_workgroups, lib), Cint, (Ptr{Cvoid},), plan.handle))
 "(fused runs, tape entries they replace, launches-or-entries per replay)"
 function fused(plan::Plan)
     g = Ref{Cint}(0); n = Ref{Cint}(0); len = Ref{Int64}(0)

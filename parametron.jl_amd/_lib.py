@@ -155,6 +155,7 @@ SIGNATURES = {
     "pmt_plan_set_fusion": (_ci, [_vp, _ci]),
     "pmt_plan_fused": (_ci, [_vp, C.POINTER(_ci), C.POINTER(_ci), C.POINTER(_i64)]),
     "pmt_plan_fused_phases": (_ci, [_vp]),
+    "pmt_plan_fused_workgroups": (_ci, [_vp]),
     "pmt_fill_uniform_dyn_f64": (_ci, [_vp, _i64, _i64, _i64, C.POINTER(_u64), _f64, _vp]),
     "pmt_plan_update": (_ci, [_vp]),
     "pmt_plan_instantiate_graph": (_ci, [_vp]),

@@ -43,7 +43,8 @@ struct pmt_plan {
     std::vector<int> node_of;         // per tape entry: index into `nodes`, or -1 (an entry only its closure can execute)
     std::vector<pmt::SmallNode> nodes;
     bool fusion = true;
-    int fused_groups = 0, fused_nodes = 0, fused_phases = 0;
+    int fused_groups = 0, fused_nodes = 0, fused_phases = 0, fused_workgroups = 0;
+    bool single_workgroup_runs = false;      // a graph replays its runs with ONE workgroup (the grid barrier's base is a kernel argument)
     std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
                                       // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
     char record_lane = 0;
@@ -546,8 +547,9 @@ extern "C" int pmt_plan_begin_record(pmt_plan *plan) {
 namespace pmt {
 size_t small_table_bytes(int count);
 void small_table_image(const SmallNode *nodes, int count, void *image);
+int small_plan_workgroups(int64_t work);
 int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
-                      unsigned long long narrowmask, hipStream_t s);
+                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, hipStream_t s);
 void small_plan_masks(const SmallNode *nodes, int count, unsigned long long *syncmask, unsigned long long *narrowmask);
 int small_plan_phases(SmallNode *nodes, int count);
 int small_max_nodes();
@@ -557,7 +559,7 @@ int small_max_nodes();
 // node tables live in plan-owned device memory, written here once (setup, not the solve path).
 static int build_exec(pmt_plan *plan) {
     plan->exec.clear(); plan->exec_lanes.clear();
-    plan->fused_groups = 0; plan->fused_nodes = 0; plan->fused_phases = 0;
+    plan->fused_groups = 0; plan->fused_nodes = 0; plan->fused_phases = 0; plan->fused_workgroups = 0;
     const size_t n = plan->tape.size();
     auto small = [&](size_t i) {
         return plan->fusion && plan->node_of[i] >= 0 && plan->lanes[i] == 0 && plan->nodes[(size_t)plan->node_of[i]].work <= pmt::SMALL_NODE_WORK_MAX;
@@ -594,15 +596,28 @@ static int build_exec(pmt_plan *plan) {
         plan->fused_phases += pmt::small_plan_phases(group.data(), count);
         std::vector<char> image(pmt::small_table_bytes(count));
         pmt::small_table_image(group.data(), count, image.data());
+        // the table, and behind it (64-byte aligned) the run's grid-barrier counter + its time-out word, zeroed once
+        const size_t table_bytes = (image.size() + 63) / 64 * 64;
         void *table = nullptr;
-        hipError_t e = hipMalloc(&table, image.size());
+        hipError_t e = hipMalloc(&table, table_bytes + 64);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
         plan->allocations.push_back(table);
-        plan->bytes += image.size();
+        plan->bytes += table_bytes + 64;
         PMT_HIP_CHECK(hipMemcpy(table, image.data(), image.size(), hipMemcpyHostToDevice));
+        PMT_HIP_CHECK(hipMemset(static_cast<char *>(table) + table_bytes, 0, 64));
         unsigned long long syncmask = 0, narrowmask = 0;
         pmt::small_plan_masks(group.data(), count, &syncmask, &narrowmask);
-        plan->exec.push_back([=](hipStream_t s) { return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, s); });
+        int64_t group_work = 0;
+        for (const pmt::SmallNode &nd : group) group_work += nd.work;
+        const int wgs = plan->single_workgroup_runs ? 1 : pmt::small_plan_workgroups(group_work);
+        unsigned long long *bar = reinterpret_cast<unsigned long long *>(static_cast<char *>(table) + table_bytes);
+        const unsigned long long per_launch = (unsigned long long)__builtin_popcountll(syncmask) * (unsigned long long)wgs;
+        std::shared_ptr<unsigned long long> launches = std::make_shared<unsigned long long>(0);      // of this run so far: the counter's base
+        plan->fused_workgroups = std::max(plan->fused_workgroups, wgs);
+        plan->exec.push_back([=](hipStream_t s) {
+            const unsigned long long base = (*launches)++ * per_launch;
+            return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, s);
+        });
         plan->exec_lanes.push_back(0);
         plan->fused_groups += 1;
         plan->fused_nodes += count;
@@ -630,6 +645,7 @@ extern "C" int pmt_plan_set_fusion(pmt_plan *plan, int on) {
 }
 
 extern "C" int pmt_plan_fused_phases(const pmt_plan *plan) { return plan ? plan->fused_phases : 0; }
+extern "C" int pmt_plan_fused_workgroups(const pmt_plan *plan) { return plan ? plan->fused_workgroups : 0; }
 
 extern "C" int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_length) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fused: null plan");
@@ -786,6 +802,13 @@ extern "C" int pmt_plan_instantiate_graph(pmt_plan *plan) {
     PMT_REQUIRE(plan->fetch_events.empty() && !plan->no_graph, PMT_STATE_ERROR,
                 "plan_instantiate_graph: a tape with recorded fetches or a host delivery is replayed as launches (its copies leave the capture)");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
+    if (plan->fused_workgroups > 1) {
+        // a run on several workgroups counts its grid barriers from a base that is a kernel argument of each launch: a captured launch
+        // would replay a stale one — inside a graph the runs are single-workgroup launches (as they all were before round 5)
+        PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
+        plan->single_workgroup_runs = true;
+        if (int rc = build_exec(plan)) return rc;
+    }
     PMT_HIP_CHECK(hipStreamBeginCapture(plan->stream, hipStreamCaptureModeThreadLocal));
     int rc = replay(plan, plan->stream);
     hipError_t e = hipStreamEndCapture(plan->stream, &plan->graph);

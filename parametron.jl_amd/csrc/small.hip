@@ -421,8 +421,34 @@ constexpr int SMALL_MAX_NODES = 48;          // nodes of one launch (their descr
 
 // syncmask / narrowmask: bit k = node k's `sync` / `narrow` flag, as kernel arguments (scalar registers): a wave skips the nodes that are
 // not its own without touching their descriptions (an LDS read and a wait per skipped node was ~0.3 us)
+// SEVERAL workgroups (plans whose phases hold tens of thousands of elements: a model of ~100 variables kept ONE CU busy for 21 us): every
+// node's element loop strides over all of them, narrow nodes are dealt to the waves of all, and the barrier in front of a dependent node
+// becomes a GRID barrier — one monotonic counter per plan (`bar`, zeroed when the table is uploaded; the launches of a plan are
+// serialised on its stream, launch e waits for the values base + W, base + 2 W, .. with base = e * barriers * W): workgroup barrier,
+// lane 0 releases the workgroup's writes at agent scope and arrives, polls (bounded), acquires; every wave acquires behind the closing
+// workgroup barrier.  At most 32 workgroups: co-resident on any MI355X partition, so the poll cannot starve its own grid.
+__device__ __forceinline__ void small_grid_barrier(unsigned long long *bar, unsigned long long target, int tid) {
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) {        // 2 s of 100 MHz ticks: report, do not hang
+                __hip_atomic_store(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// syncmask / narrowmask: bit k = node k's `sync` / `narrow` flag, as kernel arguments (scalar registers): a wave skips the nodes that are
+// not its own without touching their descriptions (an LDS read and a wait per skipped node was ~0.3 us)
 __global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__restrict__ table, int count, SmallDyn dyn, unsigned long long syncmask,
-                                                          unsigned long long narrowmask) {
+                                                          unsigned long long narrowmask, unsigned long long *bar, unsigned long long base) {
     __shared__ SmallDev nodes[SMALL_MAX_NODES];
     __shared__ uint64_t sdyn[SMALL_MAX_DYN];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -436,15 +462,22 @@ __global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__rest
     for (int i = tid; i < count * W8; i += nt) reinterpret_cast<u64 *>(nodes)[i] = reinterpret_cast<const u64 *>(table)[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;     // (scalar: a wave BRANCHES around the nodes of others)
-    constexpr int nw = 16;                         // (the launch is always 1024 threads)
+    const int wgs = (int)gridDim.x;
+    const int nw = 16 * wgs, gwave = (int)blockIdx.x * 16 + wave;                    // (a workgroup is always 1024 threads)
+    const int gtid = (int)blockIdx.x * nt + tid, gnt = wgs * nt;
     int slot = 0;                                  // narrow nodes of the current phase seen so far
+    unsigned long long target = base;
     for (int k = 0; k < count; ++k) {
-        if ((syncmask >> k) & 1) { __syncthreads(); slot = 0; }   // (uniform: what the previous phase wrote is visible — same workgroup — before this one reads it)
+        if ((syncmask >> k) & 1) {                 // (uniform: what the previous phase wrote is visible before this one reads it)
+            if (wgs == 1) __syncthreads();
+            else { target += (unsigned long long)wgs; small_grid_barrier(bar, target, tid); }
+            slot = 0;
+        }
         if ((narrowmask >> k) & 1) {
-            if (slot % nw == wave) sp_node(nodes[k], sdyn, lane, 64);
+            if (slot % nw == gwave) sp_node(nodes[k], sdyn, lane, 64);
             ++slot;
         } else {
-            sp_node(nodes[k], sdyn, tid, nt);
+            sp_node(nodes[k], sdyn, gtid, gnt);
         }
     }
 }
@@ -543,11 +576,16 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
 }
 
 int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
-                      unsigned long long narrowmask, hipStream_t s) {
+                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, hipStream_t s) {
     SmallDyn dyn;
     for (int i = 0; i < SMALL_MAX_DYN; ++i) dyn.v[i] = (i < ndyn && seed_words[i]) ? *seed_words[i] : 0;
-    PMT_LAUNCH(small_plan_kernel, dim3(1), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn, syncmask, narrowmask);
+    PMT_LAUNCH(small_plan_kernel, dim3((unsigned)std::max(1, workgroups)), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn, syncmask,
+               narrowmask, barrier_word, barrier_base);
     return check_launch("small_plan_kernel");
 }
+
+// workgroups of a fused run: one up to 8192 elements of work (README Example 1: ~700; its launch is then the single-workgroup kernel of
+// before, bit for bit and cycle for cycle), one more per 4096 beyond, 32 at most
+int small_plan_workgroups(int64_t work) { return (int)std::min<int64_t>(32, std::max<int64_t>(1, work / 4096)); }
 
 }  // namespace pmt

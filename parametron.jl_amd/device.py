@@ -200,7 +200,8 @@ class DeviceContext:
         tape entries they replace, and what one replay executes"""
         g, n, ln = C.c_int(), C.c_int(), C.c_int64()
         _lib.call("pmt_plan_fused", self.plan, C.byref(g), C.byref(n), C.byref(ln))
-        return {"groups": g.value, "nodes": n.value, "exec_length": ln.value, "phases": int(self.lib.pmt_plan_fused_phases(self.plan))}
+        return {"groups": g.value, "nodes": n.value, "exec_length": ln.value, "phases": int(self.lib.pmt_plan_fused_phases(self.plan)),
+                "workgroups": int(self.lib.pmt_plan_fused_workgroups(self.plan))}
 
     def set_fusion(self, on):
         _lib.call("pmt_plan_set_fusion", self.plan, 1 if on else 0)

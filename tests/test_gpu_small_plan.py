@@ -425,3 +425,88 @@ def test_small_model_with_several_constraints_follows_every_update():
         t = recs[0].f.terms                                              # VectorAffineTerms of G x: row-major (src/moi_interop.jl:64-81)
         assert np.array_equal(t["coeff"].reshape(m, n), bufs["G"]) and np.all(recs[1].f.terms["coeff"] == 1.0)
     model.close()
+
+
+def test_runs_on_several_workgroups_equal_the_recorded_tape():
+    """A run with tens of thousands of elements of work is executed by SEVERAL workgroups; the barrier in front of its dependent nodes is a
+    grid barrier on a counter the plan owns (csrc/small.hip), whose base advances with every replay.  Every replay: the constraint's MOI
+    terms and constants equal the oracle bit for bit for this replay's seeds (phase 2 reads, across workgroups, what phase 1's fills
+    wrote), the objective the tall node's tolerance; the same tape replayed as recorded gives the same bits; a hipGraph of the plan falls
+    back to single-workgroup runs."""
+    import parametron_jl_amd as P
+    from oracle import oracle as O
+    n, r, m = 100, 150, 30
+    model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+    x = [P.Variable(model) for _ in range(n)]
+    A = P.DeviceUniformParameter((r, n), 1, model); b = P.DeviceUniformParameter((r,), 2, model)
+    Cm = P.DeviceUniformParameter((m, n), 3, model); d = P.DeviceUniformParameter((m,), 4, model, scale=2.0)
+    res = A * x - b
+    P.objective(model, P.Minimize, P.dot(res, res))
+    P.constraint(model, Cm * x == d)
+    P.solve(model)
+    ctx = model.device()
+    fz = ctx.fused()
+    assert model._small and fz["groups"] == 1 and fz["workgroups"] > 1 and fz["phases"] >= 2, fz
+    xi = np.arange(1, n + 1, dtype=np.int64)
+    vm = model.model_var_to_optimizer
+    for it in range(40):
+        P.solve(model)
+        Ch, dh = (O.fill_uniform(int(np.prod(p_.shape)), p_.current_seed(), p_.scale) for p_ in (Cm, d))
+        w = O.LsqWorkspace(n, r, m)
+        w.eval_constraint(Ch, dh, xi)
+        ct, cc = w.constraint.moi(vm)
+        cf = list(model.constraints)[0].f
+        assert np.array_equal(cf.terms.view(np.int64), ct.view(np.int64)) and np.array_equal(cf.constants, cc), it
+        Ah, bh = (O.fill_uniform(int(np.prod(p_.shape)), p_.current_seed(), p_.scale) for p_ in (A, b))
+        Am = Ah.reshape(n, r).T
+        f = model.objective.f
+        np.testing.assert_allclose(f.quadratic_terms["coeff"], (2 * Am.T @ Am)[np.triu_indices(n)], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(f.affine_terms["coeff"], -2 * Am.T @ bh, rtol=1e-12, atol=0)
+    fused = [a.copy() for a in (model.objective.f.quadratic_terms, model.objective.f.affine_terms, cf.terms, cf.constants)]
+    ctx.synchronize(); ctx.set_fusion(False)
+    assert ctx.fused()["groups"] == 0
+    model._run_tape(); ctx.synchronize()                                  # the same Parameter values (nothing was set dirty), entry by entry
+    for a, b_ in zip(fused, (model.objective.f.quadratic_terms, model.objective.f.affine_terms, cf.terms, cf.constants)):
+        assert a.tobytes() == b_.tobytes()
+    ctx.set_fusion(True)
+    assert ctx.fused()["workgroups"] > 1
+    model.close()
+
+
+def test_a_graph_replays_large_runs_with_one_workgroup():
+    """C ABI: a recorded run of ~45000 elements takes several workgroups when replayed as launches; pmt_plan_instantiate_graph rebuilds it as
+    a single-workgroup run (the grid barrier's base is a kernel argument a captured launch could not advance) — same bits either way"""
+    import gpu_util as g
+    from oracle import oracle as O
+    r, n = 150, 100
+    s = g.stream()
+    dA, db = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    res, rc = g.empty_terms(r * n, g.LT), g.empty_f64(r)
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, s, C.byref(plan))
+    rec = C.c_void_p(g.lib().pmt_plan_recording_stream(plan))
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(dA), r, n, r, C.c_uint64(5), 1.0, rec)
+    g.call("pmt_fill_uniform_f64", g.ptr(db), r, C.c_uint64(6), 1.0, rec)
+    g.call("pmt_affine_assemble_f64", g.ptr(dA), r, r, n, g.ptr(xvar), g.ptr(db), -1, g.ptr(res), g.ptr(rc), rec)
+    g.call("pmt_plan_end_record", plan)
+    assert g.lib().pmt_plan_fused_workgroups(plan) > 1
+    want_t = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(O.fill_uniform(r * n, 5).reshape(n, r).T.copy(), np.arange(1, n + 1, dtype=np.int64)),
+                                     O.fill_uniform(r, 6))
+    terms, _, consts = want_t.flat()
+    for _ in range(5):                                                    # launches: the counter's base advances
+        res.zero_(); rc.zero_()
+        g.call("pmt_plan_update", plan)
+        torch.cuda.synchronize()
+        g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), terms)
+        assert g.same_bits(g.f64_to_host(rc, r), consts)
+    g.call("pmt_plan_instantiate_graph", plan)
+    assert g.lib().pmt_plan_fused_workgroups(plan) == 1
+    for _ in range(3):
+        res.zero_(); rc.zero_()
+        g.call("pmt_plan_update", plan)
+        torch.cuda.synchronize()
+        g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), terms)
+        assert g.same_bits(g.f64_to_host(rc, r), consts)
+    g.call("pmt_plan_destroy", plan)
