@@ -244,7 +244,9 @@ int pmt_fetch_synchronize(void *stream);
 int pmt_set_host_delivery(int mode);
 int pmt_get_host_delivery(int device, int *out_mode, int *out_copy_engine);
 /* TEST HOOK (fault injection; 0 = off, the default).  1: in a staged contraction the first halves of split tiles never announce
- * themselves, and the second halves' bounded wait is cut from 2 s to 20 ms — exercises the error path of pmt_fetch_synchronize above. */
+ * themselves, and the second halves' bounded wait is cut from 2 s to 20 ms — exercises the error path of pmt_fetch_synchronize above.
+ * 2: the grid barriers of a small plan's run on several workgroups wait (20 ms) for an arrival that never comes: pmt_plan_synchronize
+ * returns PMT_HIP_ERROR for that re-evaluation.  3: both. */
 int pmt_set_fault_injection(int what);
 
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])

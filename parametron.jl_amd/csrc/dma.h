@@ -13,7 +13,8 @@ struct Signal { uint64_t handle = 0; int64_t *value = nullptr; };     // value: 
 Engine *get(int device);                                             // null: no HSA runtime / no unambiguous agent match -> kernel copies
 // pmt_set_host_delivery: 0 = copy engine when there is one (default), 1 = copy engine or an error, 2 = kernel copies (deliver.hip)
 int delivery_mode();
-// pmt_set_fault_injection (test hook): bit 0 = the first halves of a pair fold never raise their flag (gram_sk.hip)
+// pmt_set_fault_injection (test hook): bit 0 = the first halves of a pair fold never raise their flag (gram_sk.hip);
+// bit 1 = the grid barrier of a small plan's run on several workgroups waits for an arrival that never comes, with a 20 ms bound (small.hip)
 int fault_injection();
 int signal_create(Engine *e, int64_t initial, Signal *out);
 void signal_destroy(Engine *e, Signal s);

@@ -44,6 +44,7 @@ struct pmt_plan {
     std::vector<pmt::SmallNode> nodes;
     bool fusion = true;
     int fused_groups = 0, fused_nodes = 0, fused_phases = 0, fused_workgroups = 0;
+    int *barrier_error = nullptr;            // page-locked word a run on several workgroups stores 1 into when its grid barrier times out
     bool single_workgroup_runs = false;      // a graph replays its runs with ONE workgroup (the grid barrier's base is a kernel argument)
     std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
                                       // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
@@ -308,6 +309,7 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
     for (void *p : plan->allocations) (void)hipFree(p);
+    if (plan->barrier_error) (void)hipHostFree(plan->barrier_error);
     if (plan->owns_stream) (void)hipStreamDestroy(plan->stream);
     delete plan;
     return PMT_OK;
@@ -533,6 +535,9 @@ extern "C" int pmt_plan_synchronize(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_synchronize: null plan");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
+    if (plan->barrier_error && __atomic_exchange_n(plan->barrier_error, 0, __ATOMIC_ACQ_REL))
+        return fail(PMT_HIP_ERROR, "small plan: a workgroup waited 2 s at the grid barrier of a fused run (its workgroups were not all running); "
+                                   "the outputs of this re-evaluation are invalid");
     return PMT_OK;
 }
 
@@ -549,7 +554,8 @@ size_t small_table_bytes(int count);
 void small_table_image(const SmallNode *nodes, int count, void *image);
 int small_plan_workgroups(int64_t work);
 int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
-                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, hipStream_t s);
+                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, int *barrier_error,
+                      long long barrier_bound, hipStream_t s);
 void small_plan_masks(const SmallNode *nodes, int count, unsigned long long *syncmask, unsigned long long *narrowmask);
 int small_plan_phases(SmallNode *nodes, int count);
 int small_max_nodes();
@@ -611,12 +617,20 @@ static int build_exec(pmt_plan *plan) {
         for (const pmt::SmallNode &nd : group) group_work += nd.work;
         const int wgs = plan->single_workgroup_runs ? 1 : pmt::small_plan_workgroups(group_work);
         unsigned long long *bar = reinterpret_cast<unsigned long long *>(static_cast<char *>(table) + table_bytes);
+        if (wgs > 1 && !plan->barrier_error) {
+            PMT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&plan->barrier_error), 64, hipHostMallocDefault));
+            memset(plan->barrier_error, 0, 64);
+        }
+        int *barrier_error = plan->barrier_error;
         const unsigned long long per_launch = (unsigned long long)__builtin_popcountll(syncmask) * (unsigned long long)wgs;
         std::shared_ptr<unsigned long long> launches = std::make_shared<unsigned long long>(0);      // of this run so far: the counter's base
         plan->fused_workgroups = std::max(plan->fused_workgroups, wgs);
         plan->exec.push_back([=](hipStream_t s) {
-            const unsigned long long base = (*launches)++ * per_launch;
-            return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, s);
+            unsigned long long base = (*launches)++ * per_launch;
+            long long bound = 200000000LL;                            // 2 s of 100 MHz ticks
+            // test hook (pmt_set_fault_injection(2)): every barrier of this launch waits for one arrival more than there will be, for 20 ms
+            if (wgs > 1 && (pmt::dma::fault_injection() & 2)) { base += 1; bound = 2000000LL; }
+            return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, barrier_error, bound, s);
         });
         plan->exec_lanes.push_back(0);
         plan->fused_groups += 1;

@@ -427,7 +427,7 @@ constexpr int SMALL_MAX_NODES = 48;          // nodes of one launch (their descr
 // serialised on its stream, launch e waits for the values base + W, base + 2 W, .. with base = e * barriers * W): workgroup barrier,
 // lane 0 releases the workgroup's writes at agent scope and arrives, polls (bounded), acquires; every wave acquires behind the closing
 // workgroup barrier.  At most 32 workgroups: co-resident on any MI355X partition, so the poll cannot starve its own grid.
-__device__ __forceinline__ void small_grid_barrier(unsigned long long *bar, unsigned long long target, int tid) {
+__device__ __forceinline__ void small_grid_barrier(unsigned long long *bar, unsigned long long target, int *error, long long bound, int tid) {
     __syncthreads();
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -435,8 +435,8 @@ __device__ __forceinline__ void small_grid_barrier(unsigned long long *bar, unsi
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000LL) {        // 2 s of 100 MHz ticks: report, do not hang
-                __hip_atomic_store(bar + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > bound) {                // 2 s of 100 MHz ticks: report, do not hang
+                if (error) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (pmt_plan_synchronize reports it)
                 break;
             }
         }
@@ -448,7 +448,7 @@ __device__ __forceinline__ void small_grid_barrier(unsigned long long *bar, unsi
 // syncmask / narrowmask: bit k = node k's `sync` / `narrow` flag, as kernel arguments (scalar registers): a wave skips the nodes that are
 // not its own without touching their descriptions (an LDS read and a wait per skipped node was ~0.3 us)
 __global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__restrict__ table, int count, SmallDyn dyn, unsigned long long syncmask,
-                                                          unsigned long long narrowmask, unsigned long long *bar, unsigned long long base) {
+                                                          unsigned long long narrowmask, unsigned long long *bar, unsigned long long base, int *error, long long bound) {
     __shared__ SmallDev nodes[SMALL_MAX_NODES];
     __shared__ uint64_t sdyn[SMALL_MAX_DYN];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(1024) void small_plan_kernel(const SmallDev *__rest
     for (int k = 0; k < count; ++k) {
         if ((syncmask >> k) & 1) {                 // (uniform: what the previous phase wrote is visible before this one reads it)
             if (wgs == 1) __syncthreads();
-            else { target += (unsigned long long)wgs; small_grid_barrier(bar, target, tid); }
+            else { target += (unsigned long long)wgs; small_grid_barrier(bar, target, error, bound, tid); }
             slot = 0;
         }
         if ((narrowmask >> k) & 1) {
@@ -576,11 +576,12 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
 }
 
 int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
-                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, hipStream_t s) {
+                      unsigned long long narrowmask, int workgroups, unsigned long long *barrier_word, unsigned long long barrier_base, int *barrier_error,
+                      long long barrier_bound, hipStream_t s) {
     SmallDyn dyn;
     for (int i = 0; i < SMALL_MAX_DYN; ++i) dyn.v[i] = (i < ndyn && seed_words[i]) ? *seed_words[i] : 0;
     PMT_LAUNCH(small_plan_kernel, dim3((unsigned)std::max(1, workgroups)), dim3(1024), 0, s, static_cast<const SmallDev *>(device_table), count, dyn, syncmask,
-               narrowmask, barrier_word, barrier_base);
+               narrowmask, barrier_word, barrier_base, barrier_error, barrier_bound);
     return check_launch("small_plan_kernel");
 }
 

@@ -510,3 +510,37 @@ def test_a_graph_replays_large_runs_with_one_workgroup():
         g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), terms)
         assert g.same_bits(g.f64_to_host(rc, r), consts)
     g.call("pmt_plan_destroy", plan)
+
+
+def test_grid_barrier_timeout_is_reported_by_synchronize():
+    """fault injection 2: every workgroup of a multi-workgroup run waits at its grid barrier for an arrival that never comes (bound cut to
+    20 ms); the run finishes, pmt_plan_synchronize returns PMT_HIP_ERROR for that re-evaluation, and the next one (injection off) is clean"""
+    import gpu_util as g
+    from parametron_jl_amd import _lib
+    r, n = 150, 100
+    s = g.stream()
+    dA, db = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    res, rc = g.empty_terms(r * n, g.LT), g.empty_f64(r)
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, s, C.byref(plan))
+    rec = C.c_void_p(g.lib().pmt_plan_recording_stream(plan))
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(dA), r, n, r, C.c_uint64(5), 1.0, rec)
+    g.call("pmt_fill_uniform_f64", g.ptr(db), r, C.c_uint64(6), 1.0, rec)
+    g.call("pmt_affine_assemble_f64", g.ptr(dA), r, r, n, g.ptr(xvar), g.ptr(db), -1, g.ptr(res), g.ptr(rc), rec)
+    g.call("pmt_plan_end_record", plan)
+    assert g.lib().pmt_plan_fused_workgroups(plan) > 1
+    g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+    good = g.terms_to_host(res, r * n, g.LT).copy()
+    try:
+        g.call("pmt_set_fault_injection", 2)
+        g.call("pmt_plan_update", plan)
+        with pytest.raises(_lib.HipError, match="grid barrier"):
+            g.call("pmt_plan_synchronize", plan)
+    finally:
+        g.call("pmt_set_fault_injection", 0)
+    res.zero_()
+    g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+    g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), good)
+    g.call("pmt_plan_destroy", plan)
