@@ -303,8 +303,11 @@ class Model:
             # SMALL models (README Example 1): launch-bound on the device.  Their Parameter callbacks are recorded into the tape and the whole
             # update! replays as one small plan (csrc/small.hip); overlapped recorded fetches — a signal kernel and a copy-engine transfer per
             # MOI buffer, worth it for megabytes — would cut the run of small entries and cost more launches than the copies they hide
+            def _elements(ps):
+                return sum(int(getattr(getattr(p_, "val", None), "nnz", np.size(getattr(p_, "val", 0)))) for p_ in ps)
             self._small = (not self._use_graph and self.handoff == "moi" and
-                           sum(int(getattr(getattr(p_, "val", None), "nnz", np.size(getattr(p_, "val", 0)))) for p_ in self.params) <= self.SMALL_MODEL_ELEMENTS)
+                           _elements(p_ for p_ in self.params if not getattr(p_, "device_resident", False)) <= self.SMALL_MODEL_ELEMENTS and
+                           _elements(p_ for p_ in self.params if getattr(p_, "device_resident", False)) <= self.SMALL_MODEL_DEVICE_ELEMENTS)
             if self._small:
                 self._overlap_moi = False
             self._varmap_buf = ctx.alloc(8 * max(self.nvars, 1))
@@ -384,7 +387,13 @@ class Model:
         if records and self._use_graph:
             self.device().instantiate_graph()
 
-    SMALL_MODEL_ELEMENTS = 32768
+    # measured crossover (tools/mid_table.py, solve! with host Parameters and a do-nothing optimizer): the small-model path (mailboxes, one or two
+    # launches, MOI buffers stored straight into the function objects) beats uploads + separate kernels + overlapped fetches up to ~300 000
+    # Parameter elements (n = 128, r = 240: 69 vs 156 us; n = 300, r = 800: 212 vs 229; n = 400, r = 800: equal)
+    SMALL_MODEL_ELEMENTS = 262144
+    # Parameters regenerated ON the device (DeviceUniformParameter): nothing to upload, so the separate-kernel path catches up earlier
+    # (update! on the device, n = 128 / r = 240: 33 vs 40 us; n = 200 / r = 600: 75 vs 68)
+    SMALL_MODEL_DEVICE_ELEMENTS = 65536
 
     def _record_parameter_callbacks(self, ctx):
         """SMALL models: the device-side callbacks of the DeviceUniformParameters go INTO the tape, at its front, with their seeds in host

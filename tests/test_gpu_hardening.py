@@ -114,6 +114,7 @@ def test_side_lane_results_equal_the_single_stream_tape(use_graph):
     def build(side_lane):
         n, r, m = 300, 520, 70
         model = P.Model(P.MockOptimizer(variable_offset=3), quadratic_mode="canonical", use_graph=use_graph, side_lane=side_lane)
+        model.SMALL_MODEL_ELEMENTS = 0          # the LARGE-model path (uploads, side lane) at a size that keeps the test fast
         x = [Variable(model) for _ in range(n)]
         rng = np.random.default_rng(77)
         fill = lambda a: a.__setitem__(Ellipsis, rng.random(a.shape) - 0.25)
