@@ -183,8 +183,12 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
             for (int k = 0; k < TBLK; ++k) {
                 if (tw_blk(W, k, 1) != c) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    // a DIAGONAL block's third rotation — 4 x 4 sub-blocks (b, b + 3) — holds the transposes of the first rotation's
+                    // (b + 1, b): never computed, the fix-up reads the (3, 0) sub-block of rotation 1 as (0, 3) (tall_diag_rule)
+                    if (r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)], bv[r], acc[k * 4 + r], 0, 0, 0);
+                }
             }
         }
     }
@@ -403,7 +407,14 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
             tm = TALL_BLOCKS[w][k][0]; tn = TALL_BLOCKS[w][k][1];
         }
         const int i = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3;
-        const int64_t j = j0 + 16 * tm + 4 * b + i, kk = j0 + 16 * tn + 4 * ((b + r) & 3) + jj;
+        int64_t j = j0 + 16 * tm + 4 * b + i, kk = j0 + 16 * tn + 4 * ((b + r) & 3) + jj;
+        if (tm == tn) {
+            // tall_diag_rule — a diagonal block's 4 x 4 sub-blocks (b, (b + r) & 3): rotation 0 is the diagonal sub-blocks (their upper halves
+            // are taken), rotation 1 gives (0,1), (1,2), (2,3) and, as its transpose (the same products in the same order: the same bits),
+            // (0,3) out of (3,0); rotation 2 gives (0,2), (1,3) (its other two are their transposes); rotation 3 is never computed
+            if (r == 3 || (r == 2 && j > kk) || (r == 0 && j > kk)) return;
+            if (r == 1 && j > kk) { const int64_t t = j; j = kk; kk = t; }
+        }
         if (kk >= n || j > kk) return;
         double c = v;
         if (f.moi || j != kk) c = 2 * c;
@@ -550,6 +561,7 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
 #else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (r == 3 && c == 0) { bv[r] = 0.0; continue; }         // (column 0 has the diagonal block only)
                 const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);
                 bv[r] = panel[(c * 16 + rc) * N::PITCH + ks * 4];
             }
@@ -558,6 +570,7 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
             for (int tm = 0; tm <= c; ++tm)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (r == 3 && tm == c) continue;                      // (diagonal block: tall_stage)
                     const int k = c * (c + 1) / 2 + tm;
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], bv[r], acc[k * 4 + r], 0, 0, 0);
                 }
