@@ -626,11 +626,13 @@ static int build_exec(pmt_plan *plan) {
         std::shared_ptr<unsigned long long> launches = std::make_shared<unsigned long long>(0);      // of this run so far: the counter's base
         plan->fused_workgroups = std::max(plan->fused_workgroups, wgs);
         plan->exec.push_back([=](hipStream_t s) {
-            unsigned long long base = (*launches)++ * per_launch;
+            unsigned long long base = *launches * per_launch;
             long long bound = 200000000LL;                            // 2 s of 100 MHz ticks
             // test hook (pmt_set_fault_injection(2)): every barrier of this launch waits for one arrival more than there will be, for 20 ms
             if (wgs > 1 && (pmt::dma::fault_injection() & 2)) { base += 1; bound = 2000000LL; }
-            return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, barrier_error, bound, s);
+            const int rc = pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, barrier_error, bound, s);
+            if (!rc) ++*launches;                                     // (a launch that was not enqueued does not arrive at the counter)
+            return rc;
         });
         plan->exec_lanes.push_back(0);
         plan->fused_groups += 1;
