@@ -41,6 +41,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
                    unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0);
 bool gram_tall_applies(int64_t rows, int64_t cols);
 bool gram_tiny(int64_t rows, int64_t cols);
+int launch_small_one(const SmallNode &nd, hipStream_t s);
 bool gram_tall_diag_applies(int64_t rows, int64_t cols);
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
@@ -742,7 +743,8 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         nd.op = SOP_GRAM; nd.sign = (b && sign) ? sign : 0; nd.moi = moi; nd.d[0] = lda; nd.d[1] = rows; nd.d[2] = cols;
         nd.in[0] = A; nd.in[1] = xvar; nd.in[2] = b; nd.in[3] = varmap; nd.out[0] = out_quad; nd.out[1] = out_lin; nd.out[2] = out_const;
         nd.work = rows * cols * (cols + 1) / 2 + 64 * rows;
-        return dispatch(stream, node, nd);
+        // (by itself — an immediate call, or a run of one — the node is ONE launch of the interpreter's body: the same bits as inside a run)
+        return dispatch(stream, [=](hipStream_t s) { return launch_small_one(nd, s); }, nd);
     }
     return dispatch(stream, node);
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include <cstring>
 
 namespace pmt {
 
@@ -573,6 +574,32 @@ void small_table_image(const SmallNode *nodes, int count, void *image) {
         for (int k = 0; k < 3; ++k) d[i].out[k] = s.out[k];
         d[i].scale = s.scale; d[i].seed = s.seed;
     }
+}
+
+// ONE node by itself, its description a kernel argument (no table): the stand-alone form of a node that has no kernel of its own at its
+// size — the tiny canonical Gram objective (gram.hip), whose other form, the stream-K node, is three kernels and a side-stream fork.
+struct SmallRaw { u64 w[sizeof(SmallDev) / 8]; };      // (a description as plain words: a kernel argument struct that holds pointers sends this compiler's infer-address-spaces pass into a crash)
+__global__ __launch_bounds__(1024) void small_one_kernel(SmallRaw d) {
+    __shared__ SmallDev node;                          // (sp_node indexes the description's arrays with registers: not from kernel arguments)
+    constexpr int W8 = (int)(sizeof(SmallDev) / 8);
+#pragma unroll
+    for (int i = 0; i < W8; ++i)
+        if ((int)threadIdx.x == i) reinterpret_cast<u64 *>(&node)[i] = d.w[i];
+    __shared__ uint64_t sdyn[SMALL_MAX_DYN];           // (no host-word seeds here; sp_node wants the array)
+    if (threadIdx.x < SMALL_MAX_DYN) sdyn[threadIdx.x] = 0;
+    __syncthreads();
+    sp_node(node, sdyn, (int)threadIdx.x, (int)blockDim.x);
+}
+
+int launch_small_one(const SmallNode &nd, hipStream_t s) {
+    SmallNode one = nd;
+    one.dyn = -1; one.sync = 0;
+    SmallDev d;
+    small_table_image(&one, 1, &d);
+    SmallRaw raw;
+    std::memcpy(&raw, &d, sizeof raw);
+    PMT_LAUNCH(small_one_kernel, dim3(1), dim3(1024), 0, s, raw);
+    return check_launch("small_one_kernel");
 }
 
 int launch_small_plan(const void *device_table, int count, const uint64_t *const *seed_words, int ndyn, unsigned long long syncmask,
