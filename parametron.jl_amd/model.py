@@ -118,6 +118,32 @@ class MockOptimizer(AbstractOptimizer):
         return "NO_SOLUTION"
 
 
+def _mailbox_writer(x):
+    """_write_mailbox with the layout resolved once: val -> the mailbox, in the device layout"""
+    from .device import DMat, DVec
+    dv, mb = x._dev, x._mailbox
+    if isinstance(dv, DMat):
+        view, shape = mb.reshape(dv.cols, dv.lda)[:, :dv.rows], (dv.rows, dv.cols)
+
+        def write(val):
+            m = np.asarray(val, dtype=np.float64)
+            if m.shape != shape:
+                raise DimensionMismatch("Parameter changed shape: %r -> %r" % (shape, m.shape))
+            view[...] = m.T
+    elif isinstance(dv, DVec):
+        view, shape = mb[:dv.n], (dv.n,)
+
+        def write(val):
+            v = np.asarray(val, dtype=np.float64)
+            if v.shape != shape:
+                raise DimensionMismatch("Parameter changed shape: %r -> %r" % (shape, v.shape))
+            view[...] = v
+    else:
+        def write(val):
+            mb[0] = float(val)
+    return write
+
+
 def _write_mailbox(x, val):
     """the value of a host-updated Parameter into its page-locked mailbox, in the layout of the device buffer (padded leading dimension)"""
     from .device import DMat, DVec
@@ -418,6 +444,7 @@ class Model:
                     continue
                 x._mailbox = ctx.pinned_array(n_doubles, np.float64)
                 x._mailbox[:] = 0.0
+                x._mailbox_write = _mailbox_writer(x)
                 _write_mailbox(x, x.val if getattr(x, "val", None) is not None else None)
                 ctx.call("pmt_copy_bytes", C.c_void_p(dv.buf), C.c_void_p(x._mailbox.ctypes.data), 8 * n_doubles)
                 x._in_tape = True
@@ -427,7 +454,10 @@ class Model:
             x._seed_word = C.c_uint64(x.current_seed() % (1 << 64))
             rows, cols, lda = (dv.rows, dv.cols, dv.lda) if isinstance(dv, DMat) else (int(x.shape[0]), 1, int(x.shape[0]))
             ctx.call("pmt_fill_uniform_dyn_f64", C.c_void_p(dv.buf), rows, cols, lda, C.byref(x._seed_word), x.scale)
+            x._mailbox_write = None
             x._in_tape = True
+        if ps and all(getattr(x, "_in_tape", False) for x in ps):
+            self._tape_parameters = ps             # every value enters through the tape: _refresh_parameters' short walk
 
     def _mark_side_lane_parameters(self):
         """Host-updated Parameters that ONLY side-lane records read (and, with a hand-off, only when its launches are side-lane entries too)
@@ -481,6 +511,25 @@ class Model:
 
     def _refresh_parameters(self):
         ctx = self.device()
+        fast = getattr(self, "_tape_parameters", None)
+        if fast is not None and not ctx.recording and not any(getattr(x, "_staged_pending", False) for x in fast):
+            # a SMALL model: every Parameter's value enters through an entry of the tape (mailbox copy or seeded fill) — the general walk
+            # below (device_value_of: staging slots, lanes, uploads) reduces to "evaluate, write the mailbox / the seed word when it changed"
+            synced = False
+            for x in fast:
+                val = Parameter.__call__(x)                              # evalarg(::Parameter) (src/lazyexpression.jl:51)
+                if x._dev_version != x.version:
+                    write = x._mailbox_write
+                    if write is not None:
+                        if not synced and getattr(ctx, "_replay_pending", False):
+                            ctx.synchronize()                           # the previous replay may still be reading the mailboxes
+                        synced = True
+                        if val is not None:
+                            write(val)
+                    else:
+                        x._seed_word.value = x.current_seed() % (1 << 64)
+                    x._dev_version = x.version
+            return
         from .lazyexpression import device_value_of
         ctx._staging_dirty = False
         if ctx._stage_slot != ctx._pending_slot:
