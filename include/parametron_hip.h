@@ -200,7 +200,9 @@ int pmt_quad_gram_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
 /* The same node with the solver hand-off fused into the epilogue (see "Solver hand-off" below): the values of P's upper
  * triangle in CSC order, out_P_values[k(k+1)/2 + j] = alpha * 2 * sum_i A[i,j]*A[i,k] (j <= k) — valid as the CSC value array
  * whenever j -> vm[xvar[j]] is strictly increasing (col_ptr[c] counts the variables below, row indices follow).  out_quad
- * (MOI terms, as above with moi = 1) is optional here: NULL skips the 24-byte term structs entirely.  out_lin / out_const as above. */
+ * (MOI terms, as above with moi = 1) is optional here: NULL skips the 24-byte term structs entirely.  out_lin / out_const as above.
+ * The values equal the coefficients pmt_quad_gram_f64 writes for the same inputs bit for bit, except for TINY shapes (those the small-plan
+ * interpreter takes: row-order sums there, the contraction's MFMA order here — equal to rounding; the constant is sequential in both). */
 int pmt_quad_gram_csc_f64(const double *A, int64_t lda, int64_t rows, int64_t cols,
                           const int64_t *xvar, const double *b, int sign, const int64_t *varmap,
                           double alpha, double *out_P_values, pmt_quadratic_term *out_quad,
