@@ -48,6 +48,9 @@
 #endif
 
 #ifndef PMT_BS_NT
+#ifndef PMT_BS_DIAG3
+#define PMT_BS_DIAG3 1       // the third rotation of diagonal sub-tiles is not computed (see matrix_wave)
+#endif
 #define PMT_BS_NT 3        // bit 0 = the A stream is loaded with the nt policy, bit 1 = the slab copy-out stores are nontemporal
 #endif
 // (measured, profiles/r04_batch_small.txt: A is read once and the slab written once — with both marked nontemporal the step takes 0.430 instead
@@ -195,10 +198,16 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
                     if (ks + 1 < CK / 4) read_operands(s_ ^ 1, ks + 1);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        // (the third rotation of a DIAGONAL sub-tile — i = KA - 1 / KB - 1 — holds the transposes of the first one's 4 x 4 blocks:
+                        // not computed, the write-out below takes block (3, 0) of rotation 1 as (0, 3); gram_tall.hip tall_diag_rule)
 #pragma unroll
-                        for (int i = 0; i < KA; ++i) accA[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bA[s_][r], accA[i][r], 0, 0, 0);
+                        for (int i = 0; i < KA; ++i)
+                            if (!(PMT_BS_DIAG3 && r == 3 && i == KA - 1))
+                                accA[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bA[s_][r], accA[i][r], 0, 0, 0);
 #pragma unroll
-                        for (int i = 0; i < KB; ++i) accB[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bB[s_][r], accB[i][r], 0, 0, 0);
+                        for (int i = 0; i < KB; ++i)
+                            if (!(PMT_BS_DIAG3 && r == 3 && i == KB - 1))
+                                accB[i][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][i], bB[s_][r], accB[i][r], 0, 0, 0);
                     }
                     if (PMT_BS_FENCE) asm volatile("" ::: "memory");
                 }
@@ -213,15 +222,29 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
                 for (int i = 0; i < KA; ++i) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool ok = (i < KA - 1 || rowdA <= cA[r]) && (ALLCOLS || cA[r] < n);
-                        if (ok) st[rb[i] + cA[r]] = 2 * accA[i][r];
+                        if (PMT_BS_DIAG3 && i == KA - 1) {
+                            // diagonal sub-tile: rotation 0 keeps row <= col, 2 keeps row < col, 1 keeps everything — its block (3, 0) at the
+                            // transposed position —, 3 was not computed
+                            const int row = rowdA, col = cA[r];
+                            if (r == 1 && row > col) { if (ALLCOLS || row < n) st[(col * n - (col * (col - 1)) / 2 - col) + row] = 2 * accA[i][r]; }
+                            else if (r != 3 && row <= col && (ALLCOLS || col < n)) st[rb[i] + col] = 2 * accA[i][r];
+                        } else {
+                            const bool ok = (i < KA - 1 || rowdA <= cA[r]) && (ALLCOLS || cA[r] < n);
+                            if (ok) st[rb[i] + cA[r]] = 2 * accA[i][r];
+                        }
                         accA[i][r] = 0.0;
                     }
                     if (i < KB) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const bool ok = (i < KB - 1 || rowdB <= cB[r]) && (ALLCOLS || cB[r] < n);
-                            if (ok) st[rb[i] + cB[r]] = 2 * accB[i][r];
+                            if (PMT_BS_DIAG3 && i == KB - 1) {
+                                const int row = rowdB, col = cB[r];
+                                if (r == 1 && row > col) { if (ALLCOLS || row < n) st[(col * n - (col * (col - 1)) / 2 - col) + row] = 2 * accB[i][r]; }
+                                else if (r != 3 && row <= col && (ALLCOLS || col < n)) st[rb[i] + col] = 2 * accB[i][r];
+                            } else {
+                                const bool ok = (i < KB - 1 || rowdB <= cB[r]) && (ALLCOLS || cB[r] < n);
+                                if (ok) st[rb[i] + cB[r]] = 2 * accB[i][r];
+                            }
                             accB[i][r] = 0.0;
                         }
                     }
