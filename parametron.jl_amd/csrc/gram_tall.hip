@@ -42,7 +42,13 @@
 #define PMT_TALL_MAXG 512
 #endif
 #ifndef PMT_TALL_K2
-#define PMT_TALL_K2 0
+#define PMT_TALL_K2 1
+#endif
+#ifndef PMT_TALL_DIAG3
+#define PMT_TALL_DIAG3 1         // a diagonal block's third rotation is not computed (tall_diag_rule)
+#endif
+#ifndef PMT_TALL_DEAL
+#define PMT_TALL_DEAL 0          // 0: blocks dealt by rectangles (36 / 34 / 33 / 33 MFMAs per k-step); 1: two diagonal + seven other blocks per wave (34 each)
 #endif
 
 namespace pmt {
@@ -68,6 +74,7 @@ constexpr int TALL_MIN_CHUNK = 64;          // rows per chunk at least (one stag
 //   wave 3: rows 4..7 x cols {5,6,7} on and above the diagonal
 // (local constexpr tables inside constexpr functions: usable from device code without a device-side definition; every use below has
 // compile-time arguments after unrolling)
+#if PMT_TALL_DEAL == 0
 __host__ __device__ constexpr int tw_nr(int w) { constexpr int t[4] = {3, 5, 4, 4}; return t[w]; }
 __host__ __device__ constexpr int tw_nc(int w) { constexpr int t[4] = {3, 2, 6, 3}; return t[w]; }
 __host__ __device__ constexpr int tw_row(int w, int i) {          // i-th distinct block row of wave w
@@ -95,6 +102,34 @@ __device__ __constant__ signed char TALL_BLOCKS[4][TBLK][2] = {
     {{4, 5}, {5, 5}, {4, 6}, {5, 6}, {6, 6}, {4, 7}, {5, 7}, {6, 7}, {7, 7}},
 };
 
+#else
+// (the balanced dealing: index pairs {0,1} .. {6,7}, a wave owns the triangle on its pair and six cross blocks; profiles/r05_gram_tall.txt)
+__host__ __device__ constexpr int tw_nr(int w) { constexpr int t[4] = {2, 2, 4, 6}; return t[w]; }
+__host__ __device__ constexpr int tw_nc(int w) { constexpr int t[4] = {5, 5, 4, 3}; return t[w]; }
+__host__ __device__ constexpr int tw_row(int w, int i) {
+    constexpr int t[4][6] = {{0, 1, 0, 0, 0, 0}, {2, 3, 0, 0, 0, 0}, {4, 5, 0, 1, 0, 0}, {6, 7, 4, 5, 2, 3}};
+    return t[w][i];
+}
+__host__ __device__ constexpr int tw_col(int w, int i) {
+    constexpr int t[4][6] = {{0, 1, 5, 6, 7, 0}, {2, 3, 5, 6, 7, 0}, {4, 5, 2, 3, 0, 0}, {6, 7, 4, 0, 0, 0}};
+    return t[w][i];
+}
+__host__ __device__ constexpr int tw_blk(int w, int k, int which) {
+    constexpr int t[4][TBLK][2] = {
+        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
+        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
+        {{0, 0}, {0, 1}, {1, 1}, {2, 2}, {3, 2}, {2, 3}, {3, 3}, {2, 0}, {3, 0}},
+        {{0, 0}, {0, 1}, {1, 1}, {2, 0}, {3, 0}, {2, 1}, {3, 1}, {4, 2}, {5, 2}}};
+    return t[w][k][which];
+}
+__device__ __constant__ signed char TALL_BLOCKS[4][TBLK][2] = {
+    {{0, 0}, {0, 1}, {1, 1}, {0, 5}, {1, 5}, {0, 6}, {1, 6}, {0, 7}, {1, 7}},
+    {{2, 2}, {2, 3}, {3, 3}, {2, 5}, {3, 5}, {2, 6}, {3, 6}, {2, 7}, {3, 7}},
+    {{4, 4}, {4, 5}, {5, 5}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
+    {{6, 6}, {6, 7}, {7, 7}, {4, 6}, {5, 6}, {4, 7}, {5, 7}, {2, 4}, {3, 4}},
+};
+
+#endif
 struct TallArgs {
     const double *A; int64_t lda, rows, cols;
     const double *b; int sign;            // c_i = 0.0 (+|-) b[i]; b == null or sign == 0: c = 0
@@ -159,6 +194,7 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
                 if (tw_blk(W, k, 1) != c) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;      // (diagonal block: see below)
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
                 }
@@ -186,7 +222,7 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
                 for (int r = 0; r < 4; ++r) {
                     // a DIAGONAL block's third rotation — 4 x 4 sub-blocks (b, b + 3) — holds the transposes of the first rotation's
                     // (b + 1, b): never computed, the fix-up reads the (3, 0) sub-block of rotation 1 as (0, 3) (tall_diag_rule)
-                    if (r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;
+                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)], bv[r], acc[k * 4 + r], 0, 0, 0);
                 }
             }
@@ -570,7 +606,7 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
             for (int tm = 0; tm <= c; ++tm)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (r == 3 && tm == c) continue;                      // (diagonal block: tall_stage)
+                    if (PMT_TALL_DIAG3 && r == 3 && tm == c) continue;    // (diagonal block: tall_stage)
                     const int k = c * (c + 1) / 2 + tm;
                     acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm], bv[r], acc[k * 4 + r], 0, 0, 0);
                 }

@@ -58,7 +58,8 @@ for it in range(count):
         order = C.c_int()
         g.call("pmt_quad_gram_constant_order", r, n, C.byref(order), None, None)
         tiny = order.value == 0 and n <= 128                   # (the interpreter's node: row-order sums; the CSC form of a tiny shape is the stream-K node)
-        ok = np.all(np.abs(got - w2) <= 1e-12 * np.abs(w2) + 1e-300) if tiny else g.same_bits(got, w2)
+        sc2 = np.empty(nq); sc2[iu[1] * (iu[1] + 1) // 2 + iu[0]] = scale
+        ok = np.all(np.abs(got - w2) <= 1e-12 * sc2 + 1e-300) if tiny else g.same_bits(got, w2)      # (signed data: relative to sum |a||b|)
     if not ok:
         bad += 1
         print("MISMATCH r=%d n=%d lda=%d shift=%d sign=%d moi=%d" % (r, n, lda, shift, sign, moi), flush=True)
