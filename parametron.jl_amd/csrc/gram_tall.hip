@@ -580,10 +580,43 @@ __device__ __forceinline__ void narrow_store(double *__restrict__ panel, const f
     }
 }
 
-// this wave's quarter of a stage: every block, KSTEPS k-steps (`panel` points at the wave's first row + this lane's k offset)
+// this wave's quarter of a stage: every block, KSTEPS k-steps (`panel` points at the wave's first row + this lane's k offset).
+// PMT_NARROW_K2 (as PMT_TALL_K2): the contraction slot k = lane >> 4 of k-steps 2j and 2j + 1 takes the ADJACENT rows 8j + 2k, 8j + 2k + 1, so
+// ONE 16-byte LDS read per operand serves two k-steps.
+#ifndef PMT_NARROW_K2
+#define PMT_NARROW_K2 1
+#endif
 template <int NB>
 __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, int lm, double (&acc)[Narrow<NB>::NACC]) {
     using N = Narrow<NB>;
+#if PMT_NARROW_K2
+    static_assert(N::KSTEPS % 2 == 0, "k-steps in pairs");
+#pragma unroll
+    for (int kk = 0; kk < N::KSTEPS / 2; ++kk) {
+        f64x2 a[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) a[t] = *reinterpret_cast<const f64x2 *>(panel + (t * 16 + lm) * N::PITCH + kk * 8);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            f64x2 bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (PMT_TALL_DIAG3 && r == 3 && c == 0) { bv[r].x = 0.0; bv[r].y = 0.0; continue; }
+                const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);
+                bv[r] = *reinterpret_cast<const f64x2 *>(panel + (c * 16 + rc) * N::PITCH + kk * 8);
+            }
+#pragma unroll
+            for (int tm = 0; tm <= c; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (PMT_TALL_DIAG3 && r == 3 && tm == c) continue;    // (diagonal block: tall_stage)
+                    const int k = c * (c + 1) / 2 + tm;
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tm].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
+                }
+        }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < N::KSTEPS; ++ks) {
         double a[NB];
@@ -612,6 +645,7 @@ __device__ __forceinline__ void narrow_stage(const double *__restrict__ panel, i
                 }
         }
     }
+#endif
 }
 
 template <int NB, bool FAST>
@@ -646,14 +680,14 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
         const int cur = s & 1;
         const bool more = s + 1 < nstage;
 #if PMT_NARROW_ABL == 1
-        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + lk, lm, acc);
+        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + (PMT_NARROW_K2 ? 2 : 1) * lk, lm, acc);
         if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #elif PMT_NARROW_ABL == 2
         if (more) narrow_load<NB, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #else
         if (more) narrow_load<NB, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
-        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + lk, lm, acc);
+        narrow_stage<NB>(lds[cur] + wave * (N::R / 4) + (PMT_NARROW_K2 ? 2 : 1) * lk, lm, acc);
         if (more) narrow_store<NB>(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #endif
         __syncthreads();
