@@ -47,10 +47,10 @@
 #define PMT_BS_GLDS 0      // 1: the FAST path's A chunks go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write)
 #endif
 
-#ifndef PMT_BS_NT
 #ifndef PMT_BS_DIAG3
-#define PMT_BS_DIAG3 1       // the third rotation of diagonal sub-tiles is not computed (see matrix_wave)
+#define PMT_BS_DIAG3 1    // the third rotation of diagonal sub-tiles is not computed (see matrix_wave)
 #endif
+#ifndef PMT_BS_NT
 #define PMT_BS_NT 3        // bit 0 = the A stream is loaded with the nt policy, bit 1 = the slab copy-out stores are nontemporal
 #endif
 // (measured, profiles/r04_batch_small.txt: A is read once and the slab written once — with both marked nontemporal the step takes 0.430 instead
