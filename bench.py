@@ -458,6 +458,41 @@ def config_tall(torch, _lib, steps=20):
     return out
 
 
+MID_SHAPES = ((50, 80, 10), (100, 150, 30), (128, 240, 16), (300, 500, 60))
+
+
+def config_mid(torch, P, steps=200):
+    """Mid-size least-squares QPs — the sizes the reference is used at — through the host API with HOST-updated Parameters that change every
+    solve (Parameter(model, val=buf), src/parameter.jl:88) and a do-nothing optimizer: wall time of one solve!(model) = mailboxes in, update!
+    (one or two launches + the objective's node), the MOI buffers on the host (stored by the kernels into page-locked arrays), MOI.set calls.
+    The user's own refill of the buffers is not timed."""
+    import numpy as np
+    out = {}
+    for n, r_, m in MID_SHAPES:
+        rng = np.random.default_rng(n)
+        model = P.Model(P.MockOptimizer(), quadratic_mode="canonical")
+        x = [P.Variable(model) for _ in range(n)]
+        bufs = {"A": np.asfortranarray(rng.random((r_, n))), "b": rng.random(r_), "C": np.asfortranarray(rng.random((m, n))), "d": rng.random(m)}
+        A, b, Cm, d = (P.Parameter(model, val=bufs[k]) for k in ("A", "b", "C", "d"))
+        res = A * x - b
+        P.objective(model, P.Minimize, P.dot(res, res)); P.constraint(model, Cm * x, "<=", d)
+        P.solve(model)
+        pre = [{k: rng.random(a.shape) for k, a in bufs.items()} for _ in range(2)]
+        total = 0.0
+        for it in range(20 + steps):
+            for k, a in bufs.items():
+                a[...] = pre[it & 1][k]
+            t0 = time.perf_counter()
+            P.solve(model)
+            if it >= 20:
+                total += time.perf_counter() - t0
+        fz = model.device().fused()
+        out["n%d_r%d_m%d" % (n, r_, m)] = {"solve_us": total / steps * 1e6, "small_model_path": bool(getattr(model, "_small", False)),
+                                           "launches_per_update": fz["exec_length"], "run_workgroups": fz.get("workgroups")}
+        model.close()
+    return out
+
+
 def config_c4(torch, _lib, steps):
     from parametron_jl_amd import batch
     total, n, r, m = 8192, 128, 128, 16
@@ -1078,7 +1113,7 @@ def main():
             ksteps = max(50, min(args.steps, 100))      # (at least 50 steps: 20 steps of a 1.3 ms configuration are 26 ms, too short to average out a box hiccup)
             out["configs"] = {"C1": guarded(config_c1, torch, P, _lib), "C3": guarded(config_c3, torch, P, _lib, ksteps),
                               "C4": guarded(config_c4, torch, _lib, ksteps), "C5": guarded(config_c5, torch, P, _lib, ksteps),
-                              "tall": guarded(config_tall, torch, _lib)}
+                              "tall": guarded(config_tall, torch, _lib), "mid": guarded(config_mid, torch, P)}
             out["host_api"] = guarded(host_api_c2, torch, P, 10)
         out["cpu_baseline"] = None if args.no_cpu_baseline else guarded(cpu_baseline, wl)
         out["cpu_canonical_blas"] = None if args.no_cpu_baseline else guarded(cpu_canonical_blas, wl)
@@ -1141,7 +1176,8 @@ def summary_of(out):
         # measured in this run only: the device-clock figure, else the HIP-event lower bound; the replay of a committed profile has its own key
         "pack_in_step_frac": _get(pack, "in_step", "device_clock", "frac") or _get(pack, "in_step", "rocprofv3", "frac") or _get(pack, "in_step", "hip_events", "frac"),
         "pack_in_step_frac_rocprof_replayed": _get(pack, "in_step", "rocprofv3_replayed", "frac"),
-        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "C1_us": _get(c, "C1", "update_us"), "C1_solve_us": _get(c, "C1", "solve_us_python_host_mock_optimizer"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
+        "value_inputs_resident": _get(out, "config", "value_inputs_resident"), "mid_solve_us": {k: round(v["solve_us"], 1) for k, v in (c.get("mid") or {}).items() if isinstance(v, dict) and "solve_us" in v} or None,
+        "C1_us": _get(c, "C1", "update_us"), "C1_solve_us": _get(c, "C1", "solve_us_python_host_mock_optimizer"), "C1_kernel_us": _get(c, "C1", "kernel_us", "small_plan_kernel"),
         "tall_frac": {k: round(v["frac"], 3) for k, v in (c.get("tall") or {}).items()
                       if isinstance(v, dict) and "frac" in v and v.get("binding") != "launch latency"} or None,
         "node_us_launch_bound": {k: round(v["node_ms"] * 1e3, 1) for k, v in (c.get("tall") or {}).items()
