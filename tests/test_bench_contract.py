@@ -22,7 +22,7 @@ def test_roofline_helpers_follow_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] == pytest.approx(402653184.0 / 0.05e-3 / 1e9) and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     m = bench.mfma_roofline("gram_sk_kernel", 1.18, 4096.0 * 4096 * 4097)
-    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and 0.7 < m["frac"] < 0.8
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and 0.7 < m["frac"] < 0.8 and m["traffic"] is None
     json.dumps(r), json.dumps(m)
 
 
@@ -61,31 +61,95 @@ def test_default_line_documents_the_sharded_config():
     assert "C4_sharded" in bench.__doc__ and "ranks_seen" in bench.__doc__
 
 
-def test_line_ends_with_the_contract_objects_and_a_compact_summary():
-    """a log that keeps only the tail of stdout must still show what matters: the bulky sections come first, then the contract fields,
-    `roofline`, `cpu_baseline`, and `summary` — last and short"""
-    out = {"metric": "m", "value": 800.0, "unit": "re-evaluations/s", "ms_per_step": 1.25, "n_gpus": 1,
-           "config": {"workload": "C2"}, "roofline": {"frac": 0.74, "avg_ms": 1.18}, "kernels": {"k": {"avg_ms": 1.0, "what": "x" * 4000}},
-           "configs": {"C3": {"ms_per_step": 1.27, "workload": "y" * 3000}, "C4": {"ms_per_step": 0.44, "roofline": {"frac": 0.54}},
-                       "C5": {"ms_per_step": 0.03, "roofline": {"frac": 0.55}}, "C4_sharded": {"ms_per_step": 0.45, "rccl_calls_made": True}},
-           "host_api": {"handoff_device": {"ms_per_solve": 1.29}, "handoff_host_csc": {"ms_per_solve": 1.73}, "handoff_moi": {"ms_per_solve": 4.7},
-                        "c3_host_csc": {"ms_per_solve": 1.97}},
-           "roofline_constraint_pack": {"frac": 0.63, "in_step": {"hip_events": {"frac": 0.40}, "device_clock": {"frac": 0.44, "measured_in_this_run": True},
-                                                                  "rocprofv3_replayed": {"frac": 0.55, "measured_in_this_run": False}}},
-           "roofline_affine": {"frac": 0.8, "cold": {"frac": 0.6}}, "cpu_baseline": {"value": 0.004, "sample": "z" * 500}, "ranks_seen": 1}
-    res = bench.ordered_for_the_tail(out)
-    assert set(res) == set(out) | {"summary"}
-    keys = list(res)
-    assert keys[-1] == "summary" and keys[-3:-1] == ["cpu_baseline", "roofline"] and keys.index("kernels") < keys.index("metric") < keys.index("roofline")
-    s = res["summary"]
-    for k in ("C3_ms", "C4_ms", "C4_frac", "C5_ms", "C5_frac", "host_csc_ms", "moi_ms", "device_ms", "pack_in_step_frac", "affine_warm_frac", "affine_cold_frac",
-              "ranks_seen", "rccl_calls_made", "gram_frac", "value", "ms_per_step"):
+def _full_size_out():
+    """an `out` of the size the default run builds: every section with its prose, per-kernel tables, error strings"""
+    kern = {"kernel_%d<with, template, arguments, %d>" % (i, i): {"launches": 20, "avg_ms": 1.2007552499999998, "min_ms": 1.1, "max_ms": 1.3, "measured": "x" * 90}
+            for i in range(25)}
+    roof = bench.mfma_roofline("gram_sk_kernel", 1.2007552499999998, 4096.0 * 4096 * 4097, launches=20, algorithmic_bytes=335.6e6)
+    bench.attach_traffic(roof, {"gram_sk_kernel": {"read": 870123456.789, "write": 184123456.789}, "source": "s"}, "pmt::gram_sk_kernel<")
+    shapes = {"%dx%d" % (r, n): {"node_ms": 0.0617123456, "frac": 0.2212345678, "mfma_frac": 0.22, "hbm_frac": 0.1, "binding": "mfma", "kernels_ms": kern}
+              for r, n in ((1 << 20, 16), (1 << 20, 64), (1 << 20, 128), (4096, 512), (262144, 512), (300, 300))}
+    return {"metric": "QP re-evaluations/sec (Q,q,C,d rebuild) at n=4096", "value": 805.1812345678, "unit": "re-evaluations/s", "n_gpus": 1, "steps": 20,
+            "warmup": 5, "ms_per_step": 1.2419512345678, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": bench.C2Workload.name, "n": 4096, "r": 4096, "m": 512, "objective_mode": "canonical", "instances_per_gpu": 1,
+                       "parallelism": "replicas (independent QP instances, no collective)", "replay": "tape", "step": "s" * 150},
+            "config_detail": {"value_inputs_resident": 817.123456789, "boundary": "b" * 600}, "step_algorithmic_bytes": 402800000.0, "step_flops": 68736000000.0,
+            "ranks_seen": 1, "kernels": kern, "roofline": roof, "value_200_steps": {"value": 798.5123456, "what": "w" * 200},
+            "roofline_affine": {"frac": 0.838825149931128, "cold": {"frac": 0.6634979288064853, "what": "c" * 300}, "note": "n" * 500},
+            "roofline_constraint_pack": {"frac": 0.5429215189654949, "warm": {"frac": 0.57}, "note": "n" * 500},
+            "pmc_traffic": {"gram_sk_kernel": {"read": 8.7e8, "write": 1.84e8}, "source": "s" * 200},
+            "configs": {"C1": {"update_us": 9.123456789, "solve_us_python_host_mock_optimizer": 26.87654321, "model_update_us_c_entry": 12.3456789, "workload": "y" * 300, "kernel_us": kern},
+                        "C3": {"ms_per_step": 1.2712345678, "workload": "y" * 3000, "kernels": kern},
+                        "C4": {"ms_per_step": 0.4412345678, "roofline": {"frac": 0.5412345678}, "kernels": kern},
+                        "C5": {"ms_per_step": 0.0312345678, "roofline": {"frac": 0.5512345678}, "host_updated": {"what": "h" * 400}},
+                        "shapes": shapes,
+                        "C4_sharded": {"ms_per_step": 0.4512345678, "value": 18123456.789, "rccl_calls_made": True, "ranks_seen": 1, "config": {"workload": "z" * 400}}},
+            "cpu_baseline": {"value": 0.00437123456789, "unit": "re-evaluations/s", "cores": 1, "kind": "port", "host_cores": 256, "sample": "z" * 900,
+                             "seconds_per_reevaluation_extrapolated": 228.7123456, "fit_times_s": [0.1] * 4, "cross_check_rows": {"sample": "q" * 300}},
+            "cpu_canonical_blas": {"value": 2.1320043286220307, "cores": 256, "kind": "k" * 80}}
+
+
+def test_the_line_fits_4096_bytes_and_carries_the_contract_objects():
+    """the driver could not parse a 20.8 KB line.  The stdout line of a FULL-SIZE result is at most 4096 bytes, parses, and
+    carries the contract's fields, `roofline` (with frac, traffic and the measured_in_this_run flag), `cpu_baseline` and `summary`; the
+    full objects go to the detail file."""
+    out = _full_size_out()
+    assert len(json.dumps(out)) > 20000                              # the bulk that broke round 5's record
+    line = bench.compact_line(out, "/somewhere/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text.encode()) <= 4096
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("C2") and (back["config"]["n"], back["config"]["r"], back["config"]["m"]) == (4096, 4096, 512)
+    r = back["roofline"]
+    assert r["bound"] == "mfma" and r["frac"] == pytest.approx(0.7283, abs=1e-3) and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["measured_in_this_run"] is True and r["traffic"] == pytest.approx(870123456.789 + 184123456.789, rel=1e-5) and r["avg_ms"] > 0
+    c = back["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["host_cores"] == 256 and c["value"] > 0 and len(c["sample"]) <= 400
+    s = back["summary"]
+    for k in ("C1_update_us", "C1_solve_us", "C3_ms", "C4_ms", "C4_frac", "C5_ms", "C5_frac", "C4_sharded_ms", "rccl_calls_made", "affine_warm_frac",
+              "affine_cold_frac", "pack_cold_frac", "gram_shape_frac", "value_inputs_resident", "value_200_steps", "ranks_seen"):
         assert k in s, k
-    assert s["pack_in_step_frac"] == 0.44 and s["pack_in_step_frac_rocprof_replayed"] == 0.55 and s["C4_frac"] == 0.54 and s["host_csc_ms"] == 1.73 and s["rccl_calls_made"] is True
-    text = json.dumps(res)
-    tail = text[-2000:]
-    assert '"summary"' in tail and '"roofline"' in tail and len(json.dumps(s)) < 1200
-    assert bench.summary_of({})["value"] is None                 # sections may be missing (N > 1, --no-configs): no exception
+    assert s["gram_shape_frac"]["4096x512"] == 0.221 and back["detail"] == "bench_detail.json"
+    assert "kernels" not in back and "configs" not in back
+
+
+def test_the_line_survives_missing_and_failing_sections():
+    """N > 1 / --no-configs / a section that raised: still one parseable line within the limit, the failures named in summary.errors"""
+    out = _full_size_out()
+    out["configs"]["C3"] = {"error": "RuntimeError: " + "e" * 5000}
+    out["cpu_baseline"] = {"error": "OSError: " + "e" * 5000}
+    out["roofline"]["traffic_source"] = "t" * 3000
+    line = bench.compact_line(out)
+    assert len(json.dumps(line).encode()) <= 4096
+    assert "C3" in line["summary"]["errors"] and "cpu_baseline" in line["summary"]["errors"] and "error" in line["cpu_baseline"]
+    bare = bench.compact_line({"metric": "m", "value": 1.0, "roofline": None, "cpu_baseline": None})
+    assert bare["roofline"] is None and bare["summary"] == {} and json.loads(json.dumps(bare))["value"] == 1.0
+
+
+def test_traffic_is_labelled_measured_or_replayed():
+    roof = bench.mfma_roofline("gram_sk_kernel", 1.2, 6.87e10)
+    bench.attach_traffic(roof, None, "pmt::no_such_kernel")                  # no rocprofv3, nothing on file
+    assert roof["measured_in_this_run"] is False and roof["traffic"] is None and "rocprofv3 not on PATH" in roof["traffic_source"]
+    roof = bench.mfma_roofline("gram_sk_kernel", 1.2, 6.87e10)
+    bench.attach_traffic(roof, {"error": "rocprofv3 --pmc FETCH_SIZE child: rc 1"}, "pmt::gram_sk_kernel<2, 16, 2, 0, false>")
+    assert roof["measured_in_this_run"] is False and "rc 1" in roof["traffic_source"]
+    if roof["traffic"] is not None:                                          # the committed replay, labelled as such
+        assert roof["traffic"] == pytest.approx(roof["traffic_read"] + roof["traffic_write"]) and "replay" in roof["traffic_source"]
+
+
+def test_counter_csv_reduction(tmp_path):
+    """rocprofv3's counter_collection.csv -> mean per launch over the LAST `steps` launches of each of the step's kernels"""
+    p = tmp_path / "x_counter_collection.csv"
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for i, v in enumerate([999.0, 100.0, 102.0, 104.0]):
+        rows.append('%d,"void pmt::gram_sk_kernel<2, 16, 2, 0, false>(pmt::SKArgs)",FETCH_SIZE,%r' % (i, v))
+    rows.append('9,"void pmt::affine_tile_kernel<1>(pmt::AffArgs)",FETCH_SIZE,50.0')
+    rows.append('10,"void pmt::fill_uniform_kernel(double*)",FETCH_SIZE,7.0')
+    p.write_text("\n".join(rows) + "\n")
+    got = bench.reduce_counter_csv(str(p), 3)
+    assert got == {"gram_sk_kernel": pytest.approx(102.0), "affine_tile_kernel<VAT>": pytest.approx(50.0)}
 
 
 def test_stdout_carries_the_json_line_only(tmp_path):

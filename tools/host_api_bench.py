@@ -5,12 +5,13 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402,F401
 import parametron_jl_amd as P  # noqa: E402
-import bench  # noqa: E402
+import bench_study  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-out = bench.host_api_c2(torch, P, steps)
+out = bench_study.host_api_c2(torch, P, steps)
 from parametron_jl_amd import workloads  # noqa: E402
 for name, build in (("c2_host_csc", lambda: workloads.config2(handoff="host_csc")), ("c3_host_csc", lambda: workloads.config3(pinned=True, handoff="host_csc")[0])):
     model = build()
