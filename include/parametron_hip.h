@@ -248,7 +248,8 @@ int pmt_get_host_delivery(int device, int *out_mode, int *out_copy_engine);
 /* TEST HOOK (fault injection; 0 = off, the default).  1: in a staged contraction the first halves of split tiles never announce
  * themselves, and the second halves' bounded wait is cut from 2 s to 20 ms — exercises the error path of pmt_fetch_synchronize above.
  * 2: the grid barriers of a small plan's run on several workgroups wait (20 ms) for an arrival that never comes: pmt_plan_synchronize
- * returns PMT_HIP_ERROR for that re-evaluation.  3: both. */
+ * returns PMT_HIP_ERROR for that re-evaluation.  4: every run on several workgroups is launched on ONE (the path a plan takes while another
+ * plan's multi-workgroup run is in flight on the device).  Bits combine. */
 int pmt_set_fault_injection(int what);
 
 /* dest = transpose(x) * Q * y:  quad[k] = (Q[k] (column-major linear index), x[k / ny], y[k % ny])
@@ -525,6 +526,10 @@ int pmt_plan_upload_2d(pmt_plan *plan, void *device_dst, size_t dst_pitch, const
 int pmt_plan_fetch_2d(pmt_plan *plan, void *host_dst, size_t dst_pitch, const void *device_src, size_t src_pitch, size_t width_bytes,
                       size_t height);
 int pmt_plan_synchronize(pmt_plan *plan);
+/* The plan's device-side error state for callers that wait for its stream by other means (hipStreamSynchronize, an event, a wait of
+ * their own): PMT_OK, or PMT_HIP_ERROR (cleared by the call) when a grid barrier of a fused run timed out during a replay since the last
+ * check — the outputs of that re-evaluation are invalid.  pmt_plan_synchronize and pmt_plan_fetch_synchronize check it themselves. */
+int pmt_plan_check(pmt_plan *plan);
 /* Recorded fetch (while recording; lane-aware like every recorded call): at replay the D2H copy goes to the plan's FETCH stream, ordered
  * behind everything recorded before it on its lane, and runs while the rest of the tape is still busy — results reach a HOST solver
  * (MOI.set, src/moi_interop.jl:134,171) without waiting for the end of the re-evaluation.  host_dst should be page-locked.  The plan's
@@ -620,8 +625,11 @@ int pmt_plan_fused(const pmt_plan *plan, int *groups, int *nodes, int64_t *exec_
  * (or writes what one read): independent nodes — the Parameter callbacks; the objective's chain and a constraint's — share a PHASE.
  * Number of phases over all fused runs (README Example 1: 7 entries, 3 phases). */
 int pmt_plan_fused_phases(const pmt_plan *plan);
-/* workgroups of the plan's largest fused run (1 .. 32: one per 4096 elements of work beyond 8192; the barrier in front of a dependent node
- * is then a grid barrier on a counter the plan owns; a hipGraph replays every run with ONE workgroup) */
+/* workgroups of the plan's largest fused run (1 .. 32: one per 4096 elements of work beyond 8192, never more than HALF of what the CUs
+ * of the plan's stream hold at once — occupancy calculator x the stream's CU mask / the partition's CU count; the barrier in front of a
+ * dependent node is then a grid barrier on a counter the plan owns; a hipGraph replays every run with ONE workgroup).  At most one such
+ * run is in flight per device: while another plan's is, a launch goes out on one workgroup (same results).  A grid barrier that still
+ * times out (kernels of other processes holding the CUs) is reported by pmt_plan_synchronize / pmt_plan_fetch_synchronize / pmt_plan_check. */
 int pmt_plan_fused_workgroups(const pmt_plan *plan);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
  * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */

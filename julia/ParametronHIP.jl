@@ -59,6 +59,8 @@ upload!(plan::Plan, dst::DevPtr, src::Array) =
 fetch!(plan::Plan, dst::Array, src::DevPtr) =
     check(ccall((:pmt_plan_fetch, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Csize_t), plan.handle, dst, src, sizeof(dst)))
 synchronize(plan::Plan) = check(ccall((:pmt_plan_synchronize, lib), Cint, (Ptr{Cvoid},), plan.handle))
+"the plan's device-side error state behind a wait the caller made by other means (a timed-out grid barrier of a fused run throws here)"
+check_plan(plan::Plan) = check(ccall((:pmt_plan_check, lib), Cint, (Ptr{Cvoid},), plan.handle))
 recording_stream(plan::Plan) = ccall((:pmt_plan_recording_stream, lib), Ptr{Cvoid}, (Ptr{Cvoid},), plan.handle)
 begin_record!(plan::Plan) = check(ccall((:pmt_plan_begin_record, lib), Cint, (Ptr{Cvoid},), plan.handle))
 end_record!(plan::Plan) = check(ccall((:pmt_plan_end_record, lib), Cint, (Ptr{Cvoid},), plan.handle))

@@ -134,6 +134,7 @@ SIGNATURES = {
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
+    "pmt_plan_check": (_ci, [_vp]),
     "pmt_plan_record_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_record_fetch_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "pmt_host_copy_2d": (_ci, [_vp, _sz, _vp, _sz, _sz, _sz, _ci]),

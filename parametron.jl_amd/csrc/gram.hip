@@ -439,7 +439,7 @@ using namespace pmt;
 extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows) {
     PMT_REQUIRE(rows >= 0 && cols >= 0 && order, PMT_INVALID_ARGUMENT, "quad_gram_constant_order: bad argument");
     const bool tall = cols > 0 && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
-    *order = tall ? (gram_tall_run_lanes(cols) == 16 ? 3 : 2) : (constant_chained(rows, cols) ? 1 : 0);
+    *order = tall ? (gram_tall_run_lanes(cols) == 4 ? 4 : gram_tall_run_lanes(cols) == 16 ? 3 : 2) : (constant_chained(rows, cols) ? 1 : 0);
     if (groups) *groups = tall ? gram_tall_groups(rows, cols) : (*order == 1 ? 2048 : 1);
     if (stage_rows) *stage_rows = tall ? gram_tall_stage_rows(cols) : 0;
     return PMT_OK;

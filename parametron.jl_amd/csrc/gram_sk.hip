@@ -25,6 +25,15 @@
 #include "dma.h"
 #include "gram_common.h"
 
+// The pair fold's producer side (below) publishes a partial tile with write-through (sc1) stores + s_waitcnt vmcnt(0) + a relaxed flag
+// store: the hand-off cdna_hip_programming.md describes for gfx942 / gfx950 as its second, cheaper recipe ("sc1 slab stores -> every wave
+// s_waitcnt vmcnt(0) -> __syncthreads() -> relaxed agent-scope flag; the reducer reads behind an acquire fence") — a property of THESE
+// targets' write-through stores, not of the HIP memory model.  Any other target gets the model's own release edge (the FORMAL variant,
+// +2.6 % per host_csc solve in profiles/r05_pair_fold.txt); -DPMT_SK_PAIR_FORMAL=1 forces it here too.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(PMT_SK_PAIR_FORMAL)
+#define PMT_SK_PAIR_FORMAL 1
+#endif
+
 // Codegen knobs.  The compiler's schedule of the stage loop moves by +-10 % with source changes that do not touch the loop.  Rounds 1-2
 // shipped the luckiest draw of a sweep (246 VGPRs, 1.177 ms at n = r = 4096) — an allocation that only came out that way while a second,
 // unrelated instantiation shared the translation unit (alone: 256 + 7 spilled).  Round 3 takes the lottery out of it in two steps

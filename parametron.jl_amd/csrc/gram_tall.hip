@@ -416,6 +416,13 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
     if (e < nel) {
         const double *p = f.ws + tile * (int64_t)f.G * stride + e;
         int gidx = slice;
+        for (; gidx + 7 * TSLICES < f.G; gidx += 8 * TSLICES) {          // eight loads in flight per thread (the additions keep their order)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(gidx + u * TSLICES) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum = sum + v[u];
+        }
         for (; gidx + 3 * TSLICES < f.G; gidx += 4 * TSLICES) {
             const double v0 = p[(int64_t)gidx * stride], v1 = p[(int64_t)(gidx + TSLICES) * stride];
             const double v2 = p[(int64_t)(gidx + 2 * TSLICES) * stride], v3 = p[(int64_t)(gidx + 3 * TSLICES) * stride];
@@ -726,10 +733,252 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// STREAM form of the narrow panels (round 6).  The panel kernel above moves every stage global -> registers -> LDS ->
+// barrier -> LDS operand reads -> MFMA: its memory side alone streams at 5.8 TB/s and its matrix side alone needs 18 us at 16 columns, but
+// the two phases of a workgroup overlap poorly (29 us; profiles/r05_gram_shapes.txt) and the fix-up is a second launch.  Here there is no
+// LDS and no barrier on the way: every WAVE streams its own row pieces straight into the MFMA operand layout — lane (lm = lane & 15,
+// lk = lane >> 4) loads the 16 bytes of column 16 t + lm at rows 8 i + 2 lk, 8 i + 2 lk + 1 of its iteration: exactly the two values the
+// contraction slots k = lk of k-steps 2 i and 2 i + 1 take for BOTH operands (any assignment of rows to slots is a valid contraction as
+// long as both operands use it: narrow_stage) — D iterations in flight per wave in registers, and the rotated B operands of a block column
+// are DPP row rotations of the A operand (rot_blocks; in the panel kernel they cost more than the LDS reads they replaced, here there is
+// no LDS pipe to lean on and the VALU is idle).  A load instruction touches 64 contiguous bytes of each of 16 columns; the wave's IT
+// instructions of an iteration cover 64 IT contiguous bytes per column, neighbouring waves neighbouring pieces (iteration = global wave
+// index + k * waves: the chip reads one band of consecutive rows at a time, as the panel kernels do).  q = A'c and c'c ride on the VALU
+// with the loaded values.  The four waves of a workgroup add their sums in wave order through LDS once, at the end; the workgroups'
+// partials have the panel kernel's layout (gram_tall_fixup_kernel adds them).
+#ifndef PMT_STREAM
+#define PMT_STREAM 1               // 0: the panel kernel (gram_narrow_kernel) for every narrow shape
+#endif
+#ifndef PMT_STREAM_D1
+#define PMT_STREAM_D1 3            // iterations in flight per wave: 16-column panels,
+#endif
+#ifndef PMT_STREAM_D2
+#define PMT_STREAM_D2 3            // 32,
+#endif
+#ifndef PMT_STREAM_D4
+#define PMT_STREAM_D4 2            // 64
+#endif
+#ifndef PMT_STREAM_IT4
+#define PMT_STREAM_IT4 2           // 16-byte loads per column group, lane and iteration at 64 columns
+#endif
+#ifndef PMT_STREAM_WPS
+#define PMT_STREAM_WPS 2
+#endif
+#ifndef PMT_STREAM_MAXG
+#define PMT_STREAM_MAXG 256        // workgroups at most, 16- and 32-column panels: ONE wave per SIMD streams best (HBM-bound: 2^20 x 16 25 us against 27 with two)
+#endif
+#ifndef PMT_STREAM_MAXG4
+#define PMT_STREAM_MAXG4 512       // 64 columns: the matrix pipe matters as much as the stream — two waves per SIMD (256 workgroups: 142 us against 118)
+#endif
+#ifndef PMT_STREAM_ABL
+#define PMT_STREAM_ABL 0           // ablations (wrong results): 1 no MFMAs / rotations, 2 no loads after the first D iterations
+#endif
+#ifndef PMT_STREAM_DPP
+#define PMT_STREAM_DPP 1           // 0: the rotated operands are loaded again from global memory (L1 hits) instead of DPP rotations
+#endif
+template <int NB> struct Stream {
+    static constexpr int IT = NB == 4 ? PMT_STREAM_IT4 : 4;           // 16-byte loads per column group, lane and iteration (= pairs of k-steps)
+    static constexpr int RI = 8 * IT;                    // rows per iteration
+    static constexpr int D = NB == 1 ? PMT_STREAM_D1 : NB == 2 ? PMT_STREAM_D2 : PMT_STREAM_D4;
+};
+
+// one iteration's loads of one wave: buf[t][i] = rows (row0 + 8 i + 2 lk, + 1) of column 16 t + lm; cb = row pair (lane & (4 IT - 1)) of b, raw —
+// ONE coalesced load per iteration; the contraction slots pick their pairs out of the wave's LDS piece (stream_compute).
+// FAST: scalar base (A + row0: wave-uniform) + a 32-bit per-lane byte offset (voff[t], fixed for the kernel) + an immediate: no vector
+// address arithmetic per load.  Otherwise no branch either: a load outside the matrix reads a clamped (valid) address and is replaced by
+// 0.0 afterwards — a branch around a load would make the compiler drain the whole pipeline at every merge (s_waitcnt vmcnt counts loads in order).
+template <int NB, bool FAST>
+__device__ __forceinline__ void stream_load(const TallArgs &g, int64_t row0, int lane, const unsigned (&voff)[NB], f64x2 (&buf)[NB][Stream<NB>::IT], f64x2 &cb) {
+    using S = Stream<NB>;
+    const int lm = lane & 15, lk = lane >> 4, bp = lane & (4 * S::IT - 1);
+    if (FAST) {
+        const char *base = reinterpret_cast<const char *>(g.A + row0);
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int i = 0; i < S::IT; ++i) buf[t][i] = *reinterpret_cast<const f64x2 *>(base + voff[t] + 64 * i);
+        cb.x = 0.0; cb.y = 0.0;
+        if (g.b) cb = *reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(g.b + row0) + 16u * (unsigned)bp);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        const int64_t col = 16 * t + lm;
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) {
+            const int64_t row = row0 + 8 * i + 2 * lk;
+            const bool cv = col < g.cols, v0 = cv && row < g.rows, v1 = cv && row + 1 < g.rows;
+            const double *p0 = g.A + (v0 ? col * g.lda + row : 0), *p1 = g.A + (v1 ? col * g.lda + row + 1 : 0);
+            const double x = *p0, y = *p1;
+            buf[t][i].x = v0 ? x : 0.0;
+            buf[t][i].y = v1 ? y : 0.0;
+        }
+    }
+    cb.x = 0.0; cb.y = 0.0;
+    if (g.b) {
+        const int64_t row = row0 + 2 * bp;
+        const bool v0 = row < g.rows, v1 = row + 1 < g.rows;
+        const double x = g.b[v0 ? row : 0], y = g.b[v1 ? row + 1 : 0];
+        cb.x = v0 ? x : 0.0;
+        cb.y = v1 ? y : 0.0;
+    }
+}
+
+// One iteration of one wave.  The B operand of rotation r of a block column is the A operand of the lane 4 r further up its 16-lane row
+// (column group (b + r) & 3 instead of b): the wave stores the values it has loaded into its PRIVATE piece of LDS once (16 bytes per lane,
+// linear: no bank conflicts) and reads them back rotated — LDS-pipe instructions beside the MFMAs, no barrier (a wave's LDS operations
+// execute in order), no VALU work: DPP rotations of the same values cost 20 v_mov_dpp per 20 MFMAs at 32 columns and doubled the
+// kernel's matrix phase (profiles/r06_gram_stream.txt).  q = A'c rides on the matrix pipe too: one more MFMA per column group and
+// k-step whose B operand is c itself in EVERY lane of the contraction slot — all 16 columns of the operand are c, so block b of the
+// result holds q of the columns 4 b .. 4 b + 3 (four copies), no rotation needed.  Only c = 0.0 (+|-) b and c'c stay on the VALU
+// (the constant's order is restated bit for bit by the tests: pmt_quad_gram_constant_order, order 4).
+template <int NB>
+__device__ __forceinline__ void stream_compute(double *__restrict__ rot, const f64x2 (&buf)[NB][Stream<NB>::IT], const f64x2 &cb, int sign,
+                                               int lane, double (&acc)[Narrow<NB>::NACC], double (&qacc)[NB], double &cacc) {
+    using S = Stream<NB>;
+    const int lm = lane & 15, lrow = lane & 48, lk = lane >> 4;
+    double *__restrict__ rotb = rot + NB * S::IT * 128;              // b's row pairs: lane l < 4 IT holds pair l
+    *reinterpret_cast<f64x2 *>(rotb + lane * 2) = cb;
+#if PMT_STREAM_ABL != 4
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+        for (int i = 0; i < S::IT; ++i) *reinterpret_cast<f64x2 *>(rot + ((t * S::IT + i) * 64 + lane) * 2) = buf[t][i];
+#endif
+#pragma unroll
+    for (int i = 0; i < S::IT; ++i) {
+#pragma unroll
+        for (int c = 0; c < (PMT_STREAM_ABL == 1 ? 0 : NB); ++c) {
+            f64x2 bv[4];
+            bv[0] = buf[c][i];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                if (r == 3 && c == 0) { bv[r].x = 0.0; bv[r].y = 0.0; continue; }      // (block column 0 holds the diagonal block only)
+                if (PMT_STREAM_ABL == 4) { bv[r] = buf[c][i]; continue; }                  // (ablation: no rotations)
+                bv[r] = *reinterpret_cast<const f64x2 *>(rot + ((c * S::IT + i) * 64 + lrow + ((lm + 4 * r) & 15)) * 2);
+            }
+#pragma unroll
+            for (int tm = 0; tm <= c; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r == 3 && tm == c) continue;                                      // (diagonal block: tall_diag_rule)
+                    const int k = c * (c + 1) / 2 + tm;
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm][i].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm][i].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
+                }
+        }
+        if (PMT_STREAM_ABL == 5) continue;                                                // (ablation: no q / c'c)
+        const f64x2 bi = *reinterpret_cast<const f64x2 *>(rotb + (4 * i + lk) * 2);        // rows 8 i + 2 lk, + 1 of b
+        const double c0 = signed_const(bi.x, sign), c1 = signed_const(bi.y, sign);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t][i].x, c0, qacc[t], 0, 0, 0);
+            qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t][i].y, c1, qacc[t], 0, 0, 0);
+        }
+        cacc = cacc + c0 * c0;
+        cacc = cacc + c1 * c1;
+    }
+}
+
+template <int NB, bool FAST>
+__global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallArgs g) {
+    using S = Stream<NB>;
+    using N = Narrow<NB>;
+    // per wave: the rotation buffer of one iteration (NB IT KB) during the loop; afterwards the same memory carries the waves' sums
+    constexpr int ROT = NB * S::IT * 128 + 128, RED = N::NACC * 64 + 16 * NB + 8;
+    constexpr int SH = 4 * ROT > 3 * RED ? 4 * ROT : 3 * RED;
+    __shared__ double sh[SH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, lk = lane >> 4;
+    const int64_t W = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wave;
+    const int my = (int)(g.nstages > gw ? (g.nstages - gw + W - 1) / W : 0);             // iterations gw, gw + W, ..
+
+    double acc[N::NACC];
+#pragma unroll
+    for (int r = 0; r < N::NACC; ++r) acc[r] = 0.0;
+    double qacc[NB], cacc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) qacc[t] = 0.0;
+    f64x2 buf[S::D][NB][S::IT], cb[S::D];
+    double *rot = sh + wave * ROT;
+    unsigned voff[NB];                                    // (FAST: the launch checks that the panel spans less than 4 GiB)
+#pragma unroll
+    for (int t = 0; t < NB; ++t) voff[t] = (unsigned)(((int64_t)(16 * t + lm) * g.lda + 2 * lk) * 8);
+    // (an iteration index beyond the wave's last is clamped to the last: a repeated, cached load that is never used)
+    auto row_of = [&](int s) { return (gw + (int64_t)min(s, max(my - 1, 0)) * W) * S::RI; };
+    if (my > 0) {
+#pragma unroll
+        for (int d = 0; d < S::D; ++d) stream_load<NB, FAST>(g, row_of(d), lane, voff, buf[d], cb[d]);
+        for (int s0 = 0; s0 < my; s0 += S::D) {
+#pragma unroll
+            for (int d = 0; d < S::D; ++d) {
+                if (s0 + d < my) stream_compute<NB>(rot, buf[d], cb[d], g.sign, lane, acc, qacc, cacc);
+                if (PMT_STREAM_ABL != 2 && PMT_STREAM_ABL != 4 && PMT_STREAM_ABL != 5) stream_load<NB, FAST>(g, row_of(s0 + d + S::D), lane, voff, buf[d], cb[d]);
+            }
+        }
+    }
+    // c'c: the four contraction slots (lanes 0, 16, 32, 48 of column 0), tree in fixed order
+    cacc = cacc + __shfl_down(cacc, 32, 64);
+    cacc = cacc + __shfl_down(cacc, 16, 64);
+    // q of column 16 t + 4 b + i sits in the lanes (i = lane >> 4, b = (lane >> 2) & 3, any lane & 3) of qacc[t]
+    const bool qlane = (lane & 3) == 0;
+    const int qcol = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    __syncthreads();                                      // every wave is done with its rotation buffer
+    // the four waves' sums, added in wave order
+    if (wave > 0) {
+        double *rw = sh + (wave - 1) * RED;
+#pragma unroll
+        for (int r = 0; r < N::NACC; ++r) rw[r * 64 + lane] = acc[r];
+        if (qlane) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) rw[N::NACC * 64 + 16 * t + qcol] = qacc[t];
+        }
+        if (lane == 0) rw[N::NACC * 64 + 16 * NB] = cacc;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double *w = g.ws + (int64_t)blockIdx.x * N::STRIDE;
+#pragma unroll
+    for (int r = 0; r < N::NACC; ++r) {
+        double v = acc[r];
+        v = v + sh[0 * RED + r * 64 + lane];
+        v = v + sh[1 * RED + r * 64 + lane];
+        v = v + sh[2 * RED + r * 64 + lane];
+        w[r * 64 + lane] = v;
+    }
+    if (qlane) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            double v = qacc[t];
+            v = v + sh[0 * RED + N::NACC * 64 + 16 * t + qcol];
+            v = v + sh[1 * RED + N::NACC * 64 + 16 * t + qcol];
+            v = v + sh[2 * RED + N::NACC * 64 + 16 * t + qcol];
+            w[N::PART + 16 * t + qcol] = v;
+        }
+    }
+    if (lane == 0) {
+        double v = cacc;
+        v = v + sh[0 * RED + N::NACC * 64 + 16 * NB];
+        v = v + sh[1 * RED + N::NACC * 64 + 16 * NB];
+        v = v + sh[2 * RED + N::NACC * 64 + 16 * NB];
+        w[N::PART + N::C] = v;
+    }
+}
+
+static bool stream_form(int nb) { return PMT_STREAM && (nb == 1 || nb == 2 || nb == 4); }
+static int stream_iteration_rows(int nb) { return nb == 1 ? Stream<1>::RI : nb == 2 ? Stream<2>::RI : Stream<4>::RI; }
+static int stream_groups(int64_t rows, int nb) {
+    const int64_t nit = cdiv(rows, stream_iteration_rows(nb));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nb == 4 ? PMT_STREAM_MAXG4 : PMT_STREAM_MAXG, cdiv(nit, 4)));
+}
+
 static int narrow_nb(int64_t cols) { return cols <= 16 ? 1 : cols <= 32 ? 2 : cols <= 64 ? 4 : 0; }
 static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ? Narrow<2>::R : Narrow<4>::R; }
 static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
 static int narrow_groups(int64_t rows, int nb) {
+    if (stream_form(nb)) return stream_groups(rows, nb);
     const int64_t nst = cdiv(rows, narrow_stage_rows(nb));
     return (int)cdiv(nst, cdiv(nst, (int64_t)PMT_NARROW_MAXG));
 }
@@ -737,12 +986,21 @@ static int narrow_groups(int64_t rows, int nb) {
 template <int NB>
 static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStream_t s) {
     using N = Narrow<NB>;
-    g.nstages = cdiv(g.rows, N::R);
     const int G = narrow_groups(g.rows, NB);
-    const bool fast = g.vec_in && g.cols == N::C && g.rows % N::R == 0 && b_aligned;
-    if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
-    if (int rc = check_launch("gram_narrow_kernel")) return rc;
+    if (stream_form(NB)) {
+        g.nstages = cdiv(g.rows, Stream<NB>::RI);                 // iterations of RI rows, dealt out to the 4 G waves
+        // whole iterations for every wave's clamped re-reads included, whole panels, aligned pieces of A and b: no masks
+        const bool fast = g.vec_in && g.cols == N::C && g.rows % Stream<NB>::RI == 0 && b_aligned && (uint64_t)g.lda * N::C * 8 < (1ull << 32);
+        if (fast) PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
+        if (int rc = check_launch("gram_stream_kernel")) return rc;
+    } else {
+        g.nstages = cdiv(g.rows, N::R);
+        const bool fast = g.vec_in && g.cols == N::C && g.rows % N::R == 0 && b_aligned;
+        if (fast) PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
+        if (int rc = check_launch("gram_narrow_kernel")) return rc;
+    }
     f.G = G; f.nb = NB; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
@@ -782,8 +1040,12 @@ static int64_t tall_chunk(int64_t rows, int64_t cols) {
     const int64_t minst = (nt == 1 && rows <= 2048) ? 1 : TALL_MIN_CHUNK / TBK;
     return std::max<int64_t>(minst, cdiv(nst, maxg));
 }
-int gram_tall_stage_rows(int64_t cols) { return narrow_nb(cols) ? narrow_stage_rows(narrow_nb(cols)) : TBK; }
-int gram_tall_run_lanes(int64_t cols) { return narrow_nb(cols) == 1 ? Narrow<1>::LPC : 8; }       // row-pair lanes per column run
+int gram_tall_stage_rows(int64_t cols) {
+    const int nb = narrow_nb(cols);
+    return nb ? (stream_form(nb) ? stream_iteration_rows(nb) : narrow_stage_rows(nb)) : TBK;
+}
+// row-pair lanes per column run (8 or 16: the panel kernels); 4: the stream form (four contraction slots per column, iterations dealt to WAVES)
+int gram_tall_run_lanes(int64_t cols) { const int nb = narrow_nb(cols); return nb && stream_form(nb) ? 4 : nb == 1 ? Narrow<1>::LPC : 8; }
 int gram_tall_groups(int64_t rows, int64_t cols) {
     if (const int nb = narrow_nb(cols)) return narrow_groups(rows, nb);
     return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols));

@@ -32,23 +32,21 @@ extern "C" int pmt_host_copy_2d(void *dst, size_t dst_pitch, const void *src, si
     // must be joined, not destroyed (std::terminate).  Rows whose thread never started are copied by the calling thread; nothing is copied twice.
     std::vector<std::thread> pool;
     const size_t per = (height + (size_t)nt - 1) / (size_t)nt;
-    size_t unassigned = height;                 // first row no started thread owns
+    // rows [0, per) are the calling thread's; `unassigned` = first row beyond them that no STARTED thread owns — it moves forward only behind
+    // a successful emplace_back, so whatever throws (reserve's std::bad_alloc, a thread that cannot be started) leaves the rest to the caller
+    size_t unassigned = std::min(height, per);
     try {
         pool.reserve((size_t)nt - 1);
         for (int t = 1; t < nt; ++t) {
             const size_t r0 = std::min(height, (size_t)t * per), r1 = std::min(height, r0 + per);
-            if (r0 < r1) {
-                unassigned = r0;
-                pool.emplace_back(work, r0, r1);
-            }
+            if (r0 < r1) pool.emplace_back(work, r0, r1);
             unassigned = r1;
         }
         unassigned = height;
     } catch (const std::exception &) {
-        // `unassigned` is the first row of the chunk whose thread failed to start
     }
     work(0, std::min(height, per));
-    if (unassigned < height) work(std::max(unassigned, std::min(height, per)), height);
+    if (unassigned < height) work(unassigned, height);
     for (auto &th : pool) th.join();
     return PMT_OK;
 }

@@ -339,7 +339,7 @@ extern "C" int pmt_get_host_delivery(int device, int *out_mode, int *out_copy_en
 }
 
 extern "C" int pmt_set_fault_injection(int what) {
-    PMT_REQUIRE(what >= 0 && what <= 3, PMT_INVALID_ARGUMENT, "set_fault_injection: unknown fault");
+    PMT_REQUIRE(what >= 0 && what <= 7, PMT_INVALID_ARGUMENT, "set_fault_injection: unknown fault");
     pmt::dma::g_fault.store(what);
     return PMT_OK;
 }

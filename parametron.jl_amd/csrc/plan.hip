@@ -45,6 +45,9 @@ struct pmt_plan {
     bool fusion = true;
     int fused_groups = 0, fused_nodes = 0, fused_phases = 0, fused_workgroups = 0;
     int *barrier_error = nullptr;            // page-locked word a run on several workgroups stores 1 into when its grid barrier times out
+    std::vector<std::pair<void *, size_t>> fused_tables;      // node tables + barrier words of the fused runs: replaced as a whole by build_exec
+    hipEvent_t multi_done = nullptr;         // recorded behind this plan's latest launch on several workgroups (device_multi_registry)
+    bool multi_pending = false;
     bool single_workgroup_runs = false;      // a graph replays its runs with ONE workgroup (the grid barrier's base is a kernel argument)
     std::vector<char> lanes;          // per tape entry: 0 = the plan's stream, 1 = the side lane, 2 = the FRONT of the side lane, 3 = the front of
                                       // the side lane WITHOUT the fork from the plan's stream (pmt_plan_set_lane)
@@ -72,6 +75,64 @@ struct pmt_plan {
     std::vector<hipEvent_t> fetch_events;
     bool no_graph = false;            // the tape holds an entry whose replay has host-side effects (a host delivery): launches only
 };
+
+namespace pmt { int small_plan_occupancy(); }
+
+// A fused run on several workgroups waits at a grid barrier: every workgroup of its grid must be ON the chip.  One such grid is at most
+// `multi_workgroup_limit` workgroups (half of what the stream's CUs hold of this kernel); two of them at once — two plans replaying on
+// two streams, host threads — could still each hold part of a small partition (CPX: 32 CUs) and wait for the rest until the 2 s bound.
+// The library therefore keeps at most ONE multi-workgroup run in flight per device: the plans of a device that own such runs are
+// registered here, a launch on several workgroups is made under the device's mutex, and when another registered plan's latest such launch
+// has not completed yet (hipEventQuery), THIS launch goes out on one workgroup (same node table, workgroup barriers only: same results).
+// Kernels of other processes or libraries are beyond this registry: the clamp, the bounded wait and the error word cover those.
+namespace {
+struct MultiRegistry { std::mutex mu; std::vector<pmt_plan *> plans; };
+MultiRegistry &multi_registry(int device) {
+    static std::mutex mu;
+    static std::unordered_map<int, std::unique_ptr<MultiRegistry>> regs;
+    std::lock_guard<std::mutex> lock(mu);
+    auto &r = regs[device];
+    if (!r) r.reset(new MultiRegistry);
+    return *r;
+}
+void multi_unregister(pmt_plan *plan) {
+    MultiRegistry &r = multi_registry(plan->device);
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.plans.erase(std::remove(r.plans.begin(), r.plans.end(), plan), r.plans.end());
+}
+// workgroups of 1024 threads the CUs this stream may use hold at once, halved
+int multi_workgroup_limit(pmt_plan *plan) {
+    int cus = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, plan->device) == hipSuccess) cus = prop.multiProcessorCount; else (void)hipGetLastError();
+    uint32_t mask[16] = {0};
+    if (hipExtStreamGetCUMask(plan->stream, 16, mask) == hipSuccess) {
+        int bits = 0;
+        for (uint32_t m : mask) bits += __builtin_popcount(m);
+        if (bits > 0 && (cus == 0 || bits < cus)) cus = bits;
+    } else (void)hipGetLastError();
+    per_cu = pmt::small_plan_occupancy();
+    return std::max(1, cus * std::max(1, per_cu) / 2);
+}
+// under the registry's mutex: may this plan launch a run on several workgroups now?
+bool multi_may_launch(MultiRegistry &r, pmt_plan *plan) {
+    for (pmt_plan *other : r.plans) {
+        if (other == plan || !other->multi_pending) continue;
+        const hipError_t e = hipEventQuery(other->multi_done);
+        if (e == hipSuccess) { other->multi_pending = false; continue; }
+        (void)hipGetLastError();
+        return false;
+    }
+    return true;
+}
+int check_barrier_error(pmt_plan *plan) {
+    if (plan->barrier_error && __atomic_exchange_n(plan->barrier_error, 0, __ATOMIC_ACQ_REL))
+        return pmt::fail(PMT_HIP_ERROR, "small plan: a workgroup waited 2 s at the grid barrier of a fused run (its workgroups were not all running); "
+                                        "the outputs of this re-evaluation are invalid");
+    return PMT_OK;
+}
+}  // namespace
+
 
 namespace pmt {
 
@@ -309,6 +370,9 @@ extern "C" int pmt_plan_destroy(pmt_plan *plan) {
     if (plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
     for (void *p : plan->allocations) (void)hipFree(p);
+    for (auto &t : plan->fused_tables) (void)hipFree(t.first);
+    multi_unregister(plan);
+    if (plan->multi_done) (void)hipEventDestroy(plan->multi_done);
     if (plan->barrier_error) (void)hipHostFree(plan->barrier_error);
     if (plan->owns_stream) (void)hipStreamDestroy(plan->stream);
     delete plan;
@@ -535,10 +599,14 @@ extern "C" int pmt_plan_synchronize(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_synchronize: null plan");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
     PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
-    if (plan->barrier_error && __atomic_exchange_n(plan->barrier_error, 0, __ATOMIC_ACQ_REL))
-        return fail(PMT_HIP_ERROR, "small plan: a workgroup waited 2 s at the grid barrier of a fused run (its workgroups were not all running); "
-                                   "the outputs of this re-evaluation are invalid");
-    return PMT_OK;
+    return check_barrier_error(plan);
+}
+
+// For callers that wait for the plan's stream by other means (hipStreamSynchronize, an event, a fetch wait of their own): the plan's
+// device-side error state behind such a wait — today the time-out word of a fused run's grid barrier.  PMT_OK, or the error (cleared).
+extern "C" int pmt_plan_check(pmt_plan *plan) {
+    PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_check: null plan");
+    return check_barrier_error(plan);
 }
 
 extern "C" int pmt_plan_begin_record(pmt_plan *plan) {
@@ -562,15 +630,46 @@ int small_max_nodes();
 }
 
 // exec := tape, with every run of >= 2 consecutive small nodes on the plan's own lane replaced by one interpreter launch (small.hip).  The
-// node tables live in plan-owned device memory, written here once (setup, not the solve path).
+// node tables live in plan-owned device memory, written here once (setup, not the solve path); a rebuild (pmt_plan_set_fusion, a graph's
+// single-workgroup form, a re-record) frees the previous tables first, and the new exec replaces the old one only when it is complete.
+static int build_exec_into(pmt_plan *plan, std::vector<pmt::Launch> &exec, std::vector<char> &exec_lanes, std::vector<std::pair<void *, size_t>> &tables);
 static int build_exec(pmt_plan *plan) {
-    plan->exec.clear(); plan->exec_lanes.clear();
+    PMT_HIP_CHECK(hipSetDevice(plan->device));
+    if (!plan->fused_tables.empty()) {                 // the launches that read the old tables must be through with them
+        PMT_HIP_CHECK(hipStreamSynchronize(plan->stream));
+        for (auto &t : plan->fused_tables) { (void)hipFree(t.first); plan->bytes -= t.second; }
+        plan->fused_tables.clear();
+        plan->exec.clear(); plan->exec_lanes.clear();   // (they point into the freed tables)
+    }
+    std::vector<pmt::Launch> exec;
+    std::vector<char> exec_lanes;
+    std::vector<std::pair<void *, size_t>> tables;
+    const int rc = build_exec_into(plan, exec, exec_lanes, tables);
+    if (rc) {                                          // half built: nothing of it is kept, the plan replays its tape unfused
+        for (auto &t : tables) (void)hipFree(t.first);
+        plan->exec = plan->tape; plan->exec_lanes = plan->lanes;
+        plan->fused_groups = 0; plan->fused_nodes = 0; plan->fused_phases = 0; plan->fused_workgroups = 0;
+        return rc;
+    }
+    plan->exec.swap(exec); plan->exec_lanes.swap(exec_lanes);
+    for (auto &t : tables) plan->bytes += t.second;
+    plan->fused_tables.swap(tables);
+    if (plan->fused_workgroups > 1) {
+        MultiRegistry &r = multi_registry(plan->device);
+        std::lock_guard<std::mutex> lock(r.mu);
+        if (std::find(r.plans.begin(), r.plans.end(), plan) == r.plans.end()) r.plans.push_back(plan);
+        if (!plan->multi_done) PMT_HIP_CHECK(hipEventCreateWithFlags(&plan->multi_done, hipEventDisableTiming));
+    } else multi_unregister(plan);
+    return PMT_OK;
+}
+
+static int build_exec_into(pmt_plan *plan, std::vector<pmt::Launch> &out_exec, std::vector<char> &out_lanes, std::vector<std::pair<void *, size_t>> &tables) {
     plan->fused_groups = 0; plan->fused_nodes = 0; plan->fused_phases = 0; plan->fused_workgroups = 0;
+    const int wg_limit = multi_workgroup_limit(plan);
     const size_t n = plan->tape.size();
     auto small = [&](size_t i) {
         return plan->fusion && plan->node_of[i] >= 0 && plan->lanes[i] == 0 && plan->nodes[(size_t)plan->node_of[i]].work <= pmt::SMALL_NODE_WORK_MAX;
     };
-    PMT_HIP_CHECK(hipSetDevice(plan->device));
     for (size_t i = 0; i < n;) {
         size_t j = i;
         int64_t work = 0;
@@ -585,8 +684,8 @@ static int build_exec(pmt_plan *plan) {
             ++j;
         }
         if (j - i < 2) {
-            plan->exec.push_back(plan->tape[i]);
-            plan->exec_lanes.push_back(plan->lanes[i]);
+            out_exec.push_back(plan->tape[i]);
+            out_lanes.push_back(plan->lanes[i]);
             ++i;
             continue;
         }
@@ -607,15 +706,14 @@ static int build_exec(pmt_plan *plan) {
         void *table = nullptr;
         hipError_t e = hipMalloc(&table, table_bytes + 64);
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-        plan->allocations.push_back(table);
-        plan->bytes += table_bytes + 64;
+        tables.emplace_back(table, table_bytes + 64);
         PMT_HIP_CHECK(hipMemcpy(table, image.data(), image.size(), hipMemcpyHostToDevice));
         PMT_HIP_CHECK(hipMemset(static_cast<char *>(table) + table_bytes, 0, 64));
         unsigned long long syncmask = 0, narrowmask = 0;
         pmt::small_plan_masks(group.data(), count, &syncmask, &narrowmask);
         int64_t group_work = 0;
         for (const pmt::SmallNode &nd : group) group_work += nd.work;
-        const int wgs = plan->single_workgroup_runs ? 1 : pmt::small_plan_workgroups(group_work);
+        const int wgs = plan->single_workgroup_runs ? 1 : std::min(wg_limit, pmt::small_plan_workgroups(group_work));
         unsigned long long *bar = reinterpret_cast<unsigned long long *>(static_cast<char *>(table) + table_bytes);
         if (wgs > 1 && !plan->barrier_error) {
             PMT_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&plan->barrier_error), 64, hipHostMallocDefault));
@@ -623,18 +721,26 @@ static int build_exec(pmt_plan *plan) {
         }
         int *barrier_error = plan->barrier_error;
         const unsigned long long per_launch = (unsigned long long)__builtin_popcountll(syncmask) * (unsigned long long)wgs;
-        std::shared_ptr<unsigned long long> launches = std::make_shared<unsigned long long>(0);      // of this run so far: the counter's base
+        // arrivals at the run's counter so far = the next launch's base (a launch on ONE workgroup never touches the counter)
+        std::shared_ptr<unsigned long long> arrivals = std::make_shared<unsigned long long>(0);
         plan->fused_workgroups = std::max(plan->fused_workgroups, wgs);
-        plan->exec.push_back([=](hipStream_t s) {
-            unsigned long long base = *launches * per_launch;
+        out_exec.push_back([=](hipStream_t s) {
+            if (wgs == 1) return pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, 1, bar, 0, barrier_error, 0, s);
+            MultiRegistry &reg = multi_registry(plan->device);
+            std::lock_guard<std::mutex> lock(reg.mu);                 // one multi-workgroup run in flight per device (see multi_registry)
+            const bool multi = multi_may_launch(reg, plan) && !(pmt::dma::fault_injection() & 4);
+            unsigned long long base = *arrivals;
             long long bound = 200000000LL;                            // 2 s of 100 MHz ticks
             // test hook (pmt_set_fault_injection(2)): every barrier of this launch waits for one arrival more than there will be, for 20 ms
-            if (wgs > 1 && (pmt::dma::fault_injection() & 2)) { base += 1; bound = 2000000LL; }
-            const int rc = pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, wgs, bar, base, barrier_error, bound, s);
-            if (!rc) ++*launches;                                     // (a launch that was not enqueued does not arrive at the counter)
+            if (multi && (pmt::dma::fault_injection() & 2)) { base += 1; bound = 2000000LL; }
+            const int rc = pmt::launch_small_plan(table, count, words.data(), (int)words.size(), syncmask, narrowmask, multi ? wgs : 1, bar, base, barrier_error, bound, s);
+            if (!rc && multi) {
+                *arrivals += per_launch;                              // (a launch that was not enqueued does not arrive at the counter)
+                if (reg.plans.size() > 1 && plan->multi_done && hipEventRecord(plan->multi_done, s) == hipSuccess) plan->multi_pending = true;
+            }
             return rc;
         });
-        plan->exec_lanes.push_back(0);
+        out_lanes.push_back(0);
         plan->fused_groups += 1;
         plan->fused_nodes += count;
         i = j;
@@ -778,7 +884,8 @@ extern "C" int pmt_plan_record_fetch_2d(pmt_plan *plan, void *host_dst, size_t d
 extern "C" int pmt_plan_fetch_synchronize(pmt_plan *plan) {
     PMT_REQUIRE(plan, PMT_INVALID_ARGUMENT, "plan_fetch_synchronize: null plan");
     PMT_HIP_CHECK(hipSetDevice(plan->device));
-    return pmt::fetch_synchronize(plan->stream);
+    if (int rc = pmt::fetch_synchronize(plan->stream)) return rc;
+    return check_barrier_error(plan);          // (the fetched buffers were written by the replay whose fused runs report here)
 }
 
 extern "C" int pmt_plan_set_lane(pmt_plan *plan, int lane) {

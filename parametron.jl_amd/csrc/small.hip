@@ -614,6 +614,13 @@ int launch_small_plan(const void *device_table, int count, const uint64_t *const
 
 // workgroups of a fused run: one up to 8192 elements of work (README Example 1: ~700; its launch is then the single-workgroup kernel of
 // before, bit for bit and cycle for cycle), one more per 4096 beyond, 32 at most
+// workgroups of small_plan_kernel one CU holds (the occupancy calculator's answer for 1024 threads and the kernel's LDS / registers)
+int small_plan_occupancy() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, small_plan_kernel, 1024, 0) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    return std::max(1, n);
+}
+
 int small_plan_workgroups(int64_t work) { return (int)std::min<int64_t>(32, std::max<int64_t>(1, work / 4096)); }
 
 }  // namespace pmt

@@ -101,6 +101,33 @@ def constant_in_the_library_order(r, n, b, sign=-1):
             seq = seq + v
         return order.value, seq
     G, MR = groups.value, stage.value
+    if order.value == 4:
+        # the stream form (gram_stream_kernel): iterations of MR rows dealt out to the 4 G WAVES (wave 4 g + w: iterations 4 g + w, + 4 G, ..);
+        # contraction slot lk of a wave adds rows 8 i + 2 lk, + 1 of its iterations in order; slots: (0 + 2) + (1 + 3); waves of a workgroup in
+        # order; workgroups in 16 interleaved slices, then the slices in order
+        Wv = 4 * G
+        nit = -(-r // MR)
+        sq = np.zeros((nit + Wv) * MR)
+        sq[:r] = nb * nb
+        slots = np.zeros((Wv, 4))
+        wi = np.arange(Wv)
+        for k in range(-(-nit // Wv)):
+            base = (wi + k * Wv) * MR
+            live = (wi + k * Wv) < nit
+            for i in range(MR // 8):
+                idx = base[:, None] + 8 * i + 2 * np.arange(4)[None, :]
+                slots = np.where(live[:, None], (slots + sq[idx]) + sq[idx + 1], slots)
+        wave = (slots[:, 0] + slots[:, 2]) + (slots[:, 1] + slots[:, 3])
+        wave = wave.reshape(G, 4)
+        part = ((wave[:, 0] + wave[:, 1]) + wave[:, 2]) + wave[:, 3]
+        slices = np.zeros(16)
+        for g0 in range(0, G, 16):
+            seg = part[g0:g0 + 16]
+            slices[:len(seg)] = slices[:len(seg)] + seg
+        total = slices[0]
+        for t in range(1, 16):
+            total = total + slices[t]
+        return order.value, float(total)
     L = 16 if order.value == 3 else 8                                  # row-pair lanes walking down a column piece of 2 L rows
     nst = -(-r // MR)
     sq = np.zeros((nst + G) * MR)

@@ -257,8 +257,9 @@ def test_constant_order_is_host_arithmetic(lib):
     assert (o, s) == (2, 32) and g == 512
     o, g, s = order(8192, 128)
     assert o == 2 and g == 8192 // 64                           # at least 64 rows per workgroup
-    assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256)      # narrow panels: 32 columns x 128-row stages, 16 x 256
-    assert order(1 << 20, 64) == (2, 512, 64)
+    # narrow panels (<= 64 columns): the stream form (order 4) — iterations of 32 (64 columns: 16) rows dealt out to the waves of <= 512 workgroups
+    assert order(5000, 17) == (4, 40, 32) and order(1024, 1) == (4, 8, 32) and order(100, 40) == (4, 2, 16)
+    assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
     # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
     assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(300, 300)[0] == 2
     assert order(4096, 256)[0] == 2 and order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32)

@@ -544,3 +544,107 @@ def test_grid_barrier_timeout_is_reported_by_synchronize():
     g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
     g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), good)
     g.call("pmt_plan_destroy", plan)
+
+
+def _large_run_plan(g, stream=None, seed=5):
+    """a recorded run of ~45000 elements (fills + affine assemble): several workgroups when replayed as launches"""
+    r, n = 150, 100
+    s = stream if stream is not None else g.stream()
+    dA, db = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    res, rc = g.empty_terms(r * n, g.LT), g.empty_f64(r)
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, s, C.byref(plan))
+    rec = C.c_void_p(g.lib().pmt_plan_recording_stream(plan))
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_fill_uniform_matrix_f64", g.ptr(dA), r, n, r, C.c_uint64(seed), 1.0, rec)
+    g.call("pmt_fill_uniform_f64", g.ptr(db), r, C.c_uint64(seed + 1), 1.0, rec)
+    g.call("pmt_affine_assemble_f64", g.ptr(dA), r, r, n, g.ptr(xvar), g.ptr(db), -1, g.ptr(res), g.ptr(rc), rec)
+    g.call("pmt_plan_end_record", plan)
+    return plan, (dA, db, xvar, res, rc), (r, n)
+
+
+def test_a_multi_workgroup_run_launched_on_one_workgroup_gives_the_same_bits():
+    """while another plan's multi-workgroup run is in flight on the device a run goes out on ONE workgroup (fault injection 4
+    forces that path).  Launches on several / one / several workgroups in turn: the same bits every time, and the grid barrier's counter stays
+    consistent (a single-workgroup launch never arrives at it)"""
+    import gpu_util as g
+    plan, (dA, db, xvar, res, rc), (r, n) = _large_run_plan(g)
+    assert g.lib().pmt_plan_fused_workgroups(plan) > 1
+    g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+    good, goodc = g.terms_to_host(res, r * n, g.LT).copy(), g.f64_to_host(rc, r).copy()
+    try:
+        for inject in (4, 0, 4, 4, 0, 0):
+            g.call("pmt_set_fault_injection", inject)
+            res.zero_(); rc.zero_()
+            g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+            g.assert_terms_equal(g.terms_to_host(res, r * n, g.LT), good)
+            assert g.same_bits(g.f64_to_host(rc, r), goodc)
+    finally:
+        g.call("pmt_set_fault_injection", 0)
+    g.call("pmt_plan_destroy", plan)
+
+
+def test_two_plans_with_multi_workgroup_runs_on_two_streams():
+    """two plans replaying fused runs on several workgroups from two streams, interleaved without synchronisation in between: at most one
+    multi-workgroup run is in flight per device (the other launch goes out on one workgroup) — every result right, no barrier time-out"""
+    import gpu_util as g
+    s2 = torch.cuda.Stream()
+    plan1, bufs1, (r, n) = _large_run_plan(g, seed=5)
+    with torch.cuda.stream(s2):
+        plan2, bufs2, _ = _large_run_plan(g, stream=C.c_void_p(s2.cuda_stream), seed=9)
+    torch.cuda.synchronize()
+    want = {}
+    for name, plan, bufs in (("1", plan1, bufs1), ("2", plan2, bufs2)):
+        g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+        want[name] = (g.terms_to_host(bufs[3], r * n, g.LT).copy(), g.f64_to_host(bufs[4], r).copy())
+    assert not np.array_equal(want["1"][0]["coeff"], want["2"][0]["coeff"])
+    for _ in range(20):
+        for _ in range(5):
+            g.call("pmt_plan_update", plan1); g.call("pmt_plan_update", plan2)
+        for name, plan, bufs in (("1", plan1, bufs1), ("2", plan2, bufs2)):
+            g.call("pmt_plan_synchronize", plan)
+            g.assert_terms_equal(g.terms_to_host(bufs[3], r * n, g.LT), want[name][0])
+            assert g.same_bits(g.f64_to_host(bufs[4], r), want[name][1])
+    g.call("pmt_plan_destroy", plan1); g.call("pmt_plan_destroy", plan2)
+
+
+def test_plan_check_reports_a_barrier_timeout_behind_a_foreign_wait():
+    """a caller that waits for the plan's stream itself (torch.cuda.synchronize here) asks pmt_plan_check for the device-side error state"""
+    import gpu_util as g
+    from parametron_jl_amd import _lib
+    plan, (dA, db, xvar, res, rc), (r, n) = _large_run_plan(g)
+    g.call("pmt_plan_update", plan); torch.cuda.synchronize()
+    g.call("pmt_plan_check", plan)                                       # clean
+    try:
+        g.call("pmt_set_fault_injection", 2)
+        g.call("pmt_plan_update", plan)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.HipError, match="grid barrier"):
+            g.call("pmt_plan_check", plan)
+    finally:
+        g.call("pmt_set_fault_injection", 0)
+    g.call("pmt_plan_check", plan)                                       # cleared by the report
+    g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+    g.call("pmt_plan_destroy", plan)
+
+
+def test_toggling_fusion_does_not_grow_the_plan():
+    """build_exec used to allocate a new node table per fused run at every rebuild and keep the old ones until pmt_plan_destroy"""
+    import gpu_util as g
+    plan, bufs, (r, n) = _large_run_plan(g)
+    L = g.lib()
+    L.pmt_plan_bytes_allocated.restype = C.c_size_t
+    fused = int(L.pmt_plan_bytes_allocated(plan))
+    g.call("pmt_plan_set_fusion", plan, 0)
+    unfused = int(L.pmt_plan_bytes_allocated(plan))
+    assert unfused < fused
+    for _ in range(10):
+        g.call("pmt_plan_set_fusion", plan, 1)
+        assert int(L.pmt_plan_bytes_allocated(plan)) == fused
+        g.call("pmt_plan_update", plan)
+        g.call("pmt_plan_set_fusion", plan, 0)
+        assert int(L.pmt_plan_bytes_allocated(plan)) == unfused
+    g.call("pmt_plan_set_fusion", plan, 1)
+    g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+    g.call("pmt_plan_destroy", plan)

@@ -221,6 +221,7 @@ def main():
     ap.add_argument("sections", nargs="*", default=[], help="tall mid host_api pack (default: all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bench_study.json"))
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--shapes", default="", help="tall: rows x columns list instead of the table, e.g. 1048576x16,4096x512")
     a = ap.parse_args()
     import torch
     import parametron_jl_amd as P
@@ -229,7 +230,8 @@ def main():
     want = a.sections or ["tall", "mid", "host_api", "pack"]
     out = {}
     if "tall" in want:
-        out["tall"] = guarded(config_tall, torch, _lib, a.steps)
+        shapes = [tuple(int(v) for v in x.split("x")) for x in a.shapes.split(",") if x] or None
+        out["tall"] = guarded(config_tall, torch, _lib, a.steps, shapes)
     if "mid" in want:
         out["mid"] = guarded(config_mid, torch, P)
     if "host_api" in want:
@@ -240,7 +242,8 @@ def main():
     json.dump(out, open(a.out, "w"), indent=1)
     for k, v in (out.get("tall") or {}).items():
         if isinstance(v, dict) and "node_ms" in v:
-            print("%-14s %9.1f us  frac %.3f (%s)  mfma %.3f hbm %.3f  launches %d" % (k, v["node_ms"] * 1e3, v["frac"], v["binding"], v["mfma_frac"], v["hbm_frac"], v["launches"]))
+            print("%-14s %9.1f us  frac %.3f (%s)  mfma %.3f hbm %.3f  %s" % (k, v["node_ms"] * 1e3, v["frac"], v["binding"], v["mfma_frac"], v["hbm_frac"],
+                                                                              {kk.replace("_kernel", ""): round(t * 1e3, 1) for kk, t in v["kernels_ms"].items()}))
     for k, v in (out.get("mid") or {}).items():
         print(k, v)
     for k, v in (out.get("host_api") or {}).items():
