@@ -38,7 +38,7 @@ int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t d
 void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0);
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0, const SKLin *lin = nullptr);
 bool gram_tall_applies(int64_t rows, int64_t cols);
 bool gram_tiny(int64_t rows, int64_t cols);
 int launch_small_one(const SmallNode &nd, hipStream_t s);
@@ -124,6 +124,17 @@ static bool constant_chained(int64_t rows, int64_t cols) {
     const double nt = (double)cdiv(std::max<int64_t>(cols, 1), GT);
     const double contraction_ms = (0.096 + 0.276 * (double)rows / 1024.0) * (nt * (nt + 1) / 2) / 528.0;
     return 0.07e-3 * (double)rows > 0.5 * contraction_ms;
+}
+
+// MID-SIZE wide shapes (129 .. 1024 columns, 32 .. 4096 rows, at most 2^21 elements): the sizes the reference is used at with a few hundred
+// variables.  Node us against the tall + strict form, same box (profiles/r06_gram_mid.txt): 300 x 300 35.7 -> 23.6, 100 x 1000 42.2 -> 29.9,
+// 1024 x 512 44.1 -> 33.1, 2048 x 512 47.6 -> 45.3, 4096 x 512 62.3 -> 54.8, 2048 x 1024 equal; beyond, the diagonal tiles' own kernel wins
+// (1024 x 2048 133 against 149, 128 x 2048 62 against 72) and one wave per column is too little for q (8192 x 256: 47 against 91).
+bool gram_mid_applies(int64_t rows, int64_t cols) {
+#ifdef PMT_NO_MID
+    return false;
+#endif
+    return gram_tall_diag_applies(rows, cols) && cols <= 1024 && rows >= 32 && rows <= 4096 && rows * cols <= (int64_t)1 << 21;
 }
 
 static int linear_splits(int64_t rows, int64_t cols) {
@@ -438,6 +449,12 @@ using namespace pmt;
 
 extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows) {
     PMT_REQUIRE(rows >= 0 && cols >= 0 && order, PMT_INVALID_ARGUMENT, "quad_gram_constant_order: bad argument");
+    if (cols > 0 && gram_mid_applies(rows, cols)) {          // the fix-up launch's last workgroup: 512 strided chains, wave trees, waves in order
+        *order = 5;
+        if (groups) *groups = 1;
+        if (stage_rows) *stage_rows = 512;
+        return PMT_OK;
+    }
     const bool tall = cols > 0 && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
     *order = tall ? (gram_tall_run_lanes(cols) == 4 ? 4 : gram_tall_run_lanes(cols) == 16 ? 3 : 2) : (constant_chained(rows, cols) ? 1 : 0);
     if (groups) *groups = tall ? gram_tall_groups(rows, cols) : (*order == 1 ? 2048 : 1);
@@ -666,6 +683,22 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (!rc && defer_const) side->deferred.push_back(const_part);
         if (side && !tall_form) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
+            if (tall_form && gram_mid_applies(rows, cols)) {
+                // MID-SIZE wide shapes: every tile (diagonal ones included) in ONE stream-K launch with fine units, and one fix-up launch that
+                // also carries the affine part (gram_sk.hip: sk_lin_role) — two launches instead of four (tall + fix-up + strict stream-K + fix-up)
+                const int64_t nt = cdiv(cols, GT);
+                const SKLin lin{(b && sign) ? b : nullptr, sign, reinterpret_cast<LT *>(out_lin), out_const};
+                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt + 1) / 2, nullptr, 0, nullptr, s, 0, &lin);
+                if (!rc && side && side->in_replay) {          // side-lane entries behind this node may read its affine part (see below)
+                    PMT_HIP_CHECK(hipEventRecord(side->fork, s));
+                    PMT_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+                }
+                if (!rc && deliver) {
+                    char *cb = static_cast<char *>(side->counters);
+                    dma::Signal word = use_engine ? sig->dep[0] : dma::Signal{0, reinterpret_cast<int64_t *>(cb + FLAGS_OFFSET)};
+                    rc = dma::launch_signal_store(word, s);
+                }
+            } else
             if (tall_form) {
                 rc = launch_gram_tall(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace, s);
                 // a plan's side-lane entries recorded behind this node may read its AFFINE part (the hand-off's q gather; plan.hip `replay`): with

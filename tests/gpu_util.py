@@ -101,6 +101,24 @@ def constant_in_the_library_order(r, n, b, sign=-1):
             seq = seq + v
         return order.value, seq
     G, MR = groups.value, stage.value
+    if order.value == 5:
+        # mid-size wide shapes (gram_sk.hip: sk_lin_role): thread t of 512 adds rows t, t + 512, .. in order; per wave the __shfl_down tree
+        # 32, 16, .., 1; the eight waves in order
+        T = MR
+        sq = np.zeros(-(-max(r, 1) // T) * T)
+        sq[:r] = nb * nb
+        lanes = np.zeros(T)
+        for k in range(len(sq) // T):
+            lanes = lanes + sq[k * T:(k + 1) * T]
+        w = lanes.reshape(T // 64, 64)
+        h = 32
+        while h >= 1:
+            w = np.concatenate([w[:, :h] + w[:, h:2 * h], w[:, h:]], axis=1)     # lane i += lane i + h for i < h (the others are not read again)
+            h //= 2
+        total = w[0, 0]
+        for k in range(1, T // 64):
+            total = total + w[k, 0]
+        return order.value, float(total)
     if order.value == 4:
         # the stream form (gram_stream_kernel): iterations of MR rows dealt out to the 4 G WAVES (wave 4 g + w: iterations 4 g + w, + 4 G, ..);
         # contraction slot lk of a wave adds rows 8 i + 2 lk, + 1 of its iterations in order; slots: (0 + 2) + (1 + 3); waves of a workgroup in

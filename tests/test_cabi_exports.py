@@ -261,8 +261,12 @@ def test_constant_order_is_host_arithmetic(lib):
     assert order(5000, 17) == (4, 40, 32) and order(1024, 1) == (4, 8, 32) and order(100, 40) == (4, 2, 16)
     assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
     # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
-    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(300, 300)[0] == 2
-    assert order(4096, 256)[0] == 2 and order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32)
+    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(31, 300)[0] == 2
+    assert order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32) and order(4090, 1000)[0] == 2
+    # mid-size wide shapes (129 .. 1024 columns, 32 .. 4096 rows, <= 2^21 elements): one stream-K launch over all tiles, the constant by the last
+    # workgroup of the fix-up launch (order 5: 512 strided chains)
+    assert order(300, 300) == (5, 1, 512) and order(4096, 512) == (5, 1, 512) and order(1024, 2048)[0] == 2 and order(100, 1000)[0] == 5 and order(8192, 256)[0] == 2
+    assert order(4096, 256)[0] == 5 and order(70, 130)[0] == 5 and order(4097, 512)[0] == 2
     with pytest.raises(lib.ArgumentError):
         lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
 
