@@ -312,6 +312,15 @@ def test_config3_full_size_inequalities_bounds_and_manual_parameters():
     assert np.array_equal(gc.terms["var"].reshape(mi, n)[7], vm)
     assert np.array_equal(lo.terms["coeff"], np.ones(n)) and np.array_equal(lo.terms["var"], vm) and np.array_equal(lo.constants, 0.0 - ld)
     assert np.array_equal(up.constants, 0.0 - ud) and np.array_equal(up.terms["out"], np.arange(1, n + 1))
+    # ... and byte for byte against the ORACLE at full size: the reference's matvecmul! + vecsubtract! (src/functions.jl:775-798,
+    # 751-764) / `Variable - Number` rows (test/model.jl:162-163) followed by update!(::MOI.VectorAffineFunction) (src/moi_interop.jl:64-81)
+    from oracle import oracle as O
+    xi = np.arange(1, n + 1, dtype=np.int64)                              # Variable.index of x (1-based, creation order)
+    for got, want in ((gc, O.AffVec(mi).vecsubtract(O.AffVec(mi).matvecmul_vars(Gd, xi), hd)),
+                      (lo, O.AffVec(n).vecsubtract(xi, ld)), (up, O.AffVec(n).vecsubtract(xi, ud))):
+        wt, wc = want.moi(vm)
+        assert got.terms.dtype == wt.dtype and np.array_equal(got.terms.view(np.int64), wt.view(np.int64))
+        assert np.array_equal(got.constants.view(np.int64), wc.view(np.int64))
     f = model.objective.f
     assert model.objective.mode == "canonical" and len(f.quadratic_terms) == n * (n + 1) // 2
     Ah = A()

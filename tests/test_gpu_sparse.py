@@ -76,6 +76,19 @@ def test_config5_size_properties():
     assert t["coeff"].sum() == pytest.approx(data.sum(), rel=1e-12)
     csr = Cs.tocsr()
     assert np.array_equal(t["coeff"], csr.data) and np.array_equal(t["var"], csr.indices + 1)
+    # a ROW BAND of the full-size block against the ORACLE, byte for byte: the reference's dense matvecmul! + vecsubtract!
+    # on the densified band and update!(::MOI.VectorAffineFunction) (src/moi_interop.jl:64-81), minus the structural zeros; the band straddles
+    # the kernel's 128-row block boundary
+    f = list(model.constraints)[0].f
+    r0, r1 = 1000, 1160
+    band = csr[r0:r1].toarray()
+    xi = np.arange(1, n + 1, dtype=np.int64)
+    wt, wc = O.AffVec(r1 - r0).vecsubtract(O.AffVec(r1 - r0).matvecmul_vars(band, xi), d()[r0:r1]).moi(model.model_var_to_optimizer)
+    wt = wt[wt["coeff"] != 0.0]
+    wt["out"] += r0                                                  # the band's rows are rows r0+1 .. r1 of the function
+    lo_, hi_ = int(csr.indptr[r0]), int(csr.indptr[r1])
+    assert hi_ - lo_ == len(wt) and np.array_equal(f.terms[lo_:hi_].view(np.int64), wt.view(np.int64))
+    assert np.array_equal(f.constants[r0:r1].view(np.int64), wc.view(np.int64))
 
 
 @pytest.mark.parametrize("m,n,density,nslab", [(37, 61, 0.08, 8), (5, 3, 0.9, 8), (200, 1000, 0.3, 8), (64, 500, 0.02, 3), (9, 40, 0.0, 8), (300, 2100, 0.2, 8), (1, 700, 0.5, 8)])
