@@ -174,6 +174,7 @@ int pmt_quad_expand_f64(int64_t rows,
  * 128-column tile, out_lin and out_const from ONE pass over A; the strictly upper tiles from one stream-K launch); tiny shapes recorded
  * into a plan are nodes of its one-launch interpreter (csrc/small.hip); wider shapes (config 2) the stream-K node with the two
  * reductions on a side stream.
+ * A is read as lda x cols doubles: a kernel may read (and ignore) the padding rows rows .. lda - 1 of a column, the last one included.
  * Requires xvar strictly increasing (distinct variables in sorted order — what Variable(model) yields);
  * moi == 0 keeps native indices (no varmap) but the same coefficients as the MOI form are NOT produced:
  *   native canonical form has diagonal coefficient (A'A)[j,j] and off-diagonal 2*(A'A)[j,k].
@@ -189,6 +190,12 @@ size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
  *            `stage_rows` rows; per stage eight row-pair lanes (rows 16 j + 2 p, + 1) add their squares in row order, an 8-lane tree
  *            ((0+4)+(2+6))+((1+5)+(3+7)) closes a workgroup, the workgroups are added in 16 interleaved slices, then the slices
  *   order 3  the same with SIXTEEN row-pair lanes (rows 32 j + 2 p, + 1; a 16-lane tree): the 16-column panel, cols <= 16
+ *            (cols <= 64: below 32768 rows)
+ *   order 4  narrow panels, cols <= 64, from 32768 rows (gram_stream_kernel): iterations of `stage_rows` rows dealt out to the 4 * `groups` WAVES (wave
+ *            4 g + w: iterations 4 g + w, + 4 * groups, ..); contraction slot k of a wave adds rows 8 i + 2 k, + 1 of its iterations in order;
+ *            slots (0 + 2) + (1 + 3); the four waves of a workgroup in order; workgroups in 16 interleaved slices, then the slices
+ *   order 5  mid-size wide shapes (129 .. 1024 columns, 32 .. 4096 rows, at most 2^21 elements): `stage_rows` = 512 strided chains (thread
+ *            t adds rows t, t + 512, ..), a shuffle tree (32, 16, .., 1) per 64 threads, the eight results in order
  * (tests/gpu_util.py restates every order bit for bit.)
  * Every order is within (rows / 2048 + 2048) * eps / 2 relative of the exact sum for same-signed terms: far inside the 1e-12 parity bar. */
 int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *order, int *groups, int *stage_rows);
@@ -515,6 +522,12 @@ size_t pmt_plan_bytes_allocated(const pmt_plan *plan);
 /* page-locked host memory (e.g. for the MOI function buffers pmt_plan_fetch writes into); not tied to a plan */
 int pmt_host_alloc(size_t bytes, void **out_host_ptr);
 int pmt_host_free(void *host_ptr);
+/* memory the host language owns (the `terms` Vector of an MOI function, src/moi_interop.jl:36-37,65,70, after its resize!) page-locked
+ * and made device-visible IN PLACE: *out_device_ptr is what a recorded entry point is given as its output pointer — the kernel stores
+ * straight into the host array (small models: a few KB over PCIe from inside the one launch; no device twin, no fetch).  The array must
+ * stay alive and keep its size until pmt_host_unregister. */
+int pmt_host_register(void *host_ptr, size_t bytes, void **out_device_ptr);
+int pmt_host_unregister(void *host_ptr);
 /* asynchronous copies on the plan's stream */
 int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
 int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);
@@ -631,6 +644,34 @@ int pmt_plan_fused_phases(const pmt_plan *plan);
  * run is in flight per device: while another plan's is, a launch goes out on one workgroup (same results).  A grid barrier that still
  * times out (kernels of other processes holding the CUs) is reported by pmt_plan_synchronize / pmt_plan_fetch_synchronize / pmt_plan_check. */
 int pmt_plan_fused_workgroups(const pmt_plan *plan);
+/* update!(m::Model) of a SMALL model behind ONE call (csrc/modelrun.hip) — what src/model.jl:132-143 does per solve, for a host that
+ * has recorded its model's tape in the small-model form:
+ *   - setdirty! + the Parameter refresh (src/parameter.jl:93-104): a HOST-updated Parameter's value array is copied into its page-locked
+ *     mailbox in the device layout (the tape's first entries copy mailbox -> Parameter buffer inside the one launch); a DEVICE-regenerated
+ *     Parameter's seed word is advanced (word = base + stride * number of updates so far);
+ *   - the re-evaluation + MOI copies (src/model.jl:134-143, src/moi_interop.jl:131-137,168-175): pmt_plan_update;
+ *   - results: registered fetches (pmt_model_add_fetch) are enqueued behind the replay; with synchronize != 0 the call returns when the
+ *     plan's stream is idle (pmt_plan_synchronize, incl. the fused runs' barrier error) and stores the registered constants
+ *     (*dst = *src, e.g. MOI function .constant fields); with 0, pmt_model_wait does that later.
+ * A pmt_model owns nothing: plan, mailboxes, seed words, host arrays stay the caller's and must outlive it.
+ *   pmt_model_add_mailbox   `host`: rows x cols doubles with strides (row_stride, col_stride) in doubles — Julia Matrix: (1, size(A, 1)),
+ *                           numpy C order: (shape[1], 1); cols == 0: a vector / scalar.  `mailbox`: `ld` doubles per column.  *out_slot = the
+ *                           slot's index (registration order) = its byte in pmt_model_update's dirty mask
+ *   pmt_model_set_host      the value array moved (an out-of-place callback returned a new array)
+ *   pmt_model_update        dirty: one byte per slot, or NULL = every slot changed (setdirty!(model) + callbacks that always write).
+ *                           A mailbox is only rewritten after the previous replay has been waited for (the launch reads it). */
+typedef struct pmt_model pmt_model;
+int pmt_model_create(pmt_plan *plan, pmt_model **out);
+int pmt_model_destroy(pmt_model *model);
+int pmt_model_add_mailbox(pmt_model *model, const double *host, int64_t rows, int64_t cols, int64_t row_stride, int64_t col_stride,
+                          double *mailbox, int64_t ld, int *out_slot);
+int pmt_model_add_seed(pmt_model *model, uint64_t *seed_word, uint64_t base, uint64_t stride, int *out_slot);
+int pmt_model_set_host(pmt_model *model, int slot, const double *host);
+int pmt_model_add_constant(pmt_model *model, const double *src, double *dst);
+int pmt_model_add_fetch(pmt_model *model, void *host_dst, const void *device_src, size_t bytes);
+int pmt_model_num_slots(const pmt_model *model);
+int pmt_model_update(pmt_model *model, const unsigned char *dirty, int nslots, int synchronize);
+int pmt_model_wait(pmt_model *model);
 /* replay the tape on the plan's stream: one update!(m::Model) (src/model.jl:132-143) — the loop over FunctionWrapper calls
  * (src/FunctionWrappersQuickFix.jl:108-126) becomes a loop over recorded launches; after pmt_plan_instantiate_graph, one hipGraph launch */
 int pmt_plan_update(pmt_plan *plan);

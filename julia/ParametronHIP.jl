@@ -256,6 +256,60 @@ function host_alloc(n::Integer)
 end
 host_free(v::Vector{Float64}) = check(ccall((:pmt_host_free, lib), Cint, (Ptr{Cvoid},), pointer(v)))
 
+"""host_register(v) -> DevPtr: the memory of a Julia array the HOST keeps using as the object it is (`moi_f.terms` after its `resize!`,
+src/moi_interop.jl:36-37,65,70) page-locked and device-visible in place (pmt_host_register).  The returned address is what a recorded entry
+point is given as its output: the kernel stores straight into the Julia array — no device twin, no fetch.  Julia's GC does not move arrays;
+the caller keeps `v` alive and un-resized until `host_unregister(v)`."""
+function host_register(v::Array)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pmt_host_register, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), pointer(v), max(sizeof(v), 1), ref))
+    DevPtr(ref[])
+end
+host_unregister(v::Array) = check(ccall((:pmt_host_unregister, lib), Cint, (Ptr{Cvoid},), pointer(v)))
+
+# ---- update!(m::Model) of a SMALL model behind one call (include/parametron_hip.h: pmt_model_*; csrc/modelrun.hip)
+"the per-solve walk of a small model: mailboxes of host-updated Parameters, seed words of device-regenerated ones, fetches, constants"
+mutable struct ModelRun
+    handle::Ptr{Cvoid}
+    plan::Plan                        # (kept alive: the run refers to it)
+    function ModelRun(plan::Plan)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pmt_model_create, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), plan.handle, ref))
+        r = new(ref[], plan)
+        finalizer(r -> ccall((:pmt_model_destroy, lib), Cint, (Ptr{Cvoid},), r.handle), r)
+        r
+    end
+end
+"`host`: the Parameter's value (Matrix: strides (1, size(host, 1)); Vector: cols = 0); `mailbox`: page-locked, `ld` doubles per column.  Returns the slot."
+function add_mailbox!(run::ModelRun, host::Ptr{Float64}, rows::Integer, cols::Integer, row_stride::Integer, col_stride::Integer, mailbox::Vector{Float64}, ld::Integer)
+    slot = Ref{Cint}(-1)
+    check(ccall((:pmt_model_add_mailbox, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int64, Ptr{Float64}, Int64, Ref{Cint}),
+                run.handle, host, rows, cols, row_stride, col_stride, pointer(mailbox), ld, slot))
+    Int(slot[])
+end
+"a device-regenerated Parameter: `word[]` = base + stride * (number of updates so far), stored before every replay"
+function add_seed!(run::ModelRun, word::Ref{UInt64}, base::Integer, stride::Integer)
+    slot = Ref{Cint}(-1)
+    check(ccall((:pmt_model_add_seed, lib), Cint, (Ptr{Cvoid}, Ref{UInt64}, UInt64, UInt64, Ref{Cint}), run.handle, word, base, stride, slot))
+    Int(slot[])
+end
+set_host!(run::ModelRun, slot::Integer, host::Ptr{Float64}) =
+    check(ccall((:pmt_model_set_host, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), run.handle, slot, host))
+"behind the wait of every update: `dst[] = src[]` (e.g. a scalar function's constant out of its page-locked word)"
+add_constant!(run::ModelRun, src::Ptr{Float64}, dst::Ptr{Float64}) =
+    check(ccall((:pmt_model_add_constant, lib), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), run.handle, src, dst))
+"a result that lives in HBM: copied into `dst` (page-locked) behind every replay, in front of the wait"
+add_fetch!(run::ModelRun, dst::Array, src::DevPtr, bytes::Integer = sizeof(dst)) =
+    check(ccall((:pmt_model_add_fetch, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, DevPtr, Csize_t), run.handle, dst, src, bytes))
+num_slots(run::ModelRun) = Int(ccall((:pmt_model_num_slots, lib), Cint, (Ptr{Cvoid},), run.handle))
+"""one update!(model): dirty mailboxes / seeds refreshed, the tape replayed, (synchronize) the MOI buffers complete on the host.
+`dirty === nothing`: every slot (setdirty!(model) semantics, src/model.jl:132-133); else one byte per slot."""
+model_update!(run::ModelRun, dirty::Nothing, synchronize::Bool = true) =
+    check(ccall((:pmt_model_update, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), run.handle, C_NULL, 0, synchronize ? 1 : 0))
+model_update!(run::ModelRun, dirty::Vector{UInt8}, synchronize::Bool = true) =
+    check(ccall((:pmt_model_update, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), run.handle, dirty, length(dirty), synchronize ? 1 : 0))
+model_wait!(run::ModelRun) = check(ccall((:pmt_model_wait, lib), Cint, (Ptr{Cvoid},), run.handle))
+
 # ---- delivery to a HOST solver while the re-evaluation runs (include/parametron_hip.h: pmt_plan_record_fetch, pmt_quad_gram_csc_deliver_f64)
 "while recording: `dst` (page-locked) receives `bytes` from `src` on the plan's fetch path as soon as what was recorded before it on its lane is done"
 record_fetch!(plan::Plan, dst::Array, src::DevPtr, bytes::Integer = sizeof(dst)) =

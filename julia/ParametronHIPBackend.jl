@@ -66,6 +66,12 @@ mutable struct DeviceParameter
     host::Vector{Float64}             # page-locked staging copy of the value (dense, column-major): the asynchronous upload reads it
     staging::NTuple{2, DevPtr}        # one device staging buffer per slot (pmt_plan_stage_slot)
     nnz::Int             # > 0: a SparseMatrixCSC with a FIXED pattern — buf / host / staging hold nzval only (BASELINE config 5)
+    # SMALL models (HIPModel: small): the value travels through a page-locked MAILBOX in the device layout that the tape's first entries copy
+    # from inside the one launch; the library writes it from the Parameter's own array (pmt_model_update, H.ModelRun)
+    mailbox::Vector{Float64}
+    slot::Int                         # slot in the ModelRun (-1: not registered)
+    host_ptr::Ptr{Float64}            # address of the value array the slot currently reads (an out-of-place callback returns a new one)
+    scalar::Vector{Float64}           # a Number's value, as the one-element array the slot reads
 end
 
 padded_rows(r) = r >= 64 ? 16 * cld(r, 16) : r
@@ -77,18 +83,18 @@ function DeviceParameter(plan::H.Plan, p::Parameter)
         r, c = size(val)
         nz = length(val.nzval)
         bytes = 8 * max(nz, 1)
-        return DeviceParameter(p, H.alloc(plan, bytes), r, c, r, H.host_alloc(max(nz, 1)), (H.alloc(plan, bytes), H.alloc(plan, bytes)), nz)
+        return DeviceParameter(p, H.alloc(plan, bytes), r, c, r, H.host_alloc(max(nz, 1)), (H.alloc(plan, bytes), H.alloc(plan, bytes)), nz, Float64[], -1, Ptr{Float64}(C_NULL), Float64[])
     elseif val isa AbstractMatrix
         r, c = size(val)
         ld = padded_ld(r)
         bytes = 8 * ld * max(c, 1)
-        return DeviceParameter(p, H.alloc(plan, bytes), r, c, ld, H.host_alloc(r * c), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0)     # zero filled: the padding rows stay zero
+        return DeviceParameter(p, H.alloc(plan, bytes), r, c, ld, H.host_alloc(r * c), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0, Float64[], -1, Ptr{Float64}(C_NULL), Float64[])     # zero filled: the padding rows stay zero
     elseif val isa AbstractVector
         r = length(val)
         bytes = 8 * max(padded_rows(r), 1)
-        return DeviceParameter(p, H.alloc(plan, bytes), r, 0, padded_rows(r), H.host_alloc(r), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0)
+        return DeviceParameter(p, H.alloc(plan, bytes), r, 0, padded_rows(r), H.host_alloc(r), (H.alloc(plan, bytes), H.alloc(plan, bytes)), 0, Float64[], -1, Ptr{Float64}(C_NULL), Float64[])
     elseif val isa Number
-        return DeviceParameter(p, H.alloc(plan, 8), 1, -1, 1, H.host_alloc(1), (H.alloc(plan, 8), H.alloc(plan, 8)), 0)
+        return DeviceParameter(p, H.alloc(plan, 8), 1, -1, 1, H.host_alloc(1), (H.alloc(plan, 8), H.alloc(plan, 8)), 0, Float64[], -1, Ptr{Float64}(C_NULL), Float64[])
     end
     throw(ArgumentError("Parameters of type $(typeof(val)) are not supported on the device"))
 end
@@ -319,6 +325,11 @@ mutable struct HIPModel
     host::Union{Nothing, HostQP}
     solver_update::Any                # f(Px, Ax, q, l, u), called by update! in the host_csc hand-off
     strict::Bool                      # true: every non-constant record runs on the device (HIPModel throws otherwise); false: unknown shapes keep the CPU update!
+    # SMALL models (launch-bound on the device: README Example 1 .. a few hundred variables): Parameter values through mailboxes, the MOI
+    # functions' own vectors registered as the kernels' outputs, update! = ONE library call (INTEGRATION.md section 5)
+    small::Bool
+    run::Union{Nothing, H.ModelRun}
+    registered::Vector{Any}           # the host arrays the kernels store into (kept alive and un-resized for the life of the plan)
 end
 
 """on_device(hm) -> (objective = :device | :cpu | :constant, constraints = [:device | :cpu | :constant ...] in the reference's update order).
@@ -357,6 +368,71 @@ function operand!(hm::HIPModel, da::DenseAffine, rec)
     t, ld, rows, cols
 end
 
+# ---- small models
+const SMALL_MODEL_ELEMENTS = 262144          # host-updated Parameter elements up to which the small-model path wins (DESIGN.md section 4: measured crossover)
+
+dense_f64(v) = v isa Matrix{Float64} || v isa Vector{Float64} || v isa Float64
+"the reference's boundary (:moi), every Parameter a dense Float64 array / number, and few enough elements that update! is launch-bound"
+function small_model(model::Model, handoff::Symbol)
+    handoff === :moi || return false
+    total = 0
+    for p in model.params
+        v = p()
+        dense_f64(v) || return false
+        total += length(v)
+    end
+    total <= SMALL_MODEL_ELEMENTS
+end
+
+"""An MOI buffer of a record: in a small model the function object's OWN vector, page-locked in place (H.host_register) — the kernel stores
+into it from inside the one launch and there is no device twin; otherwise a plan-owned device buffer that update! fetches."""
+function output_buffer(hm::HIPModel, host::Vector, n::Integer, elbytes::Integer)
+    hm.small || return H.alloc(hm.plan, elbytes * max(n, 1))
+    resize!(host, max(n, 1))                   # (as the reference's update! does, src/moi_interop.jl:37,48,53,65,70: in place, never again)
+    n == 0 && resize!(host, 0)
+    n == 0 && return H.alloc(hm.plan, elbytes)
+    push!(hm.registered, host)
+    H.host_register(host)
+end
+"the scalar functions' constant: a page-locked word the kernel stores into (small models) or a device word that is fetched"
+function constant_buffer(hm::HIPModel)
+    hm.small || return H.alloc(hm.plan, 8), zeros(1)
+    word = H.host_alloc(1)
+    DevPtr(pointer(word)), word
+end
+
+"front of a small model's tape: one mailbox per Parameter and the entry that copies it into the Parameter's device buffer"
+function record_mailboxes!(hm::HIPModel, rec)
+    for p in hm.model.params
+        d = device_param!(hm, p)
+        n = d.cols > 0 ? d.ld * d.cols : max(d.ld, 1)
+        d.mailbox = H.host_alloc(n)            # zero filled: the padding rows stay zero
+        H.copy_bytes!(d.buf, DevPtr(pointer(d.mailbox)), 8 * n, rec)
+    end
+    nothing
+end
+
+"after the tape is recorded: the run that update! calls — every Parameter's own value array registered with its strides"
+function create_run!(hm::HIPModel)
+    run = H.ModelRun(hm.plan)
+    for d in hm.params
+        v = d.param()
+        if d.cols > 0
+            d.host_ptr = pointer(v)
+            d.slot = H.add_mailbox!(run, d.host_ptr, d.rows, d.cols, 1, d.rows, d.mailbox, d.ld)
+        elseif d.cols == 0
+            d.host_ptr = pointer(v)
+            d.slot = H.add_mailbox!(run, d.host_ptr, d.rows, 0, 1, 0, d.mailbox, max(d.ld, 1))
+        else
+            d.scalar = [Float64(v)]
+            d.host_ptr = pointer(d.scalar)
+            d.slot = H.add_mailbox!(run, d.host_ptr, 1, 0, 1, 0, d.mailbox, 1)
+        end
+    end
+    hm.run = run
+    nothing
+end
+
 identity_map(hm::HIPModel, x::Vector{Variable}) = all(i -> hm.model.model_var_to_optimizer[x[i].index].value == i, eachindex(x)) && length(x) == length(hm.model.model_var_to_optimizer)
 
 function record_objective!(hm::HIPModel, objective, rec)
@@ -368,9 +444,10 @@ function record_objective!(hm::HIPModel, objective, rec)
         d = device_param!(hm, bil.Q)
         xv = upload_indices(hm.plan, Int64[v.index for v in bil.x]); yv = upload_indices(hm.plan, Int64[v.index for v in bil.y])
         nq = d.rows * d.cols
-        quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16), H.alloc(hm.plan, 8)
+        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, 0, 16)
+        constant, cbuf = constant_buffer(hm)
         H.bilinear!(quad, d.buf, d.ld, d.rows, d.cols, xv, yv, 1, hm.varmap, rec)
-        return HIPObjective(objective, quad, lin, constant, nq, 0, zeros(1), DevPtr(C_NULL), Float64[])
+        return HIPObjective(objective, quad, lin, constant, nq, 0, cbuf, DevPtr(C_NULL), Float64[])
     end
     da = analyse_lsq(objective.expr)
     A, lda, r, n = operand!(hm, da, rec)
@@ -389,13 +466,22 @@ function record_objective!(hm::HIPModel, objective, rec)
         # literal: the reference's term order and coefficients bit for bit (src/functions.jl:702-709 over :548-576, moi_interop.jl:45-62)
         nq, nl = r * n * n, 2 * r * n
         res, resc = H.alloc(hm.plan, 16 * r * n), H.alloc(hm.plan, 8 * r)
-        quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * nl), H.alloc(hm.plan, 8)
+        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, nl, 16)
+        constant, cbuf = constant_buffer(hm)
         H.affine_assemble!(res, resc, A, lda, r, n, xvar, b, da.sign, rec)
         H.quad_expand!(quad, lin, constant, r, res, n, resc, res, n, resc, 1, hm.varmap, rec)
-        return HIPObjective(objective, quad, lin, constant, nq, nl, zeros(1), DevPtr(C_NULL), Float64[])
+        return HIPObjective(objective, quad, lin, constant, nq, nl, cbuf, DevPtr(C_NULL), Float64[])
     end
     issorted([v.index for v in da.x], lt = <=) || throw(Unsupported("canonical objective needs strictly increasing variables"))
     nq = div(n * (n + 1), 2)
+    if hm.small
+        # a small model: the node stores its terms straight into the function object's own (registered) vectors; nothing to deliver
+        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, n, 16)
+        constant, cbuf = constant_buffer(hm)
+        ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(padded_rows(r), n))
+        H.quad_gram!(quad, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, 1, hm.varmap, ws, rec)
+        return HIPObjective(objective, quad, lin, constant, nq, n, cbuf, DevPtr(C_NULL), Float64[])
+    end
     quad, lin, constant = H.alloc(hm.plan, 24 * nq), H.alloc(hm.plan, 16 * n), H.alloc(hm.plan, 8)
     ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(r, n))
     # The reference's own boundary, overlapped: the objective's quadratic_terms vector is made a view of page-locked memory (24-byte isbits
@@ -471,11 +557,12 @@ function record_constraint!(hm::HIPModel, constraint, rec)
     pieces = analyse_pieces(constraint.expr)
     rows = sum(p -> piece_rows(hm, p), pieces)
     nterms = sum(p -> piece_terms(hm, p), pieces)
-    terms, constants = H.alloc(hm.plan, 24 * max(nterms, 1)), H.alloc(hm.plan, 8 * max(rows, 1))
+    terms, constants = output_buffer(hm, constraint.f.terms, nterms, 24), output_buffer(hm, constraint.f.constants, rows, 8)
     # A constraint that reads Parameter values only (no node of the tape feeds it) is independent of every other record (update! of one
     # Constraint, src/moi_interop.jl:168-175): beside a canonical least-squares objective it goes to the plan's side lane
     independent = all(p -> !(p isa DenseAffine && p.transposed) && !(p isa ScaledAffine), pieces)
-    side = independent && hm.objective !== nothing && hm.objective.nlin > 0 && (hm.objective.nquad == 0 || hm.objective.nquad == div(hm.objective.nlin * (hm.objective.nlin + 1), 2))
+    # (never in a small model: its Parameter values arrive through entries at the FRONT of the tape, which side-lane entries would overtake)
+    side = !hm.small && independent && hm.objective !== nothing && hm.objective.nlin > 0 && (hm.objective.nquad == 0 || hm.objective.nquad == div(hm.objective.nlin * (hm.objective.nlin + 1), 2))
     side && H.set_lane!(hm.plan, 1)
     t0 = 0; row0 = 0
     for p in pieces
@@ -566,10 +653,12 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
     nvars = length(model.model_var_to_optimizer)
     varmap = upload_indices(plan, Int64[vi.value for vi in model.model_var_to_optimizer])          # src/model.jl:100-107
     host = handoff === :host_csc ? HostQP(Float64[], Float64[], Float64[], nvars, 0, DevPtr(C_NULL)) : nothing
-    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit, 0, handoff, host, solver_update, strict)
+    small = small_model(model, handoff)
+    hm = HIPModel(model, plan, DeviceParameter[], varmap, nothing, HIPConstraint[], Any[], literal_limit, 0, handoff, host, solver_update, strict, small, nothing, Any[])
     rec = H.recording_stream(plan)
     H.begin_record!(plan)
     try
+        small && record_mailboxes!(hm, rec)
         obj = model.objective
         if obj.isconstant
             nothing                                                  # never updated (src/moi_interop.jl:132)
@@ -605,6 +694,7 @@ function HIPModel(model::Model; device::Integer = 0, literal_limit::Integer = 1 
     finally
         H.end_record!(plan)
     end
+    small && create_run!(hm)
     hm
 end
 
@@ -643,7 +733,36 @@ end
 
 """update!(m::Model) of src/model.jl:132-143: setdirty!, Parameters, one tape replay, then the hand-off.  Nothing below allocates: the
 Parameter values go through their page-locked staging arrays onto the copy stream, the commits and the tape onto the plan's stream."""
+"""update!(m::Model) of a SMALL model: the callbacks here (they are Julia functions), everything else — value -> mailbox, the one launch, the
+wait — in pmt_model_update; the kernels have stored the MOI terms into the function objects' own vectors when it returns.  Allocates nothing."""
+function update_small!(hm::HIPModel)
+    m = hm.model
+    setdirty!(m)
+    for d in hm.params
+        v = d.param()                                                # evaluates the callback (src/parameter.jl:93-99)
+        if d.cols == -1
+            d.scalar[1] = v
+        elseif pointer(v) != d.host_ptr                              # an out-of-place callback returned a new array
+            d.host_ptr = pointer(v)
+            H.set_host!(hm.run, d.slot, d.host_ptr)
+        end
+    end
+    H.model_update!(hm.run, nothing, true)                           # every slot is dirty: setdirty!(model) (src/model.jl:132-133)
+    o = hm.objective
+    if o !== nothing
+        f = o.objective.f
+        f.constant = o.cbuf[1]
+        MOI.set(m.optimizer, MOI.ObjectiveFunction{typeof(f)}(), f)  # src/moi_interop.jl:134
+    end
+    for c in hm.constraints
+        MOI.set(m.optimizer, MOI.ConstraintFunction(), c.constraint.optimizerindex, c.constraint.f)      # src/moi_interop.jl:171
+    end
+    hm.strict || cpu_update!(hm)
+    nothing
+end
+
 function Parametron.update!(hm::HIPModel)
+    hm.small && return update_small!(hm)
     m = hm.model
     setdirty!(m)
     slot = hm.slot

@@ -130,11 +130,23 @@ SIGNATURES = {
     "pmt_plan_bytes_allocated": (_sz, [_vp]),
     "pmt_host_alloc": (_ci, [_sz, C.POINTER(_vp)]),
     "pmt_host_free": (_ci, [_vp]),
+    "pmt_host_register": (_ci, [_vp, _sz, C.POINTER(_vp)]),
+    "pmt_host_unregister": (_ci, [_vp]),
     "pmt_plan_upload": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),
     "pmt_plan_synchronize": (_ci, [_vp]),
     "pmt_plan_check": (_ci, [_vp]),
+    "pmt_model_create": (_ci, [_vp, C.POINTER(_vp)]),
+    "pmt_model_destroy": (_ci, [_vp]),
+    "pmt_model_add_mailbox": (_ci, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, C.POINTER(_ci)]),
+    "pmt_model_add_seed": (_ci, [_vp, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, C.POINTER(_ci)]),
+    "pmt_model_set_host": (_ci, [_vp, _ci, _vp]),
+    "pmt_model_add_constant": (_ci, [_vp, _vp, _vp]),
+    "pmt_model_add_fetch": (_ci, [_vp, _vp, _vp, C.c_size_t]),
+    "pmt_model_num_slots": (_ci, [_vp]),
+    "pmt_model_update": (_ci, [_vp, _vp, _ci, _ci]),
+    "pmt_model_wait": (_ci, [_vp]),
     "pmt_plan_record_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_record_fetch_2d": (_ci, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     "pmt_host_copy_2d": (_ci, [_vp, _sz, _vp, _sz, _sz, _sz, _ci]),

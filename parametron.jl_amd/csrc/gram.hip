@@ -28,8 +28,8 @@ int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
 void mark_no_graph(void *stream);
 int launch_blocked_dot(const double *a, int sign_a, const double *b, int sign_b, int64_t n, double *scratch, double *out, hipStream_t s, int chained);
 int gram_tall_groups(int64_t rows, int64_t cols);
-int gram_tall_stage_rows(int64_t cols);
-int gram_tall_run_lanes(int64_t cols);
+int gram_tall_stage_rows(int64_t rows, int64_t cols);
+int gram_tall_run_lanes(int64_t rows, int64_t cols);
 size_t blocked_dot_scratch_doubles();
 size_t gram_sk_workspace_bytes(int64_t rows, int64_t cols);
 int launch_courier(const double *src, double *dst_dev, long long *ready, unsigned *done, int *error, int ngroups, const int64_t *gbeg, const int64_t *gend, hipStream_t s);
@@ -456,9 +456,9 @@ extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *ord
         return PMT_OK;
     }
     const bool tall = cols > 0 && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
-    *order = tall ? (gram_tall_run_lanes(cols) == 4 ? 4 : gram_tall_run_lanes(cols) == 16 ? 3 : 2) : (constant_chained(rows, cols) ? 1 : 0);
+    *order = tall ? (gram_tall_run_lanes(rows, cols) == 4 ? 4 : gram_tall_run_lanes(rows, cols) == 16 ? 3 : 2) : (constant_chained(rows, cols) ? 1 : 0);
     if (groups) *groups = tall ? gram_tall_groups(rows, cols) : (*order == 1 ? 2048 : 1);
-    if (stage_rows) *stage_rows = tall ? gram_tall_stage_rows(cols) : 0;
+    if (stage_rows) *stage_rows = tall ? gram_tall_stage_rows(rows, cols) : 0;
     return PMT_OK;
 }
 

@@ -788,6 +788,11 @@ template <int NB> struct Stream {
 // FAST: scalar base (A + row0: wave-uniform) + a 32-bit per-lane byte offset (voff[t], fixed for the kernel) + an immediate: no vector
 // address arithmetic per load.  Otherwise no branch either: a load outside the matrix reads a clamped (valid) address and is replaced by
 // 0.0 afterwards — a branch around a load would make the compiler drain the whole pipeline at every merge (s_waitcnt vmcnt counts loads in order).
+// FAST (A 16-byte aligned with an even pitch, b 16-byte aligned, the panel within 4 GiB): a WHOLE iteration's loads — scalar base (A + row0:
+// wave-uniform) + a 32-bit per-lane byte offset (voff[t], fixed for the kernel; a column beyond the matrix reads the LAST column instead:
+// its products land in accumulators nobody reads) + an immediate: no vector address arithmetic, no mask, no branch.  Otherwise, and for the
+// one ragged iteration at the end of the matrix, 8-byte loads from clamped addresses, what lies outside replaced by 0.0 (no branch around a
+// load either: s_waitcnt vmcnt counts loads in order, a merge would drain the pipeline).
 template <int NB, bool FAST>
 __device__ __forceinline__ void stream_load(const TallArgs &g, int64_t row0, int lane, const unsigned (&voff)[NB], f64x2 (&buf)[NB][Stream<NB>::IT], f64x2 &cb) {
     using S = Stream<NB>;
@@ -805,10 +810,11 @@ __device__ __forceinline__ void stream_load(const TallArgs &g, int64_t row0, int
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
         const int64_t col = 16 * t + lm;
+        const bool cv = col < g.cols;
 #pragma unroll
         for (int i = 0; i < S::IT; ++i) {
             const int64_t row = row0 + 8 * i + 2 * lk;
-            const bool cv = col < g.cols, v0 = cv && row < g.rows, v1 = cv && row + 1 < g.rows;
+            const bool v0 = cv && row < g.rows, v1 = cv && row + 1 < g.rows;
             const double *p0 = g.A + (v0 ? col * g.lda + row : 0), *p1 = g.A + (v1 ? col * g.lda + row + 1 : 0);
             const double x = *p0, y = *p1;
             buf[t][i].x = v0 ? x : 0.0;
@@ -893,7 +899,11 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, lk = lane >> 4;
     const int64_t W = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wave;
-    const int my = (int)(g.nstages > gw ? (g.nstages - gw + W - 1) / W : 0);             // iterations gw, gw + W, ..
+    // iterations gw, gw + W, .. of the nfull WHOLE ones; the ragged one behind them (rows % RI rows) is the last iteration of the wave it
+    // falls to — loaded with masks, outside the pipelined loop
+    const int64_t nfull = g.rows / S::RI;
+    const int my = (int)(nfull > gw ? (nfull - gw + W - 1) / W : 0);
+    const bool tail = nfull * S::RI < g.rows && nfull % W == gw;
 
     double acc[N::NACC];
 #pragma unroll
@@ -905,7 +915,7 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
     double *rot = sh + wave * ROT;
     unsigned voff[NB];                                    // (FAST: the launch checks that the panel spans less than 4 GiB)
 #pragma unroll
-    for (int t = 0; t < NB; ++t) voff[t] = (unsigned)(((int64_t)(16 * t + lm) * g.lda + 2 * lk) * 8);
+    for (int t = 0; t < NB; ++t) voff[t] = (unsigned)((min((int64_t)(16 * t + lm), g.cols - 1) * g.lda + 2 * lk) * 8);
     // (an iteration index beyond the wave's last is clamped to the last: a repeated, cached load that is never used)
     auto row_of = [&](int s) { return (gw + (int64_t)min(s, max(my - 1, 0)) * W) * S::RI; };
     if (my > 0) {
@@ -918,6 +928,10 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
                 if (PMT_STREAM_ABL != 2 && PMT_STREAM_ABL != 4 && PMT_STREAM_ABL != 5) stream_load<NB, FAST>(g, row_of(s0 + d + S::D), lane, voff, buf[d], cb[d]);
             }
         }
+    }
+    if (tail) {
+        stream_load<NB, false>(g, nfull * S::RI, lane, voff, buf[0], cb[0]);
+        stream_compute<NB>(rot, buf[0], cb[0], g.sign, lane, acc, qacc, cacc);
     }
     // c'c: the four contraction slots (lanes 0, 16, 32, 48 of column 0), tree in fixed order
     cacc = cacc + __shfl_down(cacc, 32, 64);
@@ -967,7 +981,12 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
     }
 }
 
-static bool stream_form(int nb) { return PMT_STREAM && (nb == 1 || nb == 2 || nb == 4); }
+// (shape alone decides — the constant's order must follow from (rows, cols): below 32768 rows the panel kernel's two launches are the
+// shorter ones: 80 x 50 9.6 against 12 us, 2000 x 40 9.8 against 12.4, 16384 x 64 13.2 against 14.8; 77777 x 50 23.7 against 22.9)
+#ifndef PMT_STREAM_MINROWS
+#define PMT_STREAM_MINROWS 32768
+#endif
+static bool stream_form(int nb, int64_t rows) { return PMT_STREAM && (nb == 1 || nb == 2 || nb == 4) && rows >= PMT_STREAM_MINROWS; }
 static int stream_iteration_rows(int nb) { return nb == 1 ? Stream<1>::RI : nb == 2 ? Stream<2>::RI : Stream<4>::RI; }
 static int stream_groups(int64_t rows, int nb) {
     const int64_t nit = cdiv(rows, stream_iteration_rows(nb));
@@ -978,7 +997,7 @@ static int narrow_nb(int64_t cols) { return cols <= 16 ? 1 : cols <= 32 ? 2 : co
 static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ? Narrow<2>::R : Narrow<4>::R; }
 static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
 static int narrow_groups(int64_t rows, int nb) {
-    if (stream_form(nb)) return stream_groups(rows, nb);
+    if (stream_form(nb, rows)) return stream_groups(rows, nb);
     const int64_t nst = cdiv(rows, narrow_stage_rows(nb));
     return (int)cdiv(nst, cdiv(nst, (int64_t)PMT_NARROW_MAXG));
 }
@@ -987,10 +1006,10 @@ template <int NB>
 static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStream_t s) {
     using N = Narrow<NB>;
     const int G = narrow_groups(g.rows, NB);
-    if (stream_form(NB)) {
+    if (stream_form(NB, g.rows)) {
         g.nstages = cdiv(g.rows, Stream<NB>::RI);                 // iterations of RI rows, dealt out to the 4 G waves
-        // whole iterations for every wave's clamped re-reads included, whole panels, aligned pieces of A and b: no masks
-        const bool fast = g.vec_in && g.cols == N::C && g.rows % Stream<NB>::RI == 0 && b_aligned && (uint64_t)g.lda * N::C * 8 < (1ull << 32);
+        // aligned pieces of A and b, 32-bit lane offsets: the whole iterations take unmasked 16-byte loads
+        const bool fast = g.vec_in && b_aligned && (uint64_t)g.lda * N::C * 8 < (1ull << 32);
         if (fast) PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<NB, true>), dim3((unsigned)G), dim3(256), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
         if (int rc = check_launch("gram_stream_kernel")) return rc;
@@ -1010,8 +1029,10 @@ static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStre
 // at one CU's rate (>= 34 us for 100 x 100, measured), computes the full square, and needs two more kernels for q and c'c.  Tiny shapes
 // are the small-plan interpreter's (row-order sums, gram.hip) and keep the stream-K node as their stand-alone form.
 bool gram_tiny(int64_t rows, int64_t cols) {           // (what one interpreter node may cost: SMALL_NODE_WORK_MAX, common.h)
+    // (the interpreter's node walks the rows in order, one thread per (j, k): its time grows with the ROW count — 300 x 8 took 80 us where
+    // the stream form's two launches take 14; up to 64 rows it stays below them)
     const int64_t t = rows * cols * (cols + 1) / 2;
-    return cols > 0 && t <= 16384 && t + 64 * rows <= SMALL_NODE_WORK_MAX;
+    return cols > 0 && rows <= 64 && t <= 16384 && t + 64 * rows <= SMALL_NODE_WORK_MAX;
 }
 bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <= TCOLS && rows >= 1 && !gram_tiny(rows, cols); }
 // WIDE shapes (129 .. 2048 columns, any number of rows): the diagonal tiles take this kernel — one launch over (row groups x tiles), which
@@ -1040,12 +1061,12 @@ static int64_t tall_chunk(int64_t rows, int64_t cols) {
     const int64_t minst = (nt == 1 && rows <= 2048) ? 1 : TALL_MIN_CHUNK / TBK;
     return std::max<int64_t>(minst, cdiv(nst, maxg));
 }
-int gram_tall_stage_rows(int64_t cols) {
+int gram_tall_stage_rows(int64_t rows, int64_t cols) {
     const int nb = narrow_nb(cols);
-    return nb ? (stream_form(nb) ? stream_iteration_rows(nb) : narrow_stage_rows(nb)) : TBK;
+    return nb ? (stream_form(nb, rows) ? stream_iteration_rows(nb) : narrow_stage_rows(nb)) : TBK;
 }
 // row-pair lanes per column run (8 or 16: the panel kernels); 4: the stream form (four contraction slots per column, iterations dealt to WAVES)
-int gram_tall_run_lanes(int64_t cols) { const int nb = narrow_nb(cols); return nb && stream_form(nb) ? 4 : nb == 1 ? Narrow<1>::LPC : 8; }
+int gram_tall_run_lanes(int64_t rows, int64_t cols) { const int nb = narrow_nb(cols); return nb && stream_form(nb, rows) ? 4 : nb == 1 ? Narrow<1>::LPC : 8; }
 int gram_tall_groups(int64_t rows, int64_t cols) {
     if (const int nb = narrow_nb(cols)) return narrow_groups(rows, nb);
     return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols));

@@ -226,6 +226,9 @@ class Model:
 
     def close(self):
         if self._ctx is not None:
+            if getattr(self, "_model_run", None) is not None:
+                self._ctx.lib.pmt_model_destroy(self._model_run)
+                self._model_run = None
             self._ctx.close()
             self._ctx = None
 
@@ -392,6 +395,8 @@ class Model:
                         ctx.set_lane(0)
             finally:
                 ctx.end_record()
+            self._model_run = None
+            self._create_model_run(ctx)
             # first evaluation with the identity map so that copy_to sees sized, filled functions (src/moi_interop.jl:127,157)
             self._run_tape()
         if not early:
@@ -458,6 +463,73 @@ class Model:
             x._in_tape = True
         if ps and all(getattr(x, "_in_tape", False) for x in ps):
             self._tape_parameters = ps             # every value enters through the tape: _refresh_parameters' short walk
+
+    def _create_model_run(self, ctx):
+        """SMALL models: the per-solve walk behind ONE C call (pmt_model_update, csrc/modelrun.hip — the entry point a Julia / C host uses
+        for the same walk): mailboxes of the host-updated Parameters whose value array is a float64 array that stays put (`val=` buffers,
+        in-place callbacks) are registered with their strides — the library copies value -> mailbox itself —, the records' constants with
+        the function objects' fields are finished there too.  Everything else keeps this host's own writers (dirty byte 0)."""
+        fast = getattr(self, "_tape_parameters", None)
+        if not getattr(self, "_small", False) or fast is None:
+            return
+        run = C.c_void_p()
+        ctx.call("pmt_model_create", ctx.plan, C.byref(run))
+        self._run_slot = []                                   # per Parameter of `fast`: slot in the C model, or -1 (written here)
+        for x in fast:
+            slot = -1
+            mb, dv = getattr(x, "_mailbox", None), x._dev
+            val = getattr(x, "val", None)
+            if getattr(x, "_mailbox_write", None) is not None and isinstance(val, np.ndarray) and val.dtype == np.float64 and \
+                    val.ndim in (1, 2) and all(st % 8 == 0 and st >= 0 for st in val.strides):
+                from .device import DMat
+                rows, cols = (dv.rows, dv.cols) if isinstance(dv, DMat) else (val.shape[0], 0)
+                rs = val.strides[0] // 8
+                cs = val.strides[1] // 8 if val.ndim == 2 else 0
+                ld = dv.lda if isinstance(dv, DMat) else max(int(mb.size), rows)
+                if val.shape == ((rows, cols) if cols else (rows,)):
+                    out = C.c_int()
+                    ctx.call("pmt_model_add_mailbox", run, C.c_void_p(val.ctypes.data), rows, cols, rs, cs, C.c_void_p(mb.ctypes.data), ld, C.byref(out))
+                    slot = out.value
+                    x._run_val = val                       # (identity of the array object: `val.ctypes.data` costs a microsecond per call)
+            self._run_slot.append(slot)
+        # what a record's fetch() would copy out of HBM (a buffer whose device twin IS the host array needs nothing): behind the replay, in C
+        for r in self._records:
+            for host, key in r.fetch_list():
+                if key in r.dev and r.dev[key] != host.ctypes.data:
+                    ctx.call("pmt_model_add_fetch", run, C.c_void_p(host.ctypes.data), C.c_void_p(r.dev[key]), host.nbytes)
+        self._run_nslots = int(ctx.lib.pmt_model_num_slots(run))
+        self._run_mask = (C.c_ubyte * max(self._run_nslots, 1))()
+        self._model_run = run
+
+    def _fast_update(self, ctx):
+        """update!(model) of a small model, synchronous: callbacks here (they are host functions), everything else in pmt_model_update"""
+        mask, slots = self._run_mask, self._run_slot
+        synced = False
+        for i, x in enumerate(self._tape_parameters):
+            val = Parameter.__call__(x)                                  # evalarg(::Parameter) (src/lazyexpression.jl:51)
+            slot = slots[i]
+            if x._dev_version == x.version:
+                if slot >= 0:
+                    mask[slot] = 0
+                continue
+            x._dev_version = x.version
+            write = x._mailbox_write
+            if write is None:
+                x._seed_word.value = x.current_seed() % (1 << 64)
+            elif slot >= 0 and val is x._run_val:
+                mask[slot] = 1                                           # the library copies value -> mailbox
+            else:
+                if slot >= 0:
+                    mask[slot] = 0
+                if not synced and getattr(ctx, "_replay_pending", False):
+                    ctx.synchronize()                                   # the previous replay may still be reading the mailboxes
+                synced = True
+                if val is not None:
+                    write(val)
+        ctx.call("pmt_model_update", self._model_run, mask, self._run_nslots, 1)
+        ctx._replay_pending = False
+        for r in self._records:
+            r.finish_fetch()
 
     def _mark_side_lane_parameters(self):
         """Host-updated Parameters that ONLY side-lane records read (and, with a hand-off, only when its launches are side-lane entries too)
@@ -551,6 +623,10 @@ class Model:
             # host_csc: dense constraint blocks leave straight out of their Parameter buffers (handoff.py): the previous solve's transfers
             # have read them before this solve's callbacks / commits rewrite them (a no-op when the caller has synchronised, as solve! does)
             ctx.fetch_synchronize()
+        if fetch and getattr(self, "_model_run", None) is not None and not ctx.recording and \
+                not any(getattr(x, "_staged_pending", False) for x in self._tape_parameters):
+            self._fast_update(ctx)
+            return
         self._refresh_parameters()
         ctx.replay()
         if not fetch:

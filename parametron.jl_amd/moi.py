@@ -413,6 +413,17 @@ class _Record:
             get(f._terms, "terms")                                        # (absent for a host_csc record whose terms are static, compile)
             get(f.constants, "consts")
 
+    def fetch_list(self):
+        """(host array, key of self.dev) pairs fetch() copies — for a host that registers them once (Model._create_model_run)"""
+        f = self.f
+        if self.kind == "aff":
+            self._c = self._cbuf
+            return [(f.terms, "terms"), (self._c, "const")]
+        if self.kind == "quad":
+            self._c = self._cbuf
+            return [(f.quadratic_terms, "quad"), (f.affine_terms, "lin"), (self._c, "const")]
+        return [(f._terms, "terms"), (f.constants, "consts")]
+
     def finish_fetch(self):
         if self.kind in ("aff", "quad"):
             self.f.constant = float(self._c[0])

@@ -185,7 +185,8 @@ def test_julia_update_path_has_no_allocating_constructors():
     (Setup functions — HIPModel, record_*, DeviceParameter — may allocate: they run once.)"""
     src = open(os.path.join(ROOT, "julia", "ParametronHIPBackend.jl")).read()
     per_solve = [r"function refresh!\(", r"function commit!\(", r"function fetch_A!\(", r"function copy_A!\(", r"function Parametron\.update!\(o::HIPObjective",
-                 r"function Parametron\.update!\(c::HIPConstraint", r"function Parametron\.update!\(hm::HIPModel\)", r"function solve!\(hm::HIPModel\)"]
+                 r"function Parametron\.update!\(c::HIPConstraint", r"function Parametron\.update!\(hm::HIPModel\)", r"function solve!\(hm::HIPModel\)",
+                 r"function update_small!\(hm::HIPModel\)"]
     banned = [r"\bVector\{[^}]*\}\(", r"\bMatrix\{[^}]*\}\(", r"\bArray\{", r"\bzeros\(", r"\bones\(", r"\bcollect\(", r"\bcopy\(", r"\bsimilar\(",
               r"\b(?:Int64|Float64|Any)\[", r"\[[^\]\n]*\bfor\b[^\]\n]*\]", r"\bpush!\(", r"\bvcat\(", r"\bhcat\(", r"\bconvert\(", r"\bstring\("]
     checked = 0
@@ -238,7 +239,9 @@ def test_julia_backend_is_strict_by_default():
     assert re.search(r"hm\.strict \|\| cpu_update!\(hm\)", upd)
     cpu = body_of(r"function cpu_update!\(hm::HIPModel\)")
     assert "Parametron.update!(r, m.optimizer, m.model_var_to_optimizer)" in cpu
-    assert len(re.findall(r"cpu_update!\(hm\)", src)) == 1          # the one guarded call
+    small = body_of(r"function update_small!\(hm::HIPModel\)")     # the small-model form of update!(hm): the same guard
+    assert re.search(r"hm\.strict \|\| cpu_update!\(hm\)", small) and "m.model_var_to_optimizer)" not in small
+    assert len(re.findall(r"cpu_update!\(hm\)", src)) == 2 == len(re.findall(r"hm\.strict \|\| cpu_update!\(hm\)", src))          # guarded calls only
 
 
 def test_constant_order_is_host_arithmetic(lib):
@@ -249,7 +252,7 @@ def test_constant_order_is_host_arithmetic(lib):
         lib.call("pmt_quad_gram_constant_order", r, n, C.byref(o), C.byref(g), C.byref(s))
         return o.value, g.value, s.value
     assert order(4096, 4096) == (0, 1, 0)                      # config 2: the reference's left-to-right sum, hidden behind 1.19 ms of contraction
-    assert order(8, 8) == (0, 1, 0) and order(256, 1)[0] == 0   # tiny shapes (the small-plan node): sequential
+    assert order(8, 8) == (0, 1, 0) and order(64, 1)[0] == 0 and order(256, 1)[0] == 3   # tiny shapes (the small-plan node, at most 64 rows): sequential
     assert order(1000, 2049)[0] == 0 and order(8192, 4096)[0] == 0 and order(4096, 2304)[0] == 1 and order(8193, 4096) == (1, 2048, 0)   # > 2048 columns: the cost model
     # up to 2048 columns the fused tall forms, whatever the row count: one tile (order 2; 3 = sixteen row-pair lanes, <= 16 columns) ..
     assert order(80, 96) == (2, 3, 32) and order(1000, 128) == (2, 32, 32) and order(4096, 128) == (2, 64, 32)
@@ -257,8 +260,10 @@ def test_constant_order_is_host_arithmetic(lib):
     assert (o, s) == (2, 32) and g == 512
     o, g, s = order(8192, 128)
     assert o == 2 and g == 8192 // 64                           # at least 64 rows per workgroup
-    # narrow panels (<= 64 columns): the stream form (order 4) — iterations of 32 (64 columns: 16) rows dealt out to the waves of <= 512 workgroups
-    assert order(5000, 17) == (4, 40, 32) and order(1024, 1) == (4, 8, 32) and order(100, 40) == (4, 2, 16)
+    # narrow panels (<= 64 columns): below 32768 rows the panel kernel (32 columns x 128-row stages: order 2; 16 x 256: order 3), from there the
+    # stream form (order 4) — iterations of 32 (64 columns: 16) rows dealt out to the waves of <= 256 (64 columns: 512) workgroups
+    assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256) and order(100, 40)[0] == 2
+    assert order(16384, 17)[0] == 2 and order(32768, 17) == (4, 256, 32) and order(77777, 50) == (4, 512, 16) and order(33001, 9)[0] == 4
     assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
     # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
     assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(31, 300)[0] == 2

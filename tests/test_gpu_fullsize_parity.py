@@ -44,11 +44,12 @@ def _sample_pairs(rng, n, count):
 # gram.hip), 2 the fused tall form (gram_tall.hip: n <= 128, r >= 1024 — one pass over A for Q, q and the constant — or the diagonal tiles of
 # a wide tall matrix, n <= 1024, r >= 16 n)
 @pytest.mark.parametrize("r,n,count,expect_order", [(4096, 4096, 10000, 0), (16384, 1024, 6000, 2), (4090, 1000, 4000, 2), (3000, 2304, 3000, 1), (9000, 2100, 2500, 1), (300, 300, 2000, 5), (100, 1000, 3000, 5), (4096, 512, 3000, 5), (1024, 512, 3000, 5), (1000, 2048, 3000, 2), (33, 129, 600, 5), (2000, 1000, 3000, 5), (517, 391, 2000, 5), (131072, 256, 3000, 2),
-                                                     (1 << 20, 128, 1500, 2), (8192, 128, 3000, 2), (100003, 100, 2000, 2), (5000, 17, 150, 4),
-                                                     (1000, 128, 2000, 2), (100, 100, 800, 2), (500, 100, 800, 2), (200, 50, 400, 4), (700, 7, 28, 4),
+                                                     (1 << 20, 128, 1500, 2), (8192, 128, 3000, 2), (100003, 100, 2000, 2), (5000, 17, 150, 2),
+                                                     (1000, 128, 2000, 2), (100, 100, 800, 2), (500, 100, 800, 2), (200, 50, 400, 2), (700, 7, 28, 3),
                                                      # narrow tall shapes (gram_stream_kernel<1 | 2 | 4>, order 4): whole panels and ragged ones
                                                      (1 << 20, 64, 1200, 4), (262144, 32, 500, 4), (1 << 20, 16, 136, 4), (77777, 50, 900, 4),
-                                                     (33001, 9, 45, 4), (1024, 1, 1, 4), (4099, 33, 500, 4), (1 << 20, 32, 500, 4), (31, 16, 136, 0), (333, 16, 136, 4), (64, 64, 600, 4)])
+                                                     (33001, 9, 45, 4), (1024, 1, 1, 3), (4099, 33, 500, 2), (1 << 20, 32, 500, 4), (31, 16, 136, 0), (333, 16, 136, 3), (64, 64, 600, 2),
+                                                     (32768, 64, 600, 4), (32800, 33, 500, 4), (40001, 16, 136, 4), (65552, 7, 28, 4), (300, 8, 36, 3), (16384, 64, 600, 2)])
 def test_canonical_objective_against_cpu_sampled_sums(r, n, count, expect_order, record_property):
     import gpu_util as g
     q, l, const = _gram(g, r, n)

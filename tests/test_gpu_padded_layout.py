@@ -119,5 +119,5 @@ def test_row_counts_that_are_not_a_multiple_of_16_use_zero_padded_copies(r, n):
         import gpu_util as g
         rp = row_padded(r)
         order, seq = g.constant_in_the_library_order(rp, n, np.concatenate([bv, np.zeros(rp - r)]))
-        assert f.constant == seq and order == (4 if n <= 64 else 5)          # <= 64 columns: the stream form; these wide shapes: the mid-size form
+        assert f.constant == seq and order == (2 if n <= 64 else 5)          # <= 64 columns (below 32768 rows): the panel kernel; these wide shapes: the mid-size form
         Av[...] = rng.random((r, n)); A.val[...] = Av; bv[...] = rng.random(r)      # overwrite: the padding must stay zero

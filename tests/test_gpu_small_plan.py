@@ -648,3 +648,123 @@ def test_toggling_fusion_does_not_grow_the_plan():
     g.call("pmt_plan_set_fusion", plan, 1)
     g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
     g.call("pmt_plan_destroy", plan)
+
+
+def test_model_update_entry_point_as_a_c_host_would_use_it():
+    """pmt_model_update (csrc/modelrun.hip) driven through the C ABI alone, the way a Julia / C host does: README
+    Example 1's shapes with HOST-updated A (Julia layout: column-major, stride (1, r)), a numpy C-order C block (stride (n, 1)), a
+    device-regenerated d (seed word), the constraint's constants stored straight into a page-locked array.  Every solve is compared with
+    the ORACLE's matvecmul! + vecsubtract! + update!(::MOI.VectorAffineFunction) byte for byte; the dirty mask skips unchanged mailboxes."""
+    import gpu_util as g
+    from oracle import oracle as O
+    from parametron_jl_amd import _lib
+    r, n = 6, 8
+    L = g.lib()
+    rng = np.random.default_rng(11)
+    s = g.stream()
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, s, C.byref(plan))
+
+    def pinned(count, dtype):
+        p = C.c_void_p()
+        g.call("pmt_host_alloc", count * np.dtype(dtype).itemsize, C.byref(p))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(count * np.dtype(dtype).itemsize,)).view(dtype)
+        a[...] = np.zeros(count, dtype=dtype)
+        return a
+    A_host = np.asfortranarray(rng.random((r, n)))                        # the host language's own array (Julia: Matrix{Float64})
+    C_host = np.ascontiguousarray(rng.random((r, n)))                     # numpy C order
+    b_host = rng.random(r)
+    ldA = 8                                                               # device layout: padded leading dimension
+    mbA, mbC, mbb = pinned(ldA * n, np.float64), pinned(ldA * n, np.float64), pinned(r, np.float64)
+    dA, dC, db, dd = g.empty_f64(ldA * n), g.empty_f64(ldA * n), g.empty_f64(r), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    vmap_h = rng.permutation(n).astype(np.int64) + 5
+    vmap = g.to_dev(vmap_h)
+    t1, c1 = pinned(r * n, g.VAT), pinned(r, np.float64)                  # MOI.VectorAffineFunction of A*x - b: terms, constants (host memory)
+    t2, c2 = pinned(r * n, g.VAT), pinned(r, np.float64)                  # ... of C*x - d
+    seed = C.c_uint64(0)
+    rec = C.c_void_p(L.pmt_plan_recording_stream(plan))
+    devp = lambda a: C.c_void_p(a.ctypes.data)
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_copy_bytes", g.ptr(dA), devp(mbA), 8 * ldA * n, rec)      # mailbox -> Parameter buffer, inside the one launch
+    g.call("pmt_copy_bytes", g.ptr(dC), devp(mbC), 8 * ldA * n, rec)
+    g.call("pmt_copy_bytes", g.ptr(db), devp(mbb), 8 * r, rec)
+    g.call("pmt_fill_uniform_dyn_f64", g.ptr(dd), r, 1, r, C.byref(seed), 2.0, rec)
+    g.call("pmt_affine_pack_vector_f64", g.ptr(dA), ldA, r, n, g.ptr(xvar), g.ptr(db), -1, g.ptr(vmap), 0, devp(t1), devp(c1), rec)
+    g.call("pmt_affine_pack_vector_f64", g.ptr(dC), ldA, r, n, g.ptr(xvar), g.ptr(dd), -1, g.ptr(vmap), 0, devp(t2), devp(c2), rec)
+    g.call("pmt_plan_end_record", plan)
+    groups, nodes, ln = C.c_int(), C.c_int(), C.c_int64()
+    g.call("pmt_plan_fused", plan, C.byref(groups), C.byref(nodes), C.byref(ln))
+    assert ln.value == 1                                                  # the whole update! is ONE launch
+    model = C.c_void_p()
+    g.call("pmt_model_create", plan, C.byref(model))
+    sA, sC, sb, sd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    g.call("pmt_model_add_mailbox", model, devp(A_host), r, n, 1, r, devp(mbA), ldA, C.byref(sA))
+    g.call("pmt_model_add_mailbox", model, devp(C_host), r, n, n, 1, devp(mbC), ldA, C.byref(sC))
+    g.call("pmt_model_add_mailbox", model, devp(b_host), r, 0, 1, 0, devp(mbb), r, C.byref(sb))
+    g.call("pmt_model_add_seed", model, C.byref(seed), C.c_uint64(4), C.c_uint64(1000), C.byref(sd))
+    total = pinned(1, np.float64)
+    g.call("pmt_model_add_constant", model, devp(c1), devp(total))        # (*dst = *src behind the wait: here c1[0] -> total[0])
+    assert (sA.value, sC.value, sb.value, sd.value) == (0, 1, 2, 3) and L.pmt_model_num_slots(model) == 4
+    xi = np.arange(1, n + 1, dtype=np.int64)
+
+    def check(epoch_of_d, Av, Cv, bv):
+        w1t, w1c = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(Av, xi), bv).moi(vmap_h)
+        dv = O.fill_uniform(r, 4 + 1000 * epoch_of_d, 2.0)
+        w2t, w2c = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(Cv, xi), dv).moi(vmap_h)
+        assert np.array_equal(t1.view(np.int64), w1t.view(np.int64)) and np.array_equal(c1.view(np.int64), w1c.view(np.int64))
+        assert np.array_equal(t2.view(np.int64), w2t.view(np.int64)) and np.array_equal(c2.view(np.int64), w2c.view(np.int64))
+        assert total[0] == c1[0]
+    g.call("pmt_model_update", model, None, 0, 1)                         # NULL mask: everything is dirty
+    check(0, A_host, C_host, b_host)
+    for it in range(1, 6):
+        A_keep = A_host.copy()
+        mask = (C.c_ubyte * 4)(0, 1, 1, 1)                                # A's byte is 0: the user did not touch it ...
+        A_host[...] = rng.random((r, n))                                  # ... (this write is NOT announced: the mailbox keeps the old value)
+        C_host[...] = rng.random((r, n)); b_host[...] = rng.random(r)
+        g.call("pmt_model_update", model, mask, 4, 0)                     # asynchronous form
+        g.call("pmt_model_wait", model)
+        check(it, A_keep, C_host, b_host)
+        A_host[...] = A_keep
+    with pytest.raises(_lib.DimensionMismatch):
+        g.call("pmt_model_update", model, (C.c_ubyte * 3)(1, 1, 1), 3, 1)
+    g.call("pmt_model_destroy", model)
+    g.call("pmt_plan_destroy", plan)
+    for a in (mbA, mbC, mbb, t1, c1, t2, c2, total):
+        g.call("pmt_host_free", C.c_void_p(a.ctypes.data))
+
+
+def test_kernels_store_into_registered_host_arrays():
+    """pmt_host_register: an array the host language owns (here a plain numpy array; in Julia the `terms` Vector of an MOI function) is made
+    device-visible in place and given to a recorded entry point as its OUTPUT: the one launch of the small plan stores the MOI triplets
+    straight into it — compared with the oracle byte for byte, solve after solve"""
+    import gpu_util as g
+    from oracle import oracle as O
+    r, n = 5, 7
+    rng = np.random.default_rng(3)
+    s = g.stream()
+    plan = C.c_void_p()
+    g.call("pmt_plan_create", 0, s, C.byref(plan))
+    terms = np.zeros(r * n + 3, dtype=g.VAT)[3:]                         # (deliberately not page-aligned)
+    consts = np.zeros(r)
+    dterms, dconsts = C.c_void_p(), C.c_void_p()
+    g.call("pmt_host_register", C.c_void_p(terms.ctypes.data), terms.nbytes, C.byref(dterms))
+    g.call("pmt_host_register", C.c_void_p(consts.ctypes.data), consts.nbytes, C.byref(dconsts))
+    dA, db = g.empty_f64(r * n), g.empty_f64(r)
+    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
+    seedA, seedb = C.c_uint64(21), C.c_uint64(22)
+    rec = C.c_void_p(g.lib().pmt_plan_recording_stream(plan))
+    g.call("pmt_plan_begin_record", plan)
+    g.call("pmt_fill_uniform_dyn_f64", g.ptr(dA), r, n, r, C.byref(seedA), 1.0, rec)
+    g.call("pmt_fill_uniform_dyn_f64", g.ptr(db), r, 1, r, C.byref(seedb), 1.0, rec)
+    g.call("pmt_affine_pack_vector_f64", g.ptr(dA), r, r, n, g.ptr(xvar), g.ptr(db), -1, None, 0, dterms, dconsts, rec)
+    g.call("pmt_plan_end_record", plan)
+    xi = np.arange(1, n + 1, dtype=np.int64)
+    for it in range(4):
+        seedA.value, seedb.value = 21 + 1000 * it, 22 + 1000 * it
+        g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
+        Av = O.fill_uniform(r * n, seedA.value).reshape(n, r).T
+        wt, wc = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(Av, xi), O.fill_uniform(r, seedb.value)).moi(None)
+        assert np.array_equal(terms.view(np.int64), wt.view(np.int64)) and np.array_equal(consts.view(np.int64), wc.view(np.int64))
+    g.call("pmt_plan_destroy", plan)
+    g.call("pmt_host_unregister", C.c_void_p(terms.ctypes.data)); g.call("pmt_host_unregister", C.c_void_p(consts.ctypes.data))
