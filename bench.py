@@ -12,12 +12,10 @@ MOI coefficient buffer from the Parameter values resident in HBM:
     python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU under torch.distributed.run; started here if RANK is unset)
 
 Prints ONE JSON line of at most 4 KB on stdout (rank 0): the contract's fields, `roofline` of the dominant kernel (HIP events in this run;
-`traffic` from rocprofv3 --pmc children of this run when rocprofv3 is on PATH), `cpu_baseline` (oracle/ on one host core, bounded sample)
-and `summary` — one number per other BASELINE config (C1, C3, C4, C5, tools/bench_configs.py) and `C4_sharded`: config 4 (8192
-independent n = 128 QPs) sharded by instance over the N ranks with the slab exchange behind the C ABI, with `ranks_seen`.  Every full
-object goes to bench_detail.json next to this script (--detail PATH); the longer studies live in tools/bench_study.py.
-N > 1 runs N independent config-2 instances (a single QP's rebuild does not shard: replicas, weak scaling, no collective).
---workload batch runs config 4 alone."""
+`traffic` from rocprofv3 --pmc children of this run, tools/bench_pmc.py), `cpu_baseline` (oracle/ on one host core, bounded sample) and
+`summary`: one number per other BASELINE config (C1, C3, C4, C5: tools/bench_configs.py) and `C4_sharded` — config 4 sharded by instance
+over the N ranks with the slab exchange behind the C ABI, with `ranks_seen`.  Full objects: bench_detail.json (--detail PATH); the longer
+studies: tools/bench_study.py.  N > 1 runs N independent config-2 instances (replicas, weak scaling); --workload batch runs config 4 alone."""
 import argparse
 import ctypes as C
 import json
@@ -68,20 +66,6 @@ def profile_report(_lib):
         name, cnt, tot, mn, mx = line.split("\t")
         out[name] = {"launches": int(cnt), "avg_ms": float(tot) / max(1, int(cnt)), "min_ms": float(mn), "max_ms": float(mx)}
     return out
-
-
-def pmc_replay(prefix):
-    """HBM-side bytes per launch of the kernel whose name starts with `prefix` from the COMMITTED rocprofv3 PMC passes
-    (profiles/pmc_traffic.json) — the fallback when this run cannot measure them (no rocprofv3 on PATH, N > 1)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            data = json.load(fh)
-    except Exception:
-        return None
-    for name, v in data.items():
-        if name.startswith(prefix) and isinstance(v, dict):
-            return {"read": v["read_bytes"], "write": v["write_bytes"]}
-    return None
 
 
 def hbm_roofline(kernel, avg_ms, nbytes, **extra):
@@ -196,72 +180,17 @@ def timed_loop(torch, fn, steps):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# HBM-side traffic of the step's kernels, measured by children of THIS run
+# HBM-side traffic of the step's kernels: rocprofv3 --pmc children of THIS run (tools/bench_pmc.py)
 
-PMC_KERNELS = {"gram_sk_kernel": "gram_sk_kernel<", "gram_sk_fixup_kernel": "gram_sk_fixup_kernel", "gram_linear_kernel": "gram_linear_kernel",
-               "affine_tile_kernel<VAT>": "affine_tile_kernel<1"}
-
-
-def reduce_counter_csv(path, steps):
-    """rocprofv3's counter_collection.csv -> {kernel: mean Counter_Value over its last `steps` launches} for the step's kernels"""
-    import csv
-    rows = list(csv.DictReader(open(path)))
-    out = {}
-    for name, key in PMC_KERNELS.items():
-        v = [float(r["Counter_Value"]) for r in rows if key in r["Kernel_Name"]]
-        if v:
-            out[name] = sum(v[-steps:]) / len(v[-steps:])
-    return out
+def _pmc():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_pmc
+    return bench_pmc
 
 
-def pmc_children(steps=5, timeout=180):
-    """Two short children of this command under `rocprofv3 --kernel-trace --pmc <counter>` — FETCH_SIZE and WRITE_SIZE in SEPARATE passes
-    (they do not fit the TCC's counter slots together), the timed loop only — reduced to bytes per launch as MI355X_MICROARCH.md's HBM
-    section prescribes: both counters in KiB, FETCH_SIZE doubled on gfx950.  None when rocprofv3 is not on PATH; {"error": ...} on failure."""
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3")
-    if not exe:
-        return None
-    env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    res = {}
-    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
-        tmp = tempfile.mkdtemp(prefix="pmt_pmc_")
-        try:
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", str(steps), "--warmup", "1", "--timed-loop-only"]
-            r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {"error": "rocprofv3 --pmc %s child: rc %d, %d counter file(s): %s" % (counter, r.returncode, len(files), r.stderr.decode(errors="replace")[-300:])}
-            res[counter] = {k: v * scale for k, v in reduce_counter_csv(files[0], steps).items()}
-        except Exception as e:
-            return {"error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            shutil.rmtree(tmp, ignore_errors=True)
-    out = {k: {"read": res["FETCH_SIZE"][k], "write": res["WRITE_SIZE"].get(k, 0.0)} for k in res["FETCH_SIZE"]}
-    out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate %d-step children of this invocation on this box; "
-                     "KiB -> bytes, FETCH_SIZE x2 (gfx950)" % steps)
-    return out
-
-
-def attach_traffic(roof, measured, prefix):
-    """roofline.traffic = HBM-side bytes per launch of the dominant kernel: measured by this run's children, else the committed replay"""
-    m = measured.get(DOMINANT) if isinstance(measured, dict) else None
-    if m:
-        roof.update(traffic=m["read"] + m["write"], traffic_read=m["read"], traffic_write=m["write"], measured_in_this_run=True,
-                    traffic_source="rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE children of this run (separate passes, x1024, FETCH x2)")
-        return roof
-    rp = pmc_replay(prefix)
-    why = "rocprofv3 not on PATH" if measured is None else (measured.get("error", "no launches seen") if isinstance(measured, dict) else "not run")
-    roof.update(traffic=(rp["read"] + rp["write"]) if rp else None, traffic_read=rp and rp["read"], traffic_write=rp and rp["write"],
-                measured_in_this_run=False, traffic_source="replay of profiles/pmc_traffic.json (%s)" % why[:160])
-    return roof
-
+pmc_children = lambda steps=5, timeout=180: _pmc().pmc_children(steps, timeout)
+reduce_counter_csv = lambda path, steps: _pmc().reduce_counter_csv(path, steps)
+attach_traffic = lambda roof, measured, prefix: _pmc().attach_traffic(roof, measured, prefix)
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1)
@@ -466,18 +395,14 @@ def compact_line(out, detail_path=None):
     return line
 
 
-def write_detail(out, path):
+def finish(out, args):
+    path = args.detail
     try:
         with open(path, "w") as fh:
             json.dump(out, fh, indent=1)
-        return path
     except Exception as e:
         sys.stderr.write("bench.py: could not write %s (%s)\n" % (path, e))
-        return None
-
-
-def finish(out, args):
-    path = write_detail(out, args.detail)
+        path = None
     emit_line(compact_line(out, path))
 
 
