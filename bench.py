@@ -202,7 +202,6 @@ def cpu_baseline(wl):
     import bench_configs
     return bench_configs.cpu_baseline(wl)
 
-
 # ---------------------------------------------------------------------------------------------------------------------------
 # stdout, launcher
 
