@@ -17,6 +17,8 @@ for it in range(count):
     n = int(rng.choice(edges_n)) if rng.random() < 0.5 else int(rng.integers(1, 700))
     rmax = max(1, min(20000, (1 << 24) // n))
     r = min(rmax, int(rng.choice(edges_r)) if rng.random() < 0.5 else int(rng.integers(1, rmax + 1)))
+    if n <= 64 and rng.random() < 0.4:                 # the stream form of the narrow panels starts at 32768 rows (round 6)
+        r = int(rng.choice([32767, 32768, 32769, 32784, 40001, 65536, 65537, 70000])) if rng.random() < 0.6 else int(rng.integers(32768, 90000))
     lda = r + int(rng.integers(0, 3)) * int(rng.integers(0, 5))
     shift = int(rng.integers(0, 2))
     sign = int(rng.choice([-1, 0, 1]))
