@@ -349,7 +349,7 @@ def summary_of(out):
         "C4_sharded_ms": _get(c, "C4_sharded", "ms_per_step"), "C4_sharded_value": _get(c, "C4_sharded", "value"),
         "rccl_calls_made": _get(c, "C4_sharded", "rccl_calls_made"),
         "affine_warm_frac": _get(out, "roofline_affine", "frac"), "affine_cold_frac": _get(out, "roofline_affine", "cold", "frac"),
-        "pack_cold_frac": _get(out, "roofline_constraint_pack", "frac"),
+        "pack_cold_frac": _get(out, "roofline_constraint_pack", "frac"), "pack_in_step_frac_rocprofv3": _get(out, "pack_in_step_rocprofv3", "frac"),
         "gram_shape_frac": {k: round(v["frac"], 3) for k, v in (c.get("shapes") or {}).items() if isinstance(v, dict) and "frac" in v} or None,
         "gram_shape_us": {k: round(v["node_ms"] * 1e3, 1) for k, v in (c.get("shapes") or {}).items() if isinstance(v, dict) and "node_ms" in v} or None,
         "cpu_blas_all_cores": _get(out, "cpu_canonical_blas", "value"), "ranks_seen": out.get("ranks_seen"),
@@ -361,7 +361,7 @@ def summary_of(out):
 
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
              "config", "ranks_seen", "step_algorithmic_bytes", "step_flops")
-ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "launches", "traffic", "traffic_read", "traffic_write",
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "avg_ms_rocprofv3", "launches", "traffic", "traffic_read", "traffic_write",
                  "measured_in_this_run", "traffic_source", "algorithmic_flops", "algorithmic_bytes", "peak_source")
 CPU_KEYS = ("value", "unit", "cores", "host_cores", "kind", "sample", "seconds_per_reevaluation_extrapolated")
 
@@ -414,6 +414,9 @@ def sections(out, args, torch, P, _lib, wl, BC):
         measured = "not run (--no-pmc)" if args.no_pmc else guarded(pmc_children)
         out["pmc_traffic"] = measured
         attach_traffic(out["roofline"], measured, "pmt::gram_sk_kernel<2, 16, 2, 0, false>")
+        us = _get(measured, "affine_tile_kernel<VAT>", "rocprofv3_us")
+        if us:      # the constraint pack INSIDE the step (cold input behind the contraction) by the profiler's own clock, this run
+            out["pack_in_step_rocprofv3"] = hbm_roofline("affine_tile_kernel<VAT>", us * 1e-3, 32.0 * wl.m * wl.n, source="rocprofv3 --kernel-trace child of this run (no counters), 20 timed steps")
     if not args.no_configs:
         ksteps = max(50, min(args.steps, 100))      # (at least 50 steps: 20 steps of a 1.3 ms configuration are too short to average out a hiccup)
         out["configs"] = {"C1": guarded(BC.config_c1, torch, P, _lib), "C3": guarded(BC.config_c3, torch, P, _lib, ksteps),
@@ -426,13 +429,10 @@ def sections(out, args, torch, P, _lib, wl, BC):
 def main():
     args = parse_args()
     claim_stdout()
-    if args.gpus < 1:
-        fail("--gpus must be >= 1")
+    args.gpus >= 1 or fail("--gpus must be >= 1")
     if "RANK" not in os.environ and (args.gpus > 1 or args.dry_launch):
         return self_launch(args, sys.argv[1:])
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     if world != args.gpus:
         # a launcher started a different number of ranks than the command line names: the line would carry the wrong n_gpus either way
         if rank == 0:

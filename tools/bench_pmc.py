@@ -41,6 +41,19 @@ def reduce_counter_csv(path, steps):
     return out
 
 
+def reduce_trace_csv(path, steps):
+    """rocprofv3's kernel_trace.csv -> {kernel: mean duration in us over its last `steps` launches} for the step's kernels (the profiler's
+    own clock; under --pmc the dispatches are serialised, a kernel's own begin-to-end time is what it is in the step)"""
+    import csv
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    out = {}
+    for name, key in PMC_KERNELS.items():
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if key in r["Kernel_Name"]]
+        if d:
+            out[name] = sum(d[-steps:]) / len(d[-steps:])
+    return out
+
+
 def pmc_children(steps=5, timeout=180):
     """Two short children of this command under `rocprofv3 --kernel-trace --pmc <counter>` — FETCH_SIZE and WRITE_SIZE in SEPARATE passes
     (they do not fit the TCC's counter slots together), the timed loop only — reduced to bytes per launch as MI355X_MICROARCH.md's HBM
@@ -56,12 +69,20 @@ def pmc_children(steps=5, timeout=180):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     res = {}
-    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+    # a third child WITHOUT counters (a --pmc pass serialises and stretches the dispatches: the pack reads 14.3 us there, 12.7 plain): the
+    # profiler's own begin / end stamps of the step's kernels over 20 timed steps
+    for counter, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0), (None, 0.0)):
         tmp = tempfile.mkdtemp(prefix="pmt_pmc_")
         try:
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable, BENCH,
-                   "--steps", str(steps), "--warmup", "1", "--timed-loop-only"]
+            nsteps = steps if counter else 20
+            cmd = [exe, "--kernel-trace"] + (["--pmc", counter] if counter else []) + ["--output-format", "csv", "-d", tmp, "--", sys.executable, BENCH,
+                   "--steps", str(nsteps), "--warmup", "5" if not counter else "1", "--timed-loop-only"]
             r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            if not counter:
+                traces = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+                if r.returncode == 0 and traces:
+                    res["durations"] = reduce_trace_csv(traces[0], nsteps)
+                continue
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": "rocprofv3 --pmc %s child: rc %d, %d counter file(s): %s" % (counter, r.returncode, len(files), r.stderr.decode(errors="replace")[-300:])}
@@ -71,8 +92,10 @@ def pmc_children(steps=5, timeout=180):
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     out = {k: {"read": res["FETCH_SIZE"][k], "write": res["WRITE_SIZE"].get(k, 0.0)} for k in res["FETCH_SIZE"]}
+    for k, us in res.get("durations", {}).items():
+        out.setdefault(k, {})["rocprofv3_us"] = us
     out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate %d-step children of this invocation on this box; "
-                     "KiB -> bytes, FETCH_SIZE x2 (gfx950)" % steps)
+                     "KiB -> bytes, FETCH_SIZE x2 (gfx950); rocprofv3_us: a third child with --kernel-trace only, 20 timed steps" % steps)
     return out
 
 
@@ -82,6 +105,8 @@ def attach_traffic(roof, measured, prefix):
     if m:
         roof.update(traffic=m["read"] + m["write"], traffic_read=m["read"], traffic_write=m["write"], measured_in_this_run=True,
                     traffic_source="rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE children of this run (separate passes, x1024, FETCH x2)")
+        if m.get("rocprofv3_us"):           # the same kernel by the profiler's own clock (a third child, --kernel-trace only)
+            roof["avg_ms_rocprofv3"] = m["rocprofv3_us"] * 1e-3
         return roof
     rp = pmc_replay(prefix)
     why = "rocprofv3 not on PATH" if measured is None else (measured.get("error", "no launches seen") if isinstance(measured, dict) else "not run")
