@@ -522,12 +522,6 @@ size_t pmt_plan_bytes_allocated(const pmt_plan *plan);
 /* page-locked host memory (e.g. for the MOI function buffers pmt_plan_fetch writes into); not tied to a plan */
 int pmt_host_alloc(size_t bytes, void **out_host_ptr);
 int pmt_host_free(void *host_ptr);
-/* memory the host language owns (the `terms` Vector of an MOI function, src/moi_interop.jl:36-37,65,70, after its resize!) page-locked
- * and made device-visible IN PLACE: *out_device_ptr is what a recorded entry point is given as its output pointer — the kernel stores
- * straight into the host array (small models: a few KB over PCIe from inside the one launch; no device twin, no fetch).  The array must
- * stay alive and keep its size until pmt_host_unregister. */
-int pmt_host_register(void *host_ptr, size_t bytes, void **out_device_ptr);
-int pmt_host_unregister(void *host_ptr);
 /* asynchronous copies on the plan's stream */
 int pmt_plan_upload(pmt_plan *plan, void *device_dst, const void *host_src, size_t bytes);
 int pmt_plan_fetch(pmt_plan *plan, void *host_dst, const void *device_src, size_t bytes);

@@ -256,16 +256,18 @@ function host_alloc(n::Integer)
 end
 host_free(v::Vector{Float64}) = check(ccall((:pmt_host_free, lib), Cint, (Ptr{Cvoid},), pointer(v)))
 
-"""host_register(v) -> DevPtr: the memory of a Julia array the HOST keeps using as the object it is (`moi_f.terms` after its `resize!`,
-src/moi_interop.jl:36-37,65,70) page-locked and device-visible in place (pmt_host_register).  The returned address is what a recorded entry
-point is given as its output: the kernel stores straight into the Julia array — no device twin, no fetch.  Julia's GC does not move arrays;
-the caller keeps `v` alive and un-resized until `host_unregister(v)`."""
-function host_register(v::Array)
+"""host_alloc_as(T, n) -> Vector{T} over page-locked memory (pmt_host_alloc) for an isbits T — e.g. the `terms` vector of an MOI function
+(`MOI.VectorAffineTerm{Float64}` = 24 bytes = pmt_vector_affine_term): a recorded entry point is given `pointer(v)` as its output and the kernel
+stores straight into the vector the function object holds — no device twin, no fetch.  NOT garbage collected (`host_free_ptr(pointer(v))`).
+(Registering the host language's own arrays in place — hipHostRegister — was tried in round 6 and removed: small heap arrays share pages
+with their neighbours, and unregistering one pulls the mapping from under the others.)"""
+function host_alloc_as(::Type{T}, n::Integer) where {T}
+    isbitstype(T) || throw(ArgumentError("host_alloc_as: $T is not an isbits type"))
     ref = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:pmt_host_register, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), pointer(v), max(sizeof(v), 1), ref))
-    DevPtr(ref[])
+    check(ccall((:pmt_host_alloc, lib), Cint, (Csize_t, Ref{Ptr{Cvoid}}), sizeof(T) * max(n, 1), ref))
+    unsafe_wrap(Array, Ptr{T}(ref[]), n; own = false)
 end
-host_unregister(v::Array) = check(ccall((:pmt_host_unregister, lib), Cint, (Ptr{Cvoid},), pointer(v)))
+host_free_ptr(p::Ptr) = check(ccall((:pmt_host_free, lib), Cint, (Ptr{Cvoid},), p))
 
 # ---- update!(m::Model) of a SMALL model behind one call (include/parametron_hip.h: pmt_model_*; csrc/modelrun.hip)
 "the per-solve walk of a small model: mailboxes of host-updated Parameters, seed words of device-regenerated ones, fetches, constants"

@@ -384,15 +384,23 @@ function small_model(model::Model, handoff::Symbol)
     total <= SMALL_MODEL_ELEMENTS
 end
 
-"""An MOI buffer of a record: in a small model the function object's OWN vector, page-locked in place (H.host_register) — the kernel stores
-into it from inside the one launch and there is no device twin; otherwise a plan-owned device buffer that update! fetches."""
-function output_buffer(hm::HIPModel, host::Vector, n::Integer, elbytes::Integer)
-    hm.small || return H.alloc(hm.plan, elbytes * max(n, 1))
-    resize!(host, max(n, 1))                   # (as the reference's update! does, src/moi_interop.jl:37,48,53,65,70: in place, never again)
-    n == 0 && resize!(host, 0)
-    n == 0 && return H.alloc(hm.plan, elbytes)
-    push!(hm.registered, host)
-    H.host_register(host)
+"""An MOI buffer of a record.  In a small model: a page-locked vector (H.host_alloc_as) that BECOMES the function object's vector — the kernel
+stores into it from inside the one launch and there is no device twin; returns (device-visible pointer, the vector).  Otherwise a plan-owned
+device buffer that update! fetches; returns (pointer, nothing)."""
+function output_buffer(hm::HIPModel, ::Type{T}, n::Integer) where {T}
+    (hm.small && n > 0) || return H.alloc(hm.plan, sizeof(T) * max(n, 1)), nothing
+    v = H.host_alloc_as(T, n)
+    push!(hm.registered, v)                    # (kept alive — and never resized — for the life of the plan)
+    DevPtr(pointer(v)), v
+end
+"""the objective's MOI buffers: in a small model its quadratic_terms / affine_terms become page-locked vectors the kernels store into (the
+function object is mutable, src/moi_interop.jl:44-53, as the delivery path below already relies on)"""
+function adopt_objective_buffers!(hm::HIPModel, objective, nq::Integer, nl::Integer)
+    quad, qv = output_buffer(hm, MOI.ScalarQuadraticTerm{Float64}, nq)
+    lin, lv = output_buffer(hm, MOI.ScalarAffineTerm{Float64}, nl)
+    qv === nothing || (objective.f.quadratic_terms = qv)
+    lv === nothing || (objective.f.affine_terms = lv)
+    quad, lin
 end
 "the scalar functions' constant: a page-locked word the kernel stores into (small models) or a device word that is fetched"
 function constant_buffer(hm::HIPModel)
@@ -444,7 +452,7 @@ function record_objective!(hm::HIPModel, objective, rec)
         d = device_param!(hm, bil.Q)
         xv = upload_indices(hm.plan, Int64[v.index for v in bil.x]); yv = upload_indices(hm.plan, Int64[v.index for v in bil.y])
         nq = d.rows * d.cols
-        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, 0, 16)
+        quad, lin = adopt_objective_buffers!(hm, objective, nq, 0)
         constant, cbuf = constant_buffer(hm)
         H.bilinear!(quad, d.buf, d.ld, d.rows, d.cols, xv, yv, 1, hm.varmap, rec)
         return HIPObjective(objective, quad, lin, constant, nq, 0, cbuf, DevPtr(C_NULL), Float64[])
@@ -466,7 +474,7 @@ function record_objective!(hm::HIPModel, objective, rec)
         # literal: the reference's term order and coefficients bit for bit (src/functions.jl:702-709 over :548-576, moi_interop.jl:45-62)
         nq, nl = r * n * n, 2 * r * n
         res, resc = H.alloc(hm.plan, 16 * r * n), H.alloc(hm.plan, 8 * r)
-        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, nl, 16)
+        quad, lin = adopt_objective_buffers!(hm, objective, nq, nl)
         constant, cbuf = constant_buffer(hm)
         H.affine_assemble!(res, resc, A, lda, r, n, xvar, b, da.sign, rec)
         H.quad_expand!(quad, lin, constant, r, res, n, resc, res, n, resc, 1, hm.varmap, rec)
@@ -476,7 +484,7 @@ function record_objective!(hm::HIPModel, objective, rec)
     nq = div(n * (n + 1), 2)
     if hm.small
         # a small model: the node stores its terms straight into the function object's own (registered) vectors; nothing to deliver
-        quad, lin = output_buffer(hm, objective.f.quadratic_terms, nq, 24), output_buffer(hm, objective.f.affine_terms, n, 16)
+        quad, lin = adopt_objective_buffers!(hm, objective, nq, n)
         constant, cbuf = constant_buffer(hm)
         ws = H.alloc(hm.plan, H.quad_gram_workspace_bytes(padded_rows(r), n))
         H.quad_gram!(quad, lin, constant, A, lda, padded_rows(r), n, xvar, b, da.sign, 1, hm.varmap, ws, rec)
@@ -557,7 +565,13 @@ function record_constraint!(hm::HIPModel, constraint, rec)
     pieces = analyse_pieces(constraint.expr)
     rows = sum(p -> piece_rows(hm, p), pieces)
     nterms = sum(p -> piece_terms(hm, p), pieces)
-    terms, constants = output_buffer(hm, constraint.f.terms, nterms, 24), output_buffer(hm, constraint.f.constants, rows, 8)
+    terms, tv = output_buffer(hm, MOI.VectorAffineTerm{Float64}, nterms)
+    constants, cv = output_buffer(hm, Float64, rows)
+    if tv !== nothing && cv !== nothing
+        # MOI.VectorAffineFunction is immutable, the reference's Constraint record is not (src/moi_interop.jl:141-147): the record gets a function
+        # object of the same type whose vectors ARE the page-locked ones
+        constraint.f = typeof(constraint.f)(tv, cv)
+    end
     # A constraint that reads Parameter values only (no node of the tape feeds it) is independent of every other record (update! of one
     # Constraint, src/moi_interop.jl:168-175): beside a canonical least-squares objective it goes to the plan's side lane
     independent = all(p -> !(p isa DenseAffine && p.transposed) && !(p isa ScaledAffine), pieces)

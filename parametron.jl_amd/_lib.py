@@ -130,8 +130,6 @@ SIGNATURES = {
     "pmt_plan_bytes_allocated": (_sz, [_vp]),
     "pmt_host_alloc": (_ci, [_sz, C.POINTER(_vp)]),
     "pmt_host_free": (_ci, [_vp]),
-    "pmt_host_register": (_ci, [_vp, _sz, C.POINTER(_vp)]),
-    "pmt_host_unregister": (_ci, [_vp]),
     "pmt_plan_upload": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_fetch": (_ci, [_vp, _vp, _vp, _sz]),
     "pmt_plan_zero": (_ci, [_vp, _vp, _sz]),

@@ -47,9 +47,6 @@
 #ifndef PMT_TALL_DIAG3
 #define PMT_TALL_DIAG3 1         // a diagonal block's third rotation is not computed (tall_diag_rule)
 #endif
-#ifndef PMT_TALL_DEAL
-#define PMT_TALL_DEAL 0          // 0: blocks dealt by rectangles (36 / 34 / 33 / 33 MFMAs per k-step); 1: two diagonal + seven other blocks per wave (34 each)
-#endif
 
 namespace pmt {
 
@@ -59,77 +56,46 @@ constexpr int TGP = TBK + 2;                // LDS pitch of a column: 2 mod 32 â
 constexpr int TSUB = TBK / 16;              // 16-row pieces of a column per stage
 constexpr int TLK = PMT_TALL_K2 ? 2 : 1;    // rows between the contraction slots of a k-step (see tall_stage)
 constexpr int TCOLS = 128;                  // columns of the one tile
-constexpr int TBLK = 9;                     // 16 x 16 blocks per wave
-constexpr int TACC = TBLK * 4;              // accumulators per lane (4 rotations per block)
-constexpr int TPART = 4 * TACC * 64;        // doubles of triangle partial per workgroup (= 36 blocks x 256)
-constexpr int TSTRIDE = TPART + TCOLS + 8;  // + q partial + c'c partial (padded to 64 bytes)
+constexpr int TBLK = 9;                     // 16 x 16 blocks per wave at most (NBC = 8)
+constexpr int TACC = TBLK * 4;              // accumulators per lane at most (4 rotations per block)
+constexpr int TPART = 4 * TACC * 64;        // doubles of triangle partial per workgroup at most (= 36 blocks x 256)
+constexpr int TSTRIDE = TPART + TCOLS + 8;  // + q partial + c'c partial (padded to 64 bytes): what the workspace is sized for
 constexpr int TSLICES = 16;                 // interleaved slices of the fix-up sum
 constexpr int TALL_MAX_G = PMT_TALL_MAXG;             // workgroups (row chunks) at most
 constexpr int TALL_MIN_CHUNK = 64;          // rows per chunk at least (one stage for one-tile shapes of up to 2048 rows: tall_chunk)
 
-// the 36 upper-triangular blocks (tm <= tn) of the 8 x 8 block grid, nine per wave:
-//   wave 0: rows {0,1,2} x cols {5,6,7}
-//   wave 1: rows {0,1,2} x cols {3,4}, and the triangle on {3,4}
-//   wave 2: the triangle on {0,1,2}, and row 3 x cols {5,6,7}
-//   wave 3: rows 4..7 x cols {5,6,7} on and above the diagonal
-// (local constexpr tables inside constexpr functions: usable from device code without a device-side definition; every use below has
-// compile-time arguments after unrolling)
-#if PMT_TALL_DEAL == 0
-__host__ __device__ constexpr int tw_nr(int w) { constexpr int t[4] = {3, 5, 4, 4}; return t[w]; }
-__host__ __device__ constexpr int tw_nc(int w) { constexpr int t[4] = {3, 2, 6, 3}; return t[w]; }
-__host__ __device__ constexpr int tw_row(int w, int i) {          // i-th distinct block row of wave w
-    constexpr int t[4][5] = {{0, 1, 2, 0, 0}, {0, 1, 2, 3, 4}, {0, 1, 2, 3, 0}, {4, 5, 6, 7, 0}};
-    return t[w][i];
+// NBC = block columns of the one tile the kernel is built for: 8 (113 .. 128 columns, and every diagonal tile of a wide matrix), 7 (97 .. 112),
+// 6 (81 .. 96), 5 (65 .. 80) â€” round 6: a 100-column matrix used to pay for all 36 blocks of the 128-column triangle (2^20 x 80: 342 us,
+// the same as 2^20 x 128).  The upper triangle of the NBC x NBC block grid is dealt to the four waves so that their MFMA counts are level
+// (3 per diagonal block, 4 per other: 33-36 / 26-27 / 19-20 / 11-15 per pair of k-steps) and each wave needs few distinct operand rows /
+// columns from LDS.  NBC = 8 is round 5's dealing by rectangles:
+//   wave 0: rows {0,1,2} x cols {5,6,7}        wave 1: rows {0,1,2} x cols {3,4}, and the triangle on {3,4}
+//   wave 2: the triangle on {0,1,2}, and row 3 x cols {5,6,7}        wave 3: rows 4..7 x cols {5,6,7} on and above the diagonal
+// 5, 6, 7 come from a small annealing search (tools/gen_tall_deal.py prints these tables).  (Local constexpr tables inside constexpr
+// functions: usable from device code without a device-side definition; every use below has compile-time arguments after unrolling.)
+__host__ __device__ constexpr int tw_nblk(int nbc, int w) { constexpr int t[4][4] = {{3, 4, 4, 4}, {5, 5, 5, 6}, {7, 7, 7, 7}, {9, 9, 9, 9}}; return t[nbc - 5][w]; }
+__host__ __device__ constexpr int tw_nr(int nbc, int w) { constexpr int t[4][4] = {{3, 3, 4, 2}, {5, 5, 4, 4}, {3, 4, 4, 5}, {3, 5, 4, 4}}; return t[nbc - 5][w]; }
+__host__ __device__ constexpr int tw_nc(int nbc, int w) { constexpr int t[4][4] = {{1, 2, 1, 2}, {1, 1, 2, 4}, {3, 2, 2, 2}, {3, 2, 6, 3}}; return t[nbc - 5][w]; }
+__host__ __device__ constexpr int tw_row(int nbc, int w, int i) {          // i-th distinct block row of wave w
+    constexpr int t[4][4][6] = {{{2, 3, 4, 0, 0, 0}, {0, 1, 2, 0, 0, 0}, {0, 1, 2, 3, 0, 0}, {0, 1, 0, 0, 0, 0}}, {{0, 1, 2, 3, 4, 0}, {0, 1, 2, 3, 4, 0}, {0, 1, 2, 3, 0, 0}, {0, 1, 2, 5, 0, 0}}, {{0, 1, 2, 0, 0, 0}, {3, 4, 5, 6, 0, 0}, {0, 1, 2, 3, 0, 0}, {0, 1, 2, 3, 4, 0}}, {{0, 1, 2, 0, 0, 0}, {0, 1, 2, 3, 4, 0}, {0, 1, 2, 3, 0, 0}, {4, 5, 6, 7, 0, 0}}};
+    return t[nbc - 5][w][i];
 }
-__host__ __device__ constexpr int tw_col(int w, int i) {          // i-th distinct block column of wave w
-    constexpr int t[4][6] = {{5, 6, 7, 0, 0, 0}, {3, 4, 0, 0, 0, 0}, {0, 1, 2, 5, 6, 7}, {5, 6, 7, 0, 0, 0}};
-    return t[w][i];
+__host__ __device__ constexpr int tw_col(int nbc, int w, int i) {          // i-th distinct block column of wave w
+    constexpr int t[4][4][6] = {{{4, 0, 0, 0, 0, 0}, {0, 2, 0, 0, 0, 0}, {3, 0, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}}, {{5, 0, 0, 0, 0, 0}, {4, 0, 0, 0, 0, 0}, {1, 3, 0, 0, 0, 0}, {0, 1, 2, 5, 0, 0}}, {{0, 2, 6, 0, 0, 0}, {5, 6, 0, 0, 0, 0}, {3, 5, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}}, {{5, 6, 7, 0, 0, 0}, {3, 4, 0, 0, 0, 0}, {0, 1, 2, 5, 6, 7}, {5, 6, 7, 0, 0, 0}}};
+    return t[nbc - 5][w][i];
 }
-__host__ __device__ constexpr int tw_blk(int w, int k, int which) {   // block k of wave w: (index into its rows, index into its columns)
-    constexpr int t[4][TBLK][2] = {
-        {{0, 0}, {1, 0}, {2, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}},
-        {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {4, 1}},
-        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 3}, {3, 4}, {3, 5}},
-        {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}}};
-    return t[w][k][which];
+__host__ __device__ constexpr int tw_blk(int nbc, int w, int k, int which) {   // block k of wave w: (index into its rows, index into its columns; 6: a padding slot)
+    constexpr int t[4][4][TBLK][2] = {{{{0, 0}, {1, 0}, {2, 0}, {0, 6}, {0, 6}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 6}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {0, 6}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {0, 6}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}}, {{{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {0, 6}, {0, 6}, {0, 6}, {0, 6}}, {{0, 0}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 3}, {0, 6}, {0, 6}, {0, 6}}}, {{{0, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {2, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 6}, {0, 6}}, {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {4, 1}, {0, 6}, {0, 6}}}, {{{0, 0}, {1, 0}, {2, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}}, {{0, 0}, {1, 0}, {2, 0}, {3, 0}, {0, 1}, {1, 1}, {2, 1}, {3, 1}, {4, 1}}, {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 3}, {3, 4}, {3, 5}}, {{0, 0}, {1, 0}, {0, 1}, {1, 1}, {2, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 2}}}};
+    return t[nbc - 5][w][k][which];
 }
+__host__ __device__ constexpr int tall_tblk(int nbc) { return nbc == 8 ? 9 : nbc == 7 ? 7 : nbc == 6 ? 6 : 4; }      // accumulator slots (blocks) per wave
+__host__ __device__ constexpr int tall_tacc(int nbc) { return 4 * tall_tblk(nbc); }
+__host__ __device__ constexpr int tall_part(int nbc) { return 4 * tall_tacc(nbc) * 64; }
+__host__ __device__ constexpr int tall_stride(int nbc) { return tall_part(nbc) + TCOLS + 8; }
 
-// (tm, tn) of block k of wave w, for the fix-up kernel (the same tables, as data)
-__device__ __constant__ signed char TALL_BLOCKS[4][TBLK][2] = {
-    {{0, 5}, {1, 5}, {2, 5}, {0, 6}, {1, 6}, {2, 6}, {0, 7}, {1, 7}, {2, 7}},
-    {{0, 3}, {1, 3}, {2, 3}, {3, 3}, {0, 4}, {1, 4}, {2, 4}, {3, 4}, {4, 4}},
-    {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 5}, {3, 6}, {3, 7}},
-    {{4, 5}, {5, 5}, {4, 6}, {5, 6}, {6, 6}, {4, 7}, {5, 7}, {6, 7}, {7, 7}},
-};
+// (tm, tn) of block k of wave w, for the fix-up kernel (the same tables, as data; -1: a padding slot)
+__device__ __constant__ signed char TALL_BLOCKS[4][4][TBLK][2] = {{{{2, 4}, {3, 4}, {4, 4}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 0}, {0, 2}, {1, 2}, {2, 2}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 3}, {1, 3}, {2, 3}, {3, 3}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 1}, {1, 1}, {0, 4}, {1, 4}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}}, {{{0, 5}, {1, 5}, {2, 5}, {3, 5}, {4, 5}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 4}, {1, 4}, {2, 4}, {3, 4}, {4, 4}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 1}, {0, 3}, {1, 3}, {2, 3}, {3, 3}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}}, {{0, 0}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {5, 5}, {-1, -1}, {-1, -1}, {-1, -1}}}, {{{0, 0}, {0, 2}, {1, 2}, {2, 2}, {0, 6}, {1, 6}, {2, 6}, {-1, -1}, {-1, -1}}, {{3, 5}, {4, 5}, {5, 5}, {3, 6}, {4, 6}, {5, 6}, {6, 6}, {-1, -1}, {-1, -1}}, {{0, 3}, {1, 3}, {2, 3}, {3, 3}, {0, 5}, {1, 5}, {2, 5}, {-1, -1}, {-1, -1}}, {{0, 1}, {1, 1}, {0, 4}, {1, 4}, {2, 4}, {3, 4}, {4, 4}, {-1, -1}, {-1, -1}}}, {{{0, 5}, {1, 5}, {2, 5}, {0, 6}, {1, 6}, {2, 6}, {0, 7}, {1, 7}, {2, 7}}, {{0, 3}, {1, 3}, {2, 3}, {3, 3}, {0, 4}, {1, 4}, {2, 4}, {3, 4}, {4, 4}}, {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {2, 2}, {3, 5}, {3, 6}, {3, 7}}, {{4, 5}, {5, 5}, {4, 6}, {5, 6}, {6, 6}, {4, 7}, {5, 7}, {6, 7}, {7, 7}}}};
 
-#else
-// (the balanced dealing: index pairs {0,1} .. {6,7}, a wave owns the triangle on its pair and six cross blocks; profiles/r05_gram_tall.txt)
-__host__ __device__ constexpr int tw_nr(int w) { constexpr int t[4] = {2, 2, 4, 6}; return t[w]; }
-__host__ __device__ constexpr int tw_nc(int w) { constexpr int t[4] = {5, 5, 4, 3}; return t[w]; }
-__host__ __device__ constexpr int tw_row(int w, int i) {
-    constexpr int t[4][6] = {{0, 1, 0, 0, 0, 0}, {2, 3, 0, 0, 0, 0}, {4, 5, 0, 1, 0, 0}, {6, 7, 4, 5, 2, 3}};
-    return t[w][i];
-}
-__host__ __device__ constexpr int tw_col(int w, int i) {
-    constexpr int t[4][6] = {{0, 1, 5, 6, 7, 0}, {2, 3, 5, 6, 7, 0}, {4, 5, 2, 3, 0, 0}, {6, 7, 4, 0, 0, 0}};
-    return t[w][i];
-}
-__host__ __device__ constexpr int tw_blk(int w, int k, int which) {
-    constexpr int t[4][TBLK][2] = {
-        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
-        {{0, 0}, {0, 1}, {1, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
-        {{0, 0}, {0, 1}, {1, 1}, {2, 2}, {3, 2}, {2, 3}, {3, 3}, {2, 0}, {3, 0}},
-        {{0, 0}, {0, 1}, {1, 1}, {2, 0}, {3, 0}, {2, 1}, {3, 1}, {4, 2}, {5, 2}}};
-    return t[w][k][which];
-}
-__device__ __constant__ signed char TALL_BLOCKS[4][TBLK][2] = {
-    {{0, 0}, {0, 1}, {1, 1}, {0, 5}, {1, 5}, {0, 6}, {1, 6}, {0, 7}, {1, 7}},
-    {{2, 2}, {2, 3}, {3, 3}, {2, 5}, {3, 5}, {2, 6}, {3, 6}, {2, 7}, {3, 7}},
-    {{4, 4}, {4, 5}, {5, 5}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}},
-    {{6, 6}, {6, 7}, {7, 7}, {4, 6}, {5, 6}, {4, 7}, {5, 7}, {2, 4}, {3, 4}},
-};
-
-#endif
 struct TallArgs {
     const double *A; int64_t lda, rows, cols;
     const double *b; int sign;            // c_i = 0.0 (+|-) b[i]; b == null or sign == 0: c = 0
@@ -172,31 +138,31 @@ __device__ __forceinline__ double rot_blocks(double v) {
 // PMT_TALL_K2: the MFMA's contraction slot k = lane >> 4 of k-steps 2j and 2j + 1 is given the ADJACENT rows 8j + 2k and 8j + 2k + 1 (any
 // assignment of rows to slots is a valid contraction as long as both operands use it), so ONE 16-byte LDS read per operand serves two
 // k-steps: half the LDS instructions and half the operand waits per MFMA.
-template <int W>
-__device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int lm, double (&acc)[TACC]) {
-    constexpr int NR = tw_nr(W), NC = tw_nc(W);
+template <int NBC, int W>
+__device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int lm, double (&acc)[tall_tacc(NBC)]) {
+    constexpr int NR = tw_nr(NBC, W), NC = tw_nc(NBC, W), NBLK = tw_nblk(NBC, W);
 #if PMT_TALL_K2
 #pragma unroll PMT_TALL_UNROLL
     for (int kk = 0; kk < TBK / 8; ++kk) {
         f64x2 a[NR];
 #pragma unroll
-        for (int t = 0; t < NR; ++t) a[t] = *reinterpret_cast<const f64x2 *>(panel + (tw_row(W, t) * 16 + lm) * TGP + kk * 8);
+        for (int t = 0; t < NR; ++t) a[t] = *reinterpret_cast<const f64x2 *>(panel + (tw_row(NBC, W, t) * 16 + lm) * TGP + kk * 8);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f64x2 bv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks (gram_sk.hip, lane maps)
-                bv[r] = *reinterpret_cast<const f64x2 *>(panel + (tw_col(W, c) * 16 + rc) * TGP + kk * 8);
+                bv[r] = *reinterpret_cast<const f64x2 *>(panel + (tw_col(NBC, W, c) * 16 + rc) * TGP + kk * 8);
             }
 #pragma unroll
-            for (int k = 0; k < TBLK; ++k) {
-                if (tw_blk(W, k, 1) != c) continue;
+            for (int k = 0; k < NBLK; ++k) {
+                if (tw_blk(NBC, W, k, 1) != c) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;      // (diagonal block: see below)
-                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
-                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
+                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(NBC, W, tw_blk(NBC, W, k, 0)) == tw_col(NBC, W, c)) continue;      // (diagonal block: see below)
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(NBC, W, k, 0)].x, bv[r].x, acc[k * 4 + r], 0, 0, 0);
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(NBC, W, k, 0)].y, bv[r].y, acc[k * 4 + r], 0, 0, 0);
                 }
             }
         }
@@ -206,24 +172,24 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
     for (int ks = 0; ks < TBK / 4; ++ks) {
         double a[NR];
 #pragma unroll
-        for (int t = 0; t < NR; ++t) a[t] = panel[(tw_row(W, t) * 16 + lm) * TGP + ks * 4];
+        for (int t = 0; t < NR; ++t) a[t] = panel[(tw_row(NBC, W, t) * 16 + lm) * TGP + ks * 4];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             double bv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rc = ((((lm >> 2) + r) & 3) << 2) | (lm & 3);      // column group rotated by r blocks (gram_sk.hip, lane maps)
-                bv[r] = panel[(tw_col(W, c) * 16 + rc) * TGP + ks * 4];
+                bv[r] = panel[(tw_col(NBC, W, c) * 16 + rc) * TGP + ks * 4];
             }
 #pragma unroll
-            for (int k = 0; k < TBLK; ++k) {
-                if (tw_blk(W, k, 1) != c) continue;
+            for (int k = 0; k < NBLK; ++k) {
+                if (tw_blk(NBC, W, k, 1) != c) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // a DIAGONAL block's third rotation â€” 4 x 4 sub-blocks (b, b + 3) â€” holds the transposes of the first rotation's
                     // (b + 1, b): never computed, the fix-up reads the (3, 0) sub-block of rotation 1 as (0, 3) (tall_diag_rule)
-                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(W, tw_blk(W, k, 0)) == tw_col(W, c)) continue;
-                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(W, k, 0)], bv[r], acc[k * 4 + r], 0, 0, 0);
+                    if (PMT_TALL_DIAG3 && r == 3 && tw_row(NBC, W, tw_blk(NBC, W, k, 0)) == tw_col(NBC, W, c)) continue;
+                    acc[k * 4 + r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[tw_blk(NBC, W, k, 0)], bv[r], acc[k * 4 + r], 0, 0, 0);
                 }
             }
         }
@@ -233,15 +199,24 @@ __device__ __forceinline__ void tall_stage(const double *__restrict__ panel, int
 
 // thread (kp = tid & 7, cc = tid >> 3) owns the row pairs 16 j + 2 kp (j < TSUB) of the columns cc + 32 p (p < 4): the TSUB loads of a
 // column are issued back to back, so the memory system sees 8 * TBK contiguous bytes per column and workgroup at a time
-template <bool FAST>
+// FAST (whole stages, A 16-byte aligned with an even pitch, b aligned): unmasked 16-byte loads; a column beyond the matrix reads the LAST
+// column instead (its products land in blocks nobody reads, its q in entries the fix-up drops) and the 32-column groups beyond the NBC
+// block columns the kernel is built for are not loaded at all.
+template <int NBC, bool FAST>
 __device__ __forceinline__ void tall_load(const TallArgs &g, int64_t row0, int64_t rend, int kp, int cc, f64x2 (&reg)[4][TSUB], f64x2 (&cv)[TSUB]) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
+        if (32 * p >= 16 * NBC) {                       // (no block of this kernel reads these columns of the panel)
+#pragma unroll
+            for (int j = 0; j < TSUB; ++j) { reg[p][j].x = 0.0; reg[p][j].y = 0.0; }
+            continue;
+        }
         const int64_t col = cc + 32 * p;
+        const int64_t ccol = FAST ? min(col, g.cols - 1) : col;
 #pragma unroll
         for (int j = 0; j < TSUB; ++j) {
             const int64_t row = row0 + 16 * j + 2 * kp;
-            const double *src = g.A + col * g.lda + row;
+            const double *src = g.A + ccol * g.lda + row;
             f64x2 v;
             if (FAST) {
                 v = *reinterpret_cast<const f64x2 *>(src);
@@ -299,8 +274,9 @@ __device__ __forceinline__ void tall_store(double *__restrict__ panel, const f64
 // stage alone: with four stage bodies behind a branch inside one loop the accumulators are a 36-double phi at every merge and the
 // allocator needs ~230 registers; specialised from the top each wave has its own 36 accumulators in fixed registers (~145).  All four
 // bodies execute the same sequence of barriers (s_barrier counts waves, the branch is wave-uniform).
-template <int W, bool FAST>
+template <int NBC, int W, bool FAST>
 __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TCOLS * TGP], int tid) {
+    constexpr int NACC = tall_tacc(NBC);
     const int lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int kp = tid & 7, cc = tid >> 3;
@@ -310,15 +286,15 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
     const int nstage = (int)(g.interleave ? (g.nstages > bid ? (g.nstages - bid + G - 1) / G : 0) : max((int64_t)0, min(g.chunk, g.nstages - sbeg)));
     const int64_t rend = g.rows;
 
-    double acc[TACC];
+    double acc[NACC];
 #pragma unroll
-    for (int r = 0; r < TACC; ++r) acc[r] = 0.0;
+    for (int r = 0; r < NACC; ++r) acc[r] = 0.0;
     double qacc[4] = {0.0, 0.0, 0.0, 0.0}, cacc = 0.0;
     auto stage_row = [&](int s) { return (sbeg + (int64_t)s * sstep) * TBK; };
     f64x2 reg[4][TSUB], cv[TSUB];
 
     if (nstage > 0) {
-        tall_load<FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
+        tall_load<NBC, FAST>(g, stage_row(0), rend, kp, cc, reg, cv);
         tall_store(lds[0], reg, cv, g.sign, kp, cc, qacc, cacc);
     }
     __syncthreads();
@@ -326,20 +302,20 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
         const int cur = s & 1;
         const bool more = s + 1 < nstage;
 #if PMT_TALL_ABL == 1      // ablation (wrong results): no global loads / LDS stores after the first stage â€” the MFMA side alone
-        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        tall_stage<NBC, W>(lds[cur] + TLK * lk, lm, acc);
 #elif PMT_TALL_ABL == 2    // ablation (wrong results): no MFMAs â€” the memory side alone
-        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        if (more) tall_load<NBC, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #elif PMT_TALL_ABL == 3    // ablation (wrong results): global loads + MFMAs, no register -> LDS phase (one add keeps the loads alive)
-        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
-        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) tall_load<NBC, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<NBC, W>(lds[cur] + TLK * lk, lm, acc);
         if (more) { cacc = cacc + reg[0][0].x; cacc = cacc + reg[3][TSUB - 1].y; cacc = cacc + cv[0].x; }
 #elif PMT_TALL_ABL == 4    // ablation (wrong results): MFMAs + the register -> LDS phase of stale registers, no global loads after the first stage
-        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        tall_stage<NBC, W>(lds[cur] + TLK * lk, lm, acc);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #elif PMT_TALL_ABL == 5    // ablation (wrong results): everything but the q / c'c arithmetic (LDS stores only)
-        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
-        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) tall_load<NBC, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<NBC, W>(lds[cur] + TLK * lk, lm, acc);
         if (more) {
 #pragma unroll
             for (int j = 0; j < TSUB; ++j)
@@ -348,17 +324,17 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
             cacc = cacc + cv[0].x;
         }
 #else
-        if (more) tall_load<FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
-        tall_stage<W>(lds[cur] + TLK * lk, lm, acc);
+        if (more) tall_load<NBC, FAST>(g, stage_row(s + 1), rend, kp, cc, reg, cv);
+        tall_stage<NBC, W>(lds[cur] + TLK * lk, lm, acc);
         if (more) tall_store(lds[cur ^ 1], reg, cv, g.sign, kp, cc, qacc, cacc);
 #endif
         __syncthreads();
     }
 
     // partials -> workspace: [wave][accumulator][lane] (512-byte runs), then q and c'c
-    double *w = g.ws + (int64_t)blockIdx.x * TSTRIDE;
+    double *w = g.ws + (int64_t)blockIdx.x * tall_stride(NBC);
 #pragma unroll
-    for (int r = 0; r < TACC; ++r) w[(W * TACC + r) * 64 + lane] = acc[r];
+    for (int r = 0; r < NACC; ++r) w[(W * NACC + r) * 64 + lane] = acc[r];
     // the 8 row-pair threads of a column are 8 consecutive lanes: tree in fixed order
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -366,18 +342,18 @@ __device__ __forceinline__ void tall_body(const TallArgs &g, double (&lds)[2][TC
         v = v + __shfl_down(v, 4, 8);
         v = v + __shfl_down(v, 2, 8);
         v = v + __shfl_down(v, 1, 8);
-        if (kp == 0) w[TPART + cc + 32 * p] = v;
+        if (kp == 0) w[tall_part(NBC) + cc + 32 * p] = v;
     }
     if (W == 0) {
         double v = cacc;
         v = v + __shfl_down(v, 4, 8);
         v = v + __shfl_down(v, 2, 8);
         v = v + __shfl_down(v, 1, 8);
-        if (tid == 0) w[TPART + TCOLS] = v;
+        if (tid == 0) w[tall_part(NBC) + TCOLS] = v;
     }
 }
 
-template <bool FAST>
+template <int NBC, bool FAST>
 __global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g) {
     __shared__ double lds[2][TCOLS * TGP];
     const int tid = threadIdx.x;
@@ -387,16 +363,17 @@ __global__ __launch_bounds__(256, PMT_TALL_WPS) void gram_tall_kernel(TallArgs g
     const int64_t tile = blockIdx.y;
     g.A += tile * TCOLS * g.lda;
     g.cols = min((int64_t)TCOLS, g.cols - tile * TCOLS);
-    g.ws += tile * (int64_t)gridDim.x * TSTRIDE;
-    if (wave == 0) tall_body<0, FAST>(g, lds, tid);
-    else if (wave == 1) tall_body<1, FAST>(g, lds, tid);
-    else if (wave == 2) tall_body<2, FAST>(g, lds, tid);
-    else tall_body<3, FAST>(g, lds, tid);
+    g.ws += tile * (int64_t)gridDim.x * tall_stride(NBC);
+    if (wave == 0) tall_body<NBC, 0, FAST>(g, lds, tid);
+    else if (wave == 1) tall_body<NBC, 1, FAST>(g, lds, tid);
+    else if (wave == 2) tall_body<NBC, 2, FAST>(g, lds, tid);
+    else tall_body<NBC, 3, FAST>(g, lds, tid);
 }
 
 struct TallFixArgs {
     const double *ws; int G;
-    int nb;                               // 0: the 36-block layout of gram_tall_kernel; NB > 0: gram_narrow_kernel<NB>'s (blocks in packed upper order)
+    int nb;                               // 0: the dealt layout of gram_tall_kernel<nbc>; NB > 0: gram_narrow_kernel<NB>'s (blocks in packed upper order)
+    int nbc;                              // nb == 0: block columns of the tall kernel that wrote the partials (5 .. 8)
     int part, pcols, stride;              // doubles of triangle partial, columns of the panel, doubles per workgroup
     int64_t cols; const int64_t *xvar; const int64_t *varmap; int moi;
     QT *out_quad; double *out_csc; double alpha; LT *out_lin; double *out_const;
@@ -446,8 +423,10 @@ __global__ __launch_bounds__(1024) void gram_tall_fixup_kernel(TallFixArgs f) {
             tn = k >= 6 ? 3 : k >= 3 ? 2 : k >= 1 ? 1 : 0;
             tm = k - tn * (tn + 1) / 2;
         } else {
-            const int w = a / TACC, k = (a % TACC) >> 2;
-            tm = TALL_BLOCKS[w][k][0]; tn = TALL_BLOCKS[w][k][1];
+            const int tacc = tall_tacc(f.nbc);
+            const int w = a / tacc, k = (a % tacc) >> 2;
+            tm = TALL_BLOCKS[f.nbc - 5][w][k][0]; tn = TALL_BLOCKS[f.nbc - 5][w][k][1];
+            if (tm < 0) return;                           // (a padding slot of a wave with fewer blocks)
         }
         const int i = lane >> 4, b = (lane >> 2) & 3, jj = lane & 3;
         int64_t j = j0 + 16 * tm + 4 * b + i, kk = j0 + 16 * tn + 4 * ((b + r) & 3) + jj;
@@ -1020,7 +999,7 @@ static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStre
         else PMT_LAUNCH_NAMED("gram_narrow_kernel", (gram_narrow_kernel<NB, false>), dim3((unsigned)G), dim3(256), 0, s, g);
         if (int rc = check_launch("gram_narrow_kernel")) return rc;
     }
-    f.G = G; f.nb = NB; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
+    f.G = G; f.nb = NB; f.nbc = 8; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
 }
@@ -1103,13 +1082,25 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     }
     const int G = gram_tall_groups(rows, cols);
     const unsigned nt = (unsigned)cdiv(cols, TCOLS);
-    // whole stages, whole panels, aligned pieces (of A and of b): no bounds checks
-    const bool fast = g.vec_in && cols % TCOLS == 0 && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
-    if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<true>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_tall_kernel", gram_tall_kernel<false>, dim3((unsigned)G, nt), dim3(256), 0, s, g);
+    // whole stages, aligned pieces (of A and of b): no bounds checks (columns beyond the matrix are clamped to its last one: tall_load)
+    const bool fast = g.vec_in && rows % TBK == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
+    // one tile of 65 .. 112 columns: the kernel built for 5 / 6 / 7 block columns (15 / 21 / 28 blocks instead of 36)
+    const int nbc = nt == 1 ? (int)std::max<int64_t>(5, cdiv(cols, 16)) : 8;
+#ifdef PMT_TALL_NBC8
+    const int use = 8;
+#else
+    const int use = nbc;
+#endif
+#define TALL_LAUNCH(N)                                                                                                          \
+    do {                                                                                                                        \
+        if (fast) PMT_LAUNCH_NAMED("gram_tall_kernel", (gram_tall_kernel<N, true>), dim3((unsigned)G, nt), dim3(256), 0, s, g);   \
+        else PMT_LAUNCH_NAMED("gram_tall_kernel", (gram_tall_kernel<N, false>), dim3((unsigned)G, nt), dim3(256), 0, s, g);      \
+    } while (0)
+    if (use == 5) TALL_LAUNCH(5); else if (use == 6) TALL_LAUNCH(6); else if (use == 7) TALL_LAUNCH(7); else TALL_LAUNCH(8);
+#undef TALL_LAUNCH
     if (int rc = check_launch("gram_tall_kernel")) return rc;
-    f.G = G; f.nb = 0; f.part = TPART; f.pcols = TCOLS; f.stride = TSTRIDE;
-    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(TPART + TCOLS + 1, 64), nt), dim3(1024), 0, s, f);
+    f.G = G; f.nb = 0; f.nbc = use; f.part = tall_part(use); f.pcols = TCOLS; f.stride = tall_stride(use);
+    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(tall_part(use) + TCOLS + 1, 64), nt), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
 }
 

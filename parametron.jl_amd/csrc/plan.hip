@@ -412,26 +412,6 @@ extern "C" int pmt_host_alloc(size_t bytes, void **out_host_ptr) {
     return PMT_OK;
 }
 
-// Memory the HOST LANGUAGE owns (a Julia Vector / numpy array that must stay the object it is — the `terms` vector of an MOI function) made
-// page-locked and device-visible in place: hipHostRegister.  *out_device_ptr is the address the kernels store to (recorded entry points take
-// it as their output pointer: the MOI buffer then has no device twin and needs no fetch).  The registration covers whole pages around
-// [host_ptr, host_ptr + bytes); the caller keeps the array alive and un-resized until pmt_host_unregister.
-extern "C" int pmt_host_register(void *host_ptr, size_t bytes, void **out_device_ptr) {
-    PMT_REQUIRE(host_ptr && out_device_ptr && bytes > 0, PMT_INVALID_ARGUMENT, "host_register: null argument / zero bytes");
-    hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
-    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); e = hipSuccess; }
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PMT_HIP_ERROR, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
-    void *d = nullptr;
-    e = hipHostGetDevicePointer(&d, host_ptr, 0);
-    if (e != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostUnregister(host_ptr); return fail(PMT_HIP_ERROR, "hipHostGetDevicePointer failed for registered memory"); }
-    *out_device_ptr = d;
-    return PMT_OK;
-}
-extern "C" int pmt_host_unregister(void *host_ptr) {
-    if (!host_ptr) return PMT_OK;
-    PMT_HIP_CHECK(hipHostUnregister(host_ptr));
-    return PMT_OK;
-}
 extern "C" int pmt_host_free(void *host_ptr) {
     if (!host_ptr) return PMT_OK;
     PMT_HIP_CHECK(hipHostFree(host_ptr));

@@ -732,39 +732,3 @@ def test_model_update_entry_point_as_a_c_host_would_use_it():
     g.call("pmt_plan_destroy", plan)
     for a in (mbA, mbC, mbb, t1, c1, t2, c2, total):
         g.call("pmt_host_free", C.c_void_p(a.ctypes.data))
-
-
-def test_kernels_store_into_registered_host_arrays():
-    """pmt_host_register: an array the host language owns (here a plain numpy array; in Julia the `terms` Vector of an MOI function) is made
-    device-visible in place and given to a recorded entry point as its OUTPUT: the one launch of the small plan stores the MOI triplets
-    straight into it — compared with the oracle byte for byte, solve after solve"""
-    import gpu_util as g
-    from oracle import oracle as O
-    r, n = 5, 7
-    rng = np.random.default_rng(3)
-    s = g.stream()
-    plan = C.c_void_p()
-    g.call("pmt_plan_create", 0, s, C.byref(plan))
-    terms = np.zeros(r * n + 3, dtype=g.VAT)[3:]                         # (deliberately not page-aligned)
-    consts = np.zeros(r)
-    dterms, dconsts = C.c_void_p(), C.c_void_p()
-    g.call("pmt_host_register", C.c_void_p(terms.ctypes.data), terms.nbytes, C.byref(dterms))
-    g.call("pmt_host_register", C.c_void_p(consts.ctypes.data), consts.nbytes, C.byref(dconsts))
-    dA, db = g.empty_f64(r * n), g.empty_f64(r)
-    xvar = g.to_dev(np.arange(1, n + 1, dtype=np.int64))
-    seedA, seedb = C.c_uint64(21), C.c_uint64(22)
-    rec = C.c_void_p(g.lib().pmt_plan_recording_stream(plan))
-    g.call("pmt_plan_begin_record", plan)
-    g.call("pmt_fill_uniform_dyn_f64", g.ptr(dA), r, n, r, C.byref(seedA), 1.0, rec)
-    g.call("pmt_fill_uniform_dyn_f64", g.ptr(db), r, 1, r, C.byref(seedb), 1.0, rec)
-    g.call("pmt_affine_pack_vector_f64", g.ptr(dA), r, r, n, g.ptr(xvar), g.ptr(db), -1, None, 0, dterms, dconsts, rec)
-    g.call("pmt_plan_end_record", plan)
-    xi = np.arange(1, n + 1, dtype=np.int64)
-    for it in range(4):
-        seedA.value, seedb.value = 21 + 1000 * it, 22 + 1000 * it
-        g.call("pmt_plan_update", plan); g.call("pmt_plan_synchronize", plan)
-        Av = O.fill_uniform(r * n, seedA.value).reshape(n, r).T
-        wt, wc = O.AffVec(r).vecsubtract(O.AffVec(r).matvecmul_vars(Av, xi), O.fill_uniform(r, seedb.value)).moi(None)
-        assert np.array_equal(terms.view(np.int64), wt.view(np.int64)) and np.array_equal(consts.view(np.int64), wc.view(np.int64))
-    g.call("pmt_plan_destroy", plan)
-    g.call("pmt_host_unregister", C.c_void_p(terms.ctypes.data)); g.call("pmt_host_unregister", C.c_void_p(consts.ctypes.data))
