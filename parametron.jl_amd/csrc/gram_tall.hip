@@ -503,6 +503,11 @@ template <int NB> struct Narrow {
     static constexpr int KSTEPS = R / 16;                // k-steps per wave and stage
     static_assert(NJ * PIECE == R && NQ * NCC >= C, "narrow panel geometry");
 };
+// 48 columns: the STREAM form only (gram_stream_kernel<3>: six blocks instead of the ten a 33 .. 48-column matrix paid for as a 64-column panel);
+// the panel kernel keeps its power-of-two panels
+template <> struct Narrow<3> {
+    static constexpr int C = 48, NBLK = 6, NACC = NBLK * 4, PART = NACC * 64, STRIDE = PART + C + 8;
+};
 
 template <int NB, bool FAST>
 __device__ __forceinline__ void narrow_load(const TallArgs &g, int64_t row0, int64_t rend, int kp, int cc,
@@ -735,6 +740,9 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 #ifndef PMT_STREAM_D2
 #define PMT_STREAM_D2 3            // 32,
 #endif
+#ifndef PMT_STREAM_D3
+#define PMT_STREAM_D3 2            // 48,
+#endif
 #ifndef PMT_STREAM_D4
 #define PMT_STREAM_D4 2            // 64
 #endif
@@ -746,6 +754,9 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 #endif
 #ifndef PMT_STREAM_MAXG
 #define PMT_STREAM_MAXG 256        // workgroups at most, 16- and 32-column panels: ONE wave per SIMD streams best (HBM-bound: 2^20 x 16 25 us against 27 with two)
+#endif
+#ifndef PMT_STREAM_MAXG3
+#define PMT_STREAM_MAXG3 512       // 48 columns
 #endif
 #ifndef PMT_STREAM_MAXG4
 #define PMT_STREAM_MAXG4 512       // 64 columns: the matrix pipe matters as much as the stream — two waves per SIMD (256 workgroups: 142 us against 118)
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 template <int NB> struct Stream {
     static constexpr int IT = NB == 4 ? PMT_STREAM_IT4 : 4;           // 16-byte loads per column group, lane and iteration (= pairs of k-steps)
     static constexpr int RI = 8 * IT;                    // rows per iteration
-    static constexpr int D = NB == 1 ? PMT_STREAM_D1 : NB == 2 ? PMT_STREAM_D2 : PMT_STREAM_D4;
+    static constexpr int D = NB == 1 ? PMT_STREAM_D1 : NB == 2 ? PMT_STREAM_D2 : NB == 3 ? PMT_STREAM_D3 : PMT_STREAM_D4;
 };
 
 // one iteration's loads of one wave: buf[t][i] = rows (row0 + 8 i + 2 lk, + 1) of column 16 t + lm; cb = row pair (lane & (4 IT - 1)) of b, raw —
@@ -965,16 +976,21 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
 #ifndef PMT_STREAM_MINROWS
 #define PMT_STREAM_MINROWS 32768
 #endif
-static bool stream_form(int nb, int64_t rows) { return PMT_STREAM && (nb == 1 || nb == 2 || nb == 4) && rows >= PMT_STREAM_MINROWS; }
-static int stream_iteration_rows(int nb) { return nb == 1 ? Stream<1>::RI : nb == 2 ? Stream<2>::RI : Stream<4>::RI; }
+static bool stream_form(int nb, int64_t rows) { return PMT_STREAM && nb >= 1 && nb <= 4 && rows >= PMT_STREAM_MINROWS; }
+// column groups of the panel: 1, 2, 4 — and 3 (33 .. 48 columns) where the stream form takes the shape
+static int narrow_nb(int64_t rows, int64_t cols) {
+    if (cols > 32 && cols <= 48 && stream_form(3, rows)) return 3;
+    return cols <= 16 ? 1 : cols <= 32 ? 2 : cols <= 64 ? 4 : 0;
+}
+static int stream_iteration_rows(int nb) { return nb == 1 ? Stream<1>::RI : nb == 2 ? Stream<2>::RI : nb == 3 ? Stream<3>::RI : Stream<4>::RI; }
 static int stream_groups(int64_t rows, int nb) {
     const int64_t nit = cdiv(rows, stream_iteration_rows(nb));
-    return (int)std::max<int64_t>(1, std::min<int64_t>(nb == 4 ? PMT_STREAM_MAXG4 : PMT_STREAM_MAXG, cdiv(nit, 4)));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(nb == 4 ? PMT_STREAM_MAXG4 : nb == 3 ? PMT_STREAM_MAXG3 : PMT_STREAM_MAXG, cdiv(nit, 4)));
 }
 
-static int narrow_nb(int64_t cols) { return cols <= 16 ? 1 : cols <= 32 ? 2 : cols <= 64 ? 4 : 0; }
+static int narrow_nb(int64_t rows, int64_t cols);
 static int narrow_stage_rows(int nb) { return nb == 1 ? Narrow<1>::R : nb == 2 ? Narrow<2>::R : Narrow<4>::R; }
-static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : Narrow<4>::STRIDE; }
+static int narrow_stride(int nb) { return nb == 1 ? Narrow<1>::STRIDE : nb == 2 ? Narrow<2>::STRIDE : nb == 3 ? Narrow<3>::STRIDE : Narrow<4>::STRIDE; }
 static int narrow_groups(int64_t rows, int nb) {
     if (stream_form(nb, rows)) return stream_groups(rows, nb);
     const int64_t nst = cdiv(rows, narrow_stage_rows(nb));
@@ -1000,6 +1016,20 @@ static int launch_gram_narrow(TallArgs g, TallFixArgs f, bool b_aligned, hipStre
         if (int rc = check_launch("gram_narrow_kernel")) return rc;
     }
     f.G = G; f.nb = NB; f.nbc = 8; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
+    PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
+    return check_launch("gram_tall_fixup_kernel");
+}
+
+// 33 .. 48 columns from 32768 rows: the stream form on three column groups (no panel kernel of that width exists)
+static int launch_gram_stream3(TallArgs g, TallFixArgs f, bool b_aligned, hipStream_t s) {
+    using N = Narrow<3>;
+    const int G = narrow_groups(g.rows, 3);
+    g.nstages = cdiv(g.rows, Stream<3>::RI);
+    const bool fast = g.vec_in && b_aligned && (uint64_t)g.lda * N::C * 8 < (1ull << 32);
+    if (fast) PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<3, true>), dim3((unsigned)G), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_stream_kernel", (gram_stream_kernel<3, false>), dim3((unsigned)G), dim3(256), 0, s, g);
+    if (int rc = check_launch("gram_stream_kernel")) return rc;
+    f.G = G; f.nb = 3; f.nbc = 8; f.part = N::PART; f.pcols = N::C; f.stride = N::STRIDE;
     PMT_LAUNCH(gram_tall_fixup_kernel, dim3((unsigned)cdiv(N::PART + N::C + 1, 64)), dim3(1024), 0, s, f);
     return check_launch("gram_tall_fixup_kernel");
 }
@@ -1041,18 +1071,18 @@ static int64_t tall_chunk(int64_t rows, int64_t cols) {
     return std::max<int64_t>(minst, cdiv(nst, maxg));
 }
 int gram_tall_stage_rows(int64_t rows, int64_t cols) {
-    const int nb = narrow_nb(cols);
+    const int nb = narrow_nb(rows, cols);
     return nb ? (stream_form(nb, rows) ? stream_iteration_rows(nb) : narrow_stage_rows(nb)) : TBK;
 }
 // row-pair lanes per column run (8 or 16: the panel kernels); 4: the stream form (four contraction slots per column, iterations dealt to WAVES)
-int gram_tall_run_lanes(int64_t rows, int64_t cols) { const int nb = narrow_nb(cols); return nb && stream_form(nb, rows) ? 4 : nb == 1 ? Narrow<1>::LPC : 8; }
+int gram_tall_run_lanes(int64_t rows, int64_t cols) { const int nb = narrow_nb(rows, cols); return nb && stream_form(nb, rows) ? 4 : nb == 1 ? Narrow<1>::LPC : 8; }
 int gram_tall_groups(int64_t rows, int64_t cols) {
-    if (const int nb = narrow_nb(cols)) return narrow_groups(rows, nb);
+    if (const int nb = narrow_nb(rows, cols)) return narrow_groups(rows, nb);
     return (int)cdiv(cdiv(rows, TBK), tall_chunk(rows, cols));
 }
 size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols) {
     if (!gram_tall_applies(rows, cols) && !gram_tall_diag_applies(rows, cols)) return 0;
-    if (const int nb = narrow_nb(cols)) return sizeof(double) * (size_t)narrow_groups(rows, nb) * (size_t)narrow_stride(nb);
+    if (const int nb = narrow_nb(rows, cols)) return sizeof(double) * (size_t)narrow_groups(rows, nb) * (size_t)narrow_stride(nb);
     return sizeof(double) * (size_t)gram_tall_groups(rows, cols) * (size_t)cdiv(cols, TCOLS) * TSTRIDE;
 }
 
@@ -1076,9 +1106,10 @@ int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     TallFixArgs f;
     f.ws = g.ws; f.cols = cols; f.xvar = xvar; f.varmap = varmap; f.moi = moi; f.out_quad = out_quad; f.out_csc = out_csc; f.alpha = alpha;
     f.out_lin = out_lin; f.out_const = out_const;
-    if (const int nb = narrow_nb(cols)) {
+    if (const int nb = narrow_nb(rows, cols)) {
         const bool b_aligned = (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
-        return nb == 1 ? launch_gram_narrow<1>(g, f, b_aligned, s) : nb == 2 ? launch_gram_narrow<2>(g, f, b_aligned, s) : launch_gram_narrow<4>(g, f, b_aligned, s);
+        return nb == 1 ? launch_gram_narrow<1>(g, f, b_aligned, s) : nb == 2 ? launch_gram_narrow<2>(g, f, b_aligned, s) :
+               nb == 3 ? launch_gram_stream3(g, f, b_aligned, s) : launch_gram_narrow<4>(g, f, b_aligned, s);
     }
     const int G = gram_tall_groups(rows, cols);
     const unsigned nt = (unsigned)cdiv(cols, TCOLS);

@@ -265,6 +265,7 @@ def test_constant_order_is_host_arithmetic(lib):
     assert order(5000, 17) == (2, 40, 128) and order(1024, 1) == (3, 4, 256) and order(100, 40)[0] == 2
     assert order(16384, 17)[0] == 2 and order(32768, 17) == (4, 256, 32) and order(77777, 50) == (4, 512, 16) and order(33001, 9)[0] == 4
     assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
+    assert order(1 << 20, 48) == (4, 512, 32) and order(40000, 40) == (4, 313, 32) and order(20000, 40)[0] == 2      # 33 .. 48 columns: three column groups (stream form only)
     # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
     assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(31, 300)[0] == 2
     assert order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32) and order(4090, 1000)[0] == 2

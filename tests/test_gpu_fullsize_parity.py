@@ -49,7 +49,7 @@ def _sample_pairs(rng, n, count):
                                                      # narrow tall shapes (gram_stream_kernel<1 | 2 | 4>, order 4): whole panels and ragged ones
                                                      (1 << 20, 64, 1200, 4), (262144, 32, 500, 4), (1 << 20, 16, 136, 4), (77777, 50, 900, 4),
                                                      (33001, 9, 45, 4), (1024, 1, 1, 3), (4099, 33, 500, 2), (1 << 20, 32, 500, 4), (31, 16, 136, 0), (333, 16, 136, 3), (64, 64, 600, 2),
-                                                     (32768, 64, 600, 4), (32800, 33, 500, 4), (40001, 16, 136, 4), (65552, 7, 28, 4), (300, 8, 36, 3), (16384, 64, 600, 2)])
+                                                     (32768, 64, 600, 4), (32800, 33, 500, 4), (1 << 20, 48, 900, 4), (50001, 41, 700, 4), (40001, 16, 136, 4), (65552, 7, 28, 4), (300, 8, 36, 3), (16384, 64, 600, 2)])
 def test_canonical_objective_against_cpu_sampled_sums(r, n, count, expect_order, record_property):
     import gpu_util as g
     q, l, const = _gram(g, r, n)
