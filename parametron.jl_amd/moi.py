@@ -207,10 +207,15 @@ class _Record:
             n = out.nterms
             self.f = ScalarAffineFunction(n, alloc=ctx.pinned_array)
             dev_terms = twin(self.f.terms, 16 * n)
-            self.dev = {"terms": dev_terms, "const": out.const}
+            # a small model: the constant (a word the expression's node left in HBM) is copied into its page-locked word by one more entry of
+            # the tape — a node of the one launch — instead of a D2H copy behind every replay (a hipMemcpyAsync of 8 bytes is ~5 us of host time)
+            dconst = self._cbuf.ctypes.data if zero_copy else out.const
+            self.dev = {"terms": dev_terms, "const": dconst}
 
             def emit(c):
                 c.call("pmt_pack_scalar_affine_f64", P(out.terms), n, P(varmap_buf), P(dev_terms))
+                if zero_copy:
+                    c.call("pmt_copy_bytes", P(dconst), P(out.const), 8)
             return emit
         if self.kind == "quad":
             gram = getattr(self.expr, "gram_candidate", None)
@@ -267,11 +272,14 @@ class _Record:
             out.materialize()
             self.f = ScalarQuadraticFunction(out.nl, out.nq, alloc=ctx.pinned_array)
             dq, dl = twin(self.f.quadratic_terms, 24 * out.nq), twin(self.f.affine_terms, 16 * out.nl)
-            self.dev = {"quad": dq, "lin": dl, "const": out.const}
+            dconst = self._cbuf.ctypes.data if zero_copy else out.const          # (as for the affine function above)
+            self.dev = {"quad": dq, "lin": dl, "const": dconst}
 
             def emit(c):
                 c.call("pmt_pack_scalar_quadratic_f64", P(out.quad), out.nq, P(varmap_buf), P(dq))
                 c.call("pmt_pack_scalar_affine_f64", P(out.lin), out.nl, P(varmap_buf), P(dl))
+                if zero_copy:
+                    c.call("pmt_copy_bytes", P(dconst), P(out.const), 8)
             return emit
         # Vector{AffineFunction}
         # handoff="host_csc": the deliverable is the solver's CSC arrays on the host and the index map is fixed (Model.initialize), so the MOI

@@ -287,9 +287,9 @@ def test_model_selects_the_small_plan_by_itself(mode):
     for it in range(4):
         P.solve(model)
         fz = model.device().fused()
-        # every kernel of the update! — four callbacks, residual, objective, constraint — is ONE launch (literal: 9 tape entries — the MOI copy of a materialised objective is two packs; canonical:
+        # every kernel of the update! — four callbacks, residual, objective, constraint — is ONE launch (literal: 10 tape entries — the MOI copy of a materialised objective is two packs and the copy of its constant into the function object's page-locked word; canonical:
         # the tiny Gram node is a small-plan node too, 6 entries); a small model fetches its MOI buffers with plain copies behind the replay
-        assert fz["groups"] == 1 and fz["exec_length"] == 1 and fz["nodes"] == model.device().tape_length() == (9 if mode == "literal" else 6), fz
+        assert fz["groups"] == 1 and fz["exec_length"] == 1 and fz["nodes"] == model.device().tape_length() == (10 if mode == "literal" else 6), fz
         P.profile_enable(True)
         model.setdirty(); model._run_tape(fetch=False); model.device().synchronize()
         rep = P.profile_report()

@@ -189,6 +189,18 @@ def config_c1(torch, P, _lib, steps=400):
             P.solve(model)
         return (time.perf_counter() - t0) / k * 1e6
     out["solve_us_python_host_mock_optimizer"] = solve_wall(steps)
+    # what a C / Julia host pays per update!(model) INCLUDING the wait for the MOI buffers on the host: the one C entry point
+    # (pmt_model_update: seeds / mailboxes, the one launch, the synchronisation), called here through ctypes (~1.5 us of the figure)
+    run = getattr(model, "_model_run", None)
+    if run is not None:
+        import ctypes
+        fn = ctx.lib.pmt_model_update
+        for _ in range(50):
+            fn(run, None, 0, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(run, None, 0, 1)
+        out["model_update_us_c_entry"] = (time.perf_counter() - t0) / steps * 1e6
     out["reference"] = {"solve_us_incl_osqp": 51.863, "update_us_estimate": 15.0,
                         "source": "README.md:132-136 (BenchmarkTools median of solve!, other hardware); the update! share per BASELINE.md section 1"}
     model.close()
