@@ -283,3 +283,21 @@ def test_batch_shard_is_host_arithmetic(lib):
     assert (per.value, first.value) == (1024, 3072)
     with pytest.raises(lib.DimensionMismatch):
         lib.call("pmt_batch_shard", 8191, 8, 0, C.byref(per), C.byref(first))
+
+
+def test_tall_kernel_dealings_in_the_source_are_the_generator_s():
+    """csrc/gram_tall.hip's `tw_*` tables and TALL_BLOCKS are pasted from tools/gen_tall_deal.py: the source must hold exactly what the generator
+    emits, every dealing must cover the upper triangle of its NBC x NBC block grid once, and the waves' MFMA counts must be level"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_tall_deal as G
+    src = open(os.path.join(ROOT, "parametron.jl_amd", "csrc", "gram_tall.hip")).read()
+    T = G.tables()
+    order = [5, 6, 7, 8]
+    for name in ("nblk", "nr", "nc", "row", "col", "blk", "blocks"):
+        text = G.braces([T[n][name] for n in order])
+        assert text in src, "gram_tall.hip does not hold the generator's `%s` table" % name
+    for nbc, waves in G.DEALS.items():
+        blocks = sorted(b for w in waves for b in w)
+        assert blocks == sorted((a, b) for b in range(nbc) for a in range(b + 1))
+        mf = [sum(3 if a == b else 4 for a, b in w) for w in waves]
+        assert max(mf) - min(mf) <= 4 and max(len(w) for w in waves) <= {5: 4, 6: 6, 7: 7, 8: 9}[nbc]

@@ -16,10 +16,24 @@ def _shapes(seed, count, rmax, nmax):
 
 @pytest.mark.parametrize("rows,n", _shapes(11, 28, 700, 420))
 def test_gram_node_random_shapes(rows, n):
-    import gpu_util as g
     rng = np.random.default_rng(rows * 1000 + n)
-    lda = rows + int(rng.integers(0, 5))                                   # odd / even / padded leading dimensions
-    shift = int(rng.integers(0, 2))                                        # 8-byte misaligned base: the 16-byte load path must not be taken
+    # odd / even / padded leading dimensions; an 8-byte misaligned base: the 16-byte load path must not be taken
+    _check_gram_node(rows, n, rows + int(rng.integers(0, 5)), int(rng.integers(0, 2)), rng)
+
+
+# round 6: the stream form of the narrow panels (from 32768 rows; 16 / 32 / 48 / 64-column groups), the tall kernel per block-column count
+# (65 .. 128 columns) and the mid-size form, each on EVERY load path: whole aligned panels (unmasked 16-byte loads), ragged rows / columns
+# (the masked tail iteration, clamped columns), an odd pitch or an 8-byte-shifted base (8-byte loads throughout)
+@pytest.mark.parametrize("rows,n,pad,shift", [
+    (32768, 16, 0, 0), (32800, 13, 0, 0), (33001, 20, 1, 0), (32769, 32, 0, 1), (40000, 48, 2, 0), (32784, 41, 0, 0), (32784, 60, 3, 1), (65536, 64, 0, 0),
+    (4000, 70, 0, 0), (3001, 90, 1, 1), (2999, 100, 0, 1), (4096, 112, 0, 0), (3000, 128, 2, 0), (40000, 80, 0, 0), (33000, 97, 2, 0),
+    (1000, 300, 1, 1), (4096, 512, 0, 0), (2040, 1000, 2, 0)])
+def test_gram_node_forms_of_round_6_on_every_load_path(rows, n, pad, shift):
+    _check_gram_node(rows, n, rows + pad, shift, np.random.default_rng(rows * 7 + n))
+
+
+def _check_gram_node(rows, n, lda, shift, rng):
+    import gpu_util as g
     A = rng.random((rows, n)) - 0.4
     b = rng.random(rows) - 0.5
     buf = np.zeros(shift + lda * n)
