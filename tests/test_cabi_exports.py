@@ -288,6 +288,7 @@ def test_batch_shard_is_host_arithmetic(lib):
 def test_tall_kernel_dealings_in_the_source_are_the_generator_s():
     """csrc/gram_tall.hip's `tw_*` tables and TALL_BLOCKS are pasted from tools/gen_tall_deal.py: the source must hold exactly what the generator
     emits, every dealing must cover the upper triangle of its NBC x NBC block grid once, and the waves' MFMA counts must be level"""
+    import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_tall_deal as G
     src = open(os.path.join(ROOT, "parametron.jl_amd", "csrc", "gram_tall.hip")).read()
