@@ -628,6 +628,12 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
     if (!b_first) phase_b();
 }
 
+#ifndef PMT_SK_APB1_BELOW
+#define PMT_SK_APB1_BELOW 64       // fix-up: one accumulator per workgroup (NACC workgroups per tile) while tiles x NACC / 4 stays below this
+#endif
+#ifndef PMT_SK_MID_G
+#define PMT_SK_MID_G 256           // workgroups of a mid-size node's stream-K launch
+#endif
 // The affine part of a mid-size node inside the fix-up launch (SKArgs::lin_blocks workgroups of 512 threads, flat id L): workgroup L < the
 // last takes the columns 8 L .. 8 L + 7, one wave each — out_lin[j] = (2 sum_i c_i A[i, j], vm[xvar[j]]), c_i = 0.0 (+|-) b[i], lanes
 // striding the rows (coalesced), a shuffle tree at the end (gram.hip: gram_linear_kernel) —; the LAST one the constant c'c in the order
@@ -863,7 +869,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #else
     constexpr int variant = 1, gdef = 0;
 #endif
-    const int gwant = gdef > 0 ? gdef : (variant == 0 ? 512 : 256);
+    const int gwant = gdef > 0 ? gdef : (lin ? PMT_SK_MID_G : (variant == 0 ? 512 : 256));
     g.G = (int)std::min<int64_t>(T * g.nchunk, std::min(gwant, MAXG));
     // strict launches of tall matrices (few tiles, each split over many workgroups): a grid that is a MULTIPLE of the tile count gives every
     // tile the same row ranges, so that the workgroups of different tiles that share a column panel read the same rows of it at the same
@@ -928,7 +934,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #endif
         // (tiles split more than 32 ways each — few tiles, many rows: the sliced form)
         if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_sliced_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC, Cfg<2>::NT / 64), Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
-        else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < 64)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC, 1), Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < PMT_SK_APB1_BELOW)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC, 1), Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
         else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC / 4, 1), Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }
