@@ -22,6 +22,10 @@
 #include "dma.h"
 #include "gram_common.h"
 
+#ifndef PMT_GRAM_ABL_NO_LINEAR
+#define PMT_GRAM_ABL_NO_LINEAR 0   // ablation (wrong q): the stream-K form without its affine part on the side stream — what folding q into the contraction could gain at most
+#endif
+
 namespace pmt {
 
 int check_strictly_increasing(const int64_t *xvar_dev, int64_t n, void *stream);
@@ -655,7 +659,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         int rc = PMT_OK;
         double *scratch = workspace ? reinterpret_cast<double *>(static_cast<char *>(workspace) + gram_sk_workspace_bytes(rows, cols)) : nullptr;
         const int nsplit = (scratch && b && sign) ? linear_splits(rows, cols) : 1;
-        if (tall_form) {
+        if (tall_form || PMT_GRAM_ABL_NO_LINEAR) {
         } else if (cols > 0 && nsplit > 1) {
             const int64_t chunk = 64 * cdiv(cdiv(rows, nsplit), 64);
             PMT_LAUNCH(gram_linear_split_kernel, dim3((unsigned)cdiv(cols, 4), (unsigned)nsplit), dim3(256), 0, s2, A, lda, rows, cols, b, sign, chunk, scratch);

@@ -752,6 +752,9 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 #ifndef PMT_STREAM_WPS
 #define PMT_STREAM_WPS 2
 #endif
+#ifndef PMT_STREAM_WPS4
+#define PMT_STREAM_WPS4 2          // workgroups per CU the 64-column kernel's registers are budgeted for
+#endif
 #ifndef PMT_STREAM_MAXG
 #define PMT_STREAM_MAXG 256        // workgroups at most, 16- and 32-column panels: ONE wave per SIMD streams best (HBM-bound: 2^20 x 16 25 us against 27 with two)
 #endif
@@ -878,12 +881,12 @@ __device__ __forceinline__ void stream_compute(double *__restrict__ rot, const f
 }
 
 template <int NB, bool FAST>
-__global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallArgs g) {
+__global__ __launch_bounds__(256, NB == 4 ? PMT_STREAM_WPS4 : PMT_STREAM_WPS) void gram_stream_kernel(TallArgs g) {
     using S = Stream<NB>;
     using N = Narrow<NB>;
     // per wave: the rotation buffer of one iteration (NB IT KB) during the loop; afterwards the same memory carries the waves' sums
     constexpr int ROT = NB * S::IT * 128 + 128, RED = N::NACC * 64 + 16 * NB + 8;
-    constexpr int SH = 4 * ROT > 3 * RED ? 4 * ROT : 3 * RED;
+    constexpr int SH = 4 * ROT > RED ? 4 * ROT : RED;
     __shared__ double sh[SH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -930,45 +933,37 @@ __global__ __launch_bounds__(256, PMT_STREAM_WPS) void gram_stream_kernel(TallAr
     const bool qlane = (lane & 3) == 0;
     const int qcol = 4 * ((lane >> 2) & 3) + (lane >> 4);
     __syncthreads();                                      // every wave is done with its rotation buffer
-    // the four waves' sums, added in wave order
-    if (wave > 0) {
-        double *rw = sh + (wave - 1) * RED;
-#pragma unroll
-        for (int r = 0; r < N::NACC; ++r) rw[r * 64 + lane] = acc[r];
-        if (qlane) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) rw[N::NACC * 64 + 16 * t + qcol] = qacc[t];
-        }
-        if (lane == 0) rw[N::NACC * 64 + 16 * NB] = cacc;
-    }
-    __syncthreads();
-    if (wave != 0) return;
+    // the four waves' sums, added in wave order: waves 1, 2, 3 hand theirs to wave 0 one after the other through ONE piece of LDS (three
+    // pieces side by side were 63 KB at 64 columns: two workgroups per CU at most)
     double *w = g.ws + (int64_t)blockIdx.x * N::STRIDE;
+    for (int src = 1; src < 4; ++src) {
+        if (wave == src) {
 #pragma unroll
-    for (int r = 0; r < N::NACC; ++r) {
-        double v = acc[r];
-        v = v + sh[0 * RED + r * 64 + lane];
-        v = v + sh[1 * RED + r * 64 + lane];
-        v = v + sh[2 * RED + r * 64 + lane];
-        w[r * 64 + lane] = v;
+            for (int r = 0; r < N::NACC; ++r) sh[r * 64 + lane] = acc[r];
+            if (qlane) {
+#pragma unroll
+                for (int t = 0; t < NB; ++t) sh[N::NACC * 64 + 16 * t + qcol] = qacc[t];
+            }
+            if (lane == 0) sh[N::NACC * 64 + 16 * NB] = cacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < N::NACC; ++r) acc[r] = acc[r] + sh[r * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) qacc[t] = qacc[t] + sh[N::NACC * 64 + 16 * t + (qlane ? qcol : 0)];
+            cacc = cacc + sh[N::NACC * 64 + 16 * NB];
+        }
+        __syncthreads();
     }
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < N::NACC; ++r) w[r * 64 + lane] = acc[r];
     if (qlane) {
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            double v = qacc[t];
-            v = v + sh[0 * RED + N::NACC * 64 + 16 * t + qcol];
-            v = v + sh[1 * RED + N::NACC * 64 + 16 * t + qcol];
-            v = v + sh[2 * RED + N::NACC * 64 + 16 * t + qcol];
-            w[N::PART + 16 * t + qcol] = v;
-        }
+        for (int t = 0; t < NB; ++t) w[N::PART + 16 * t + qcol] = qacc[t];
     }
-    if (lane == 0) {
-        double v = cacc;
-        v = v + sh[0 * RED + N::NACC * 64 + 16 * NB];
-        v = v + sh[1 * RED + N::NACC * 64 + 16 * NB];
-        v = v + sh[2 * RED + N::NACC * 64 + 16 * NB];
-        w[N::PART + N::C] = v;
-    }
+    if (lane == 0) w[N::PART + N::C] = cacc;
 }
 
 // (shape alone decides — the constant's order must follow from (rows, cols): below 32768 rows the panel kernel's two launches are the
