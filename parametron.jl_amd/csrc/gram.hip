@@ -51,6 +51,11 @@ size_t gram_tall_workspace_bytes(int64_t rows, int64_t cols);
 int launch_gram_tall(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
                      const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
                      double *out_const, void *workspace, hipStream_t s);
+size_t gram_mid_workspace_bytes(int64_t rows, int64_t cols);
+int gram_mid_counters(int64_t cols);
+int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
+                    const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
+                    double *out_const, void *workspace, unsigned *counters, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
 // a CSC delivery computes the tiles column band by column band (super-columns of ONE tile column: a band's completion is never held back by
@@ -176,7 +181,9 @@ constexpr int ERR_COURIER = 1, ERR_PAIR_FOLD = 2;
 constexpr size_t PROGRESS_OFFSET = 0;
 constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
 constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
-constexpr size_t COUNTER_BYTES = DONE_OFFSET + 2 * sizeof(unsigned);
+constexpr size_t MID_OFFSET = DONE_OFFSET + 2 * sizeof(unsigned);                  // per-tile arrival counts of the one-launch mid-size node (gram_mid.hip)
+constexpr size_t MID_COUNTER_BYTES = 4096;
+constexpr size_t COUNTER_BYTES = MID_OFFSET + MID_COUNTER_BYTES;
 static std::mutex g_side_mu;
 static std::unordered_map<hipStream_t, SideStream> g_side;
 static int wait_dma_pending(SideStream *ss);
@@ -469,7 +476,7 @@ extern "C" int pmt_quad_gram_constant_order(int64_t rows, int64_t cols, int *ord
 extern "C" size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols) {
     // behind the contraction's partial tiles: chunk sums of q (tall matrices) and the chains of the constant (long vectors); the fused
     // tall form (gram_tall.hip) keeps its per-chunk partials in the same buffer
-    return std::max(gram_tall_workspace_bytes(rows, cols),
+    return std::max(std::max(gram_tall_workspace_bytes(rows, cols), gram_mid_applies(rows, cols) ? gram_mid_workspace_bytes(rows, cols) : (size_t)0),
                     gram_sk_workspace_bytes(rows, cols) + sizeof(double) * ((size_t)linear_splits(rows, cols) * (size_t)std::max<int64_t>(cols, 0) +
                                                                             blocked_dot_scratch_doubles()));
 }
@@ -690,8 +697,15 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
             if (tall_form && gram_mid_applies(rows, cols)) {
                 // MID-SIZE wide shapes: every tile (diagonal ones included) in ONE stream-K launch with fine units, and one fix-up launch that
                 // also carries the affine part (gram_sk.hip: sk_lin_role) — two launches instead of four (tall + fix-up + strict stream-K + fix-up)
+                // round 6b: ONE launch on 64 x 64 tiles (gram_mid.hip) where the stream's counters are there; -DPMT_MID_SK keeps the two launches
                 const int64_t nt = cdiv(cols, GT);
                 const SKLin lin{(b && sign) ? b : nullptr, sign, reinterpret_cast<LT *>(out_lin), out_const};
+#ifndef PMT_MID_SK
+                if (side && side->counters && (size_t)gram_mid_counters(cols) * sizeof(unsigned) <= MID_COUNTER_BYTES)
+                    rc = launch_gram_mid(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace,
+                                         reinterpret_cast<unsigned *>(static_cast<char *>(side->counters) + MID_OFFSET), s);
+                else
+#endif
                 rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt + 1) / 2, nullptr, 0, nullptr, s, 0, &lin);
                 if (!rc && side && side->in_replay) {          // side-lane entries behind this node may read its affine part (see below)
                     PMT_HIP_CHECK(hipEventRecord(side->fork, s));

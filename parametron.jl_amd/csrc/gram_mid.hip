@@ -1,0 +1,505 @@
+// Canonical least-squares objective for MID-SIZE wide shapes (129 .. 1024 columns, a few thousand rows at most: the sizes the reference
+// is used at with a few hundred variables) in ONE launch: upper triangle of A'A, q = 2 A'c and c'c.
+//
+// Reference semantics replaced: _vecdot!/muladd! literal expansion (src/functions.jl:702-709,548-576) + canonicalize!
+// (src/functions.jl:381-386, src/util.jl:9-26) + update!(::MOI.ScalarQuadraticFunction) (src/moi_interop.jl:45-62): SURVEY Appendix A.3.
+//
+// Why a third form beside gram_sk.hip / gram_tall.hip (profiles/r06_gram_mid.txt): on 128 x 128 tiles a split tile's partial is 128 KB — as
+// large as the 64 rows x 256 columns a work unit reads.  4096 x 512 wrote and re-read 84 MB of partials through a second (fix-up) launch:
+// 54.8 us for 13.7 us of flops.  Here
+//   * tiles are 64 x 64 (a partial is 32 KB); a workgroup takes one (tile, row chunk); its four waves split the chunk's 8-row groups among
+//     themselves (a split of the contraction index: each wave holds the WHOLE tile, 16 blocks x 4 rotations = 64 accumulators, so a
+//     k-step's 4 + 4 operand loads feed 64 MFMAs) and stream their rows straight from global memory (L2 / Infinity Cache: the matrix is
+//     <= 16 MB) in the MFMA operand layout — no barrier, no shared panel; the rotated B operands come out of the wave's private piece of LDS
+//     (gram_tall.hip: gram_stream_kernel);
+//   * diagonal tiles compute their 10 upper blocks and carry q = A'c on the matrix pipe (B operand = c in every lane of the slot); they are
+//     split into fewer chunks than the off-diagonal ones (40 against 64 MFMAs per k-step);
+//   * the waves' sums are added through LDS in a fixed order; a split tile's partials go to the workspace and the LAST workgroup of the tile
+//     to arrive (one atomic counter per tile, release / acquire fences at agent scope — nobody spins, no co-residency needed) adds them in
+//     CHUNK order, whatever the arrival order: deterministic sums; it then writes the tile's terms as row-contiguous 16-byte chunks;
+//   * c'c is one more workgroup of the same launch, in the order pmt_quad_gram_constant_order reports as 5 (gram_sk.hip: sk_lin_role),
+//     restated bit for bit by tests/gpu_util.py.
+// Summation order of a coefficient (fixed by (rows, cols) alone): wave w of chunk c adds the 8-row groups c gpc + w, + 4, .. in MFMA k
+// order (rows 2 k, 2 k + 1 of a group in contraction slot k); waves (0 + 2) + (1 + 3); chunks in ascending order.
+#include "gram_common.h"
+
+#ifndef PMT_MID_WPS
+#define PMT_MID_WPS 1              // waves per SIMD the register budget aims at
+#endif
+#ifndef PMT_MID_G
+#define PMT_MID_G 256              // workgroups the tiles' row chunks are chosen for (one per CU)
+#endif
+#ifndef PMT_MID_D
+#define PMT_MID_D 2                // iterations (8-row groups) in flight per wave
+#endif
+#ifndef PMT_MID_ABL
+#define PMT_MID_ABL 0              // ablations (wrong results): 1 no MFMAs, 2 no loads after the first D groups, 3 no fold of the partials, 4 no epilogue
+#endif
+// The hand-over of a partial to the tile's last arriver.  0 (ships): the partial goes out as agent-scope write-through stores (sc1),
+// s_waitcnt vmcnt(0), then the relaxed agent-scope count; the last arriver reads the partials with agent-scope loads — per-access
+// coherence, the same contract as the pair fold of gram_sk.hip (a property of gfx942 / gfx950, which is all this library is built for).
+// 1: the memory model's form — release fence (buffer_wbl2 sc1: the XCD's whole L2) in every workgroup, acquire fence (buffer_inv sc1) in the
+// last arriver; measured in profiles/r06_gram_mid.txt.
+#ifndef PMT_MID_FORMAL
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#define PMT_MID_FORMAL 1
+#else
+#define PMT_MID_FORMAL 0
+#endif
+#endif
+
+#ifdef PMT_MID_TRACE
+// debugging aid (tools/mid_trace.py): 100 MHz wall-clock stamps of the phases of every workgroup
+__device__ unsigned long long g_mid_trace[1024 * 8];
+#define MID_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_mid_trace[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+extern "C" int pmt_mid_trace_read(unsigned long long *host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mid_trace), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define MID_STAMP(k) do { } while (0)
+#endif
+
+namespace pmt {
+
+constexpr int MT = 64;                       // tile edge
+constexpr int MACC = 64;                     // accumulators per lane: (block row tm, block column tn, rotation) = (a >> 4, (a >> 2) & 3, a & 3)
+constexpr int MPART = MACC * 64;             // doubles of a tile partial, [a][lane]
+constexpr int MSTRIDE = MPART + MT + 8;      // + q partial (diagonal tiles), padded to 64 bytes
+constexpr int MPITCH = MT + 1;
+constexpr int MRSLOT = MPART + MT;           // one wave's sums in LDS
+constexpr int MSH = 2 * MRSLOT + 8 + 2 * MT; // doubles of LDS per workgroup (67.6 KB): rotation pieces / two reduction slots / the finished tile; flag word; variable maps
+
+struct MidArgs {
+    const double *A; int64_t lda, rows, cols;
+    const double *b; int sign;               // c_i = 0.0 (+|-) b[i]; null / 0: c = 0
+    const int64_t *xvar; const int64_t *varmap; int moi;
+    QT *out_quad; double *out_csc; double alpha; LT *out_lin; double *out_const;
+    int nb;                                  // 64-column panels
+    int n_off, s_off, s_diag;                // strictly upper tiles, row chunks of one, row chunks of a diagonal tile
+    int gpc_off, gpc_diag;                   // 8-row groups per chunk
+    double *ws;                              // one MSTRIDE slot per workgroup
+    unsigned *counters;                      // one per tile, zero between launches (the last arriver re-arms its tile's)
+};
+
+struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, wgs; };
+
+// row chunks per tile: as many as PMT_MID_G workgroups allow, a diagonal tile 5/8 of an off-diagonal one's, at least four groups per chunk
+static MidPlan mid_plan(int64_t rows, int64_t cols) {
+    MidPlan p;
+    p.nb = (int)cdiv(cols, MT);
+    p.n_off = p.nb * (p.nb - 1) / 2;
+    const int ngroups = (int)std::max<int64_t>(1, cdiv(rows, 8));
+    const int maxs = std::max(1, ngroups / 4);
+    auto sd = [&](int s) { return std::min(maxs, std::max(1, (5 * s + 7) / 8)); };
+    int s = 1;
+    while (s + 1 <= maxs && p.n_off * (s + 1) + p.nb * sd(s + 1) <= PMT_MID_G) ++s;
+    p.gpc_off = (int)cdiv(ngroups, s);
+    p.s_off = (int)cdiv(ngroups, p.gpc_off);
+    p.gpc_diag = (int)cdiv(ngroups, sd(s));
+    p.s_diag = (int)cdiv(ngroups, p.gpc_diag);
+    p.wgs = p.n_off * p.s_off + p.nb * p.s_diag + 1;
+    return p;
+}
+
+// one 8-row group of one wave: buf[t] = rows (row0 + 2 lk, + 1) of column (t < 4 ? cj0 : ck0) + 16 (t & 3) + lm; cb = the same rows of b.
+// FAST (A 16-byte aligned with an even pitch, b 16-byte aligned, the matrix within 4 GiB): scalar base + 32-bit lane offset, no mask (a
+// column beyond the matrix reads the LAST column: its products land in entries nobody stores).  Otherwise 8-byte loads from clamped
+// addresses, what lies outside replaced by 0.0 — no branch around a load (gram_tall.hip: stream_load).
+template <bool DIAG, bool FAST>
+__device__ __forceinline__ void mid_load(const MidArgs &g, int64_t row0, int lane, int64_t cj0, int64_t ck0, const unsigned (&voff)[DIAG ? 4 : 8],
+                                         f64x2 (&buf)[DIAG ? 4 : 8], f64x2 &cb) {
+    constexpr int NG = DIAG ? 4 : 8;
+    const int lm = lane & 15, lk = lane >> 4;
+    if (FAST) {
+        const char *base = reinterpret_cast<const char *>(g.A + row0);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) buf[t] = *reinterpret_cast<const f64x2 *>(base + voff[t]);
+        cb.x = 0.0; cb.y = 0.0;
+        if (DIAG && g.b) cb = *reinterpret_cast<const f64x2 *>(g.b + row0 + 2 * lk);
+        return;
+    }
+    const int64_t row = row0 + 2 * lk;
+    const bool r0 = row < g.rows, r1 = row + 1 < g.rows;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        const int64_t col = (t < 4 ? cj0 : ck0) + 16 * (t & 3) + lm;
+        const bool cv = col < g.cols;
+        const bool v0 = cv && r0, v1 = cv && r1;
+        const double *p0 = g.A + (v0 ? col * g.lda + row : 0), *p1 = g.A + (v1 ? col * g.lda + row + 1 : 0);
+        const double x = *p0, y = *p1;
+        buf[t].x = v0 ? x : 0.0;
+        buf[t].y = v1 ? y : 0.0;
+    }
+    cb.x = 0.0; cb.y = 0.0;
+    if (DIAG && g.b) {
+        const double x = g.b[r0 ? row : 0], y = g.b[r1 ? row + 1 : 0];
+        cb.x = r0 ? x : 0.0;
+        cb.y = r1 ? y : 0.0;
+    }
+}
+
+// the MFMAs of one 8-row group.  The B operand of rotation r of a block column is the value the lane 4 r further up its 16-lane row holds:
+// the wave stores its four B groups into its private piece of LDS and reads them back rotated (a wave's LDS operations execute in order).
+template <bool DIAG>
+__device__ __forceinline__ void mid_compute(double *__restrict__ rot, const f64x2 (&buf)[DIAG ? 4 : 8], const f64x2 &cb, int sign, int lane,
+                                            double (&acc)[MACC], double (&qacc)[4]) {
+    constexpr int BO = DIAG ? 0 : 4;
+    const int lm = lane & 15, lrow = lane & 48;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f64x2 *>(rot + (t * 64 + lane) * 2) = buf[BO + t];
+#pragma unroll
+    for (int c = 0; c < (PMT_MID_ABL == 1 ? 0 : 4); ++c) {
+        f64x2 bv[4];
+        bv[0] = buf[BO + c];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) bv[r] = *reinterpret_cast<const f64x2 *>(rot + (c * 64 + lrow + ((lm + 4 * r) & 15)) * 2);
+#pragma unroll
+        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = (tm * 4 + c) * 4 + r;
+                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].x, bv[r].x, acc[a], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = (tm * 4 + c) * 4 + r;
+                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].y, bv[r].y, acc[a], 0, 0, 0);
+            }
+    }
+    if (DIAG) {
+        // q = A'c on the matrix pipe: the B operand is c in every lane of the contraction slot, so block b of the result holds q of the
+        // columns 4 b .. 4 b + 3 of the group (four copies)
+        const double c0 = signed_const(cb.x, sign), c1 = signed_const(cb.y, sign);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].x, c0, qacc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].y, c1, qacc[t], 0, 0, 0);
+    }
+}
+
+__host__ __device__ constexpr bool mid_used(bool diag, int a) { return !diag || (a >> 4) <= ((a >> 2) & 3); }
+
+// (row, col) inside the tile of accumulator a of a lane (gram_common.h: sk_acc_pos, on the 4 x 4 block grid of the tile)
+__device__ __forceinline__ void mid_pos(int lane, int a, int &row, int &col) {
+    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+    row = 16 * (a >> 4) + 4 * b + i;
+    col = 16 * ((a >> 2) & 3) + 4 * ((b + (a & 3)) & 3) + j;
+}
+
+// the mapped variable indices of the tile's 64 columns / 64 rows, gathered at the TOP of the workgroup's life (two dependent loads that
+// would otherwise stand in the tail of the tile's last arriver); the barriers of the wave sums order them before the epilogue
+__device__ __forceinline__ void mid_maps(const MidArgs &g, double *sh, int tid, int jb, int kb) {
+    u64 *cmap = reinterpret_cast<u64 *>(sh + 2 * MRSLOT + 8);
+    if (tid >= 2 * MT || (!g.out_quad && jb != kb)) return;
+    const int64_t i = (tid < MT ? (int64_t)kb * MT + tid : (int64_t)jb * MT + tid - MT);
+    const int64_t v = i < g.cols ? g.xvar[i] : 1;
+    cmap[tid] = (u64)(g.moi ? map_var(g.varmap, v) : v);
+}
+
+// The finished tile (sh[row * MPITCH + col], q of a diagonal tile in sh[MT * MPITCH ..]) -> terms.  Row j of the tile's entries
+// k = max(j, k0) .. are consecutive QuadraticTerms of the canonical upper triangle: one wave per row, 16-byte chunks.
+__device__ __forceinline__ void mid_epilogue(const MidArgs &g, double *sh, int tid, int jb, int kb) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int64_t n = g.cols, j0 = (int64_t)jb * MT, k0 = (int64_t)kb * MT;
+    double *tile = sh;
+    const double *qfin = sh + MT * MPITCH;
+    const u64 *cmap = reinterpret_cast<const u64 *>(sh + 2 * MRSLOT + 8);          // (mid_maps, at the top of the kernel)
+    const u64 *rmap = cmap + MT;
+    if (g.out_csc) {
+        const int64_t j = j0 + lane;
+        for (int col = wave; col < MT; col += 4) {
+            const int64_t k = k0 + col;
+            if (k >= n) break;
+            if (j <= k) {
+                double c = tile[lane * MPITCH + col];
+                if (g.moi || j != k) c = 2 * c;
+                g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
+            }
+        }
+    }
+    if (g.out_quad) {
+        u64 *out = reinterpret_cast<u64 *>(g.out_quad);
+        for (int row = wave; row < MT; row += 4) {
+            const int64_t j = j0 + row;
+            if (j >= n) break;
+            const int64_t kstart = j > k0 ? j : k0;
+            const int64_t kend = (k0 + MT < n) ? k0 + MT : n;
+            const int nterms = (int)(kend - kstart);
+            if (nterms <= 0) continue;
+            const int coff = (int)(kstart - k0);
+            const double *trow = tile + row * MPITCH + coff;
+            const u64 rv = rmap[row];
+            const bool dg = kstart == j;                 // the segment starts on the diagonal: its first term is not doubled in native mode
+            const int moi = g.moi;
+            wave_write_words<3>(out + (j * n - (j * (j - 1)) / 2 + (kstart - j)) * 3, nterms, lane, [&](int q) -> u64 {
+                const int t = q / 3, f = q - 3 * t;
+                if (f == 1) return rv;
+                if (f == 2) return cmap[coff + t];
+                double c = trow[t];
+                if (moi || !(dg && t == 0)) c = 2 * c;      // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
+                return (u64)__double_as_longlong(c);
+            });
+        }
+    }
+    if (jb == kb && tid < MT) {
+        const int64_t j = j0 + tid;
+        if (j < n) {
+            LT t;
+            t.coeff = 2 * qfin[tid];
+            t.var = (int64_t)rmap[tid];
+            g.out_lin[j] = t;
+        }
+    }
+}
+
+// c'c in order 5 (gram_sk.hip: sk_lin_role): virtual thread t of 512 adds rows t, t + 512, ..; a shuffle tree per virtual wave; the eight
+// virtual waves in order.  Thread tid of this 256-thread workgroup is the virtual threads tid and tid + 256.
+__device__ __forceinline__ void mid_constant(const MidArgs &g, double *sh, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    double s0 = 0.0, s1 = 0.0;
+    if (g.b && g.sign) {
+        for (int64_t i = tid; i < g.rows; i += 512) { const double c = signed_const(g.b[i], g.sign); s0 = s0 + c * c; }
+        for (int64_t i = tid + 256; i < g.rows; i += 512) { const double c = signed_const(g.b[i], g.sign); s1 = s1 + c * c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 = s0 + __shfl_down(s0, off, 64); s1 = s1 + __shfl_down(s1, off, 64); }
+    if (lane == 0) { sh[wave] = s0; sh[4 + wave] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        double v = sh[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v = v + sh[w];
+        *g.out_const = v;
+    }
+}
+
+__device__ __forceinline__ void mid_put(double *p, double v) {
+#if PMT_MID_FORMAL
+    *p = v;
+#else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ double mid_get(const double *p) {
+#if PMT_MID_FORMAL
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
+template <bool DIAG, bool FAST>
+__device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, int jb, int kb, int chunk, int nchunk, int gpc, int first_wg, unsigned *counter) {
+    constexpr int NG = DIAG ? 4 : 8;
+    constexpr int D = PMT_MID_D;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, lk = lane >> 4;
+    const int64_t cj0 = (int64_t)jb * MT, ck0 = (int64_t)kb * MT;
+    const int ngroups = (int)((g.rows + 7) >> 3);
+    const int g0 = chunk * gpc + wave, g1 = min((chunk + 1) * gpc, ngroups);
+    const int my = g1 > g0 ? (g1 - g0 + 3) / 4 : 0;                       // groups g0, g0 + 4, .. of this wave
+    // the one ragged group (rows % 8 rows) is the last group of the matrix: loaded with masks, outside the pipelined loop
+    const bool ragged = FAST && (g.rows & 7) && my > 0 && g0 + 4 * (my - 1) == ngroups - 1;
+    const int nfast = ragged ? my - 1 : my;
+
+    MID_STAMP(0);
+    mid_maps(g, sh, tid, jb, kb);
+    double acc[MACC], qacc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < MACC; ++a) acc[a] = 0.0;
+    unsigned voff[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) voff[t] = (unsigned)((min((t < 4 ? cj0 : ck0) + 16 * (t & 3) + lm, g.cols - 1) * g.lda + 2 * lk) * 8);
+    double *rot = sh + wave * 512;
+    f64x2 buf[D][NG], cb[D];
+    auto row_of = [&](int s) { return (int64_t)(g0 + 4 * min(s, max(nfast - 1, 0))) * 8; };
+    if (nfast > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) mid_load<DIAG, FAST>(g, row_of(d), lane, cj0, ck0, voff, buf[d], cb[d]);
+        for (int s0 = 0; s0 < nfast; s0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (s0 + d < nfast) mid_compute<DIAG>(rot, buf[d], cb[d], g.sign, lane, acc, qacc);
+                if (PMT_MID_ABL != 2) mid_load<DIAG, FAST>(g, row_of(s0 + d + D), lane, cj0, ck0, voff, buf[d], cb[d]);
+            }
+        }
+    }
+    if (ragged) {
+        mid_load<DIAG, false>(g, (int64_t)(ngroups - 1) * 8, lane, cj0, ck0, voff, buf[0], cb[0]);
+        mid_compute<DIAG>(rot, buf[0], cb[0], g.sign, lane, acc, qacc);
+    }
+
+    MID_STAMP(1);
+    // the four waves' sums: (0 + 2) + (1 + 3), through two slots of LDS
+    const bool qlane = (lane & 3) == 0;
+    const int qcol = 4 * ((lane >> 2) & 3) + (lane >> 4);          // q of column 16 t + qcol sits in qacc[t] of the lanes with lane & 3 == 0
+    auto put = [&](double *slot) {
+#pragma unroll
+        for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) slot[a * 64 + lane] = acc[a];
+        if (DIAG && qlane) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) slot[MPART + 16 * t + qcol] = qacc[t];
+        }
+    };
+    auto add = [&](const double *slot) {
+#pragma unroll
+        for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) acc[a] = acc[a] + slot[a * 64 + lane];
+        if (DIAG) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) qacc[t] = qacc[t] + slot[MPART + 16 * t + (qlane ? qcol : 0)];
+        }
+    };
+    __syncthreads();                                               // every wave is done with its rotation piece
+    if (wave >= 2) put(sh + (wave - 2) * MRSLOT);
+    __syncthreads();
+    if (wave < 2) add(sh + wave * MRSLOT);
+    __syncthreads();
+    if (wave == 1) put(sh);
+    __syncthreads();
+    if (wave == 0) add(sh);
+    __syncthreads();
+
+    unsigned *flag = reinterpret_cast<unsigned *>(sh + 2 * MRSLOT);
+    MID_STAMP(2);
+    if (nchunk == 1) {
+        // the whole tile in one workgroup: wave 0's registers -> the finished tile in LDS
+        if (wave == 0) {
+#pragma unroll
+            for (int a = 0; a < MACC; ++a) {
+                if (!mid_used(DIAG, a)) continue;
+                int row, col;
+                mid_pos(lane, a, row, col);
+                sh[row * MPITCH + col] = acc[a];
+            }
+            if (DIAG && qlane) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sh[MT * MPITCH + 16 * t + qcol] = qacc[t];
+            }
+        }
+    } else {
+        double *w = g.ws + (int64_t)(first_wg + chunk) * MSTRIDE;
+        if (wave == 0) {
+#pragma unroll
+            for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) mid_put(&w[a * 64 + lane], acc[a]);
+            if (DIAG && qlane) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mid_put(&w[MPART + 16 * t + qcol], qacc[t]);
+            }
+            // the partial is visible device-wide before the tile's count goes up
+#if PMT_MID_FORMAL
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            if (lane == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        MID_STAMP(3);
+        if (PMT_MID_ABL == 3 || *flag != (unsigned)(nchunk - 1)) return;               // (workgroup-uniform) not the last one of this tile
+#if PMT_MID_FORMAL
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+        // the chunks' partials in ascending order, LOADED four chunks at a time (64 loads in flight per thread: the sum is not a chain of
+        // round trips to the fabric); thread tid: the elements e = tid + 256 u of the [a][lane] layout
+        const double *p = g.ws + (int64_t)first_wg * MSTRIDE;
+        double sum[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum[u] = 0.0;
+        double qs = 0.0;
+        for (int c0 = 0; c0 < nchunk; c0 += 4) {
+            double v[4][16], qv[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const double *pc = p + (int64_t)min(c0 + cc, nchunk - 1) * MSTRIDE;      // (beyond the last chunk: a repeated load that is not added)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int a = (tid >> 6) + 4 * u;
+                    v[cc][u] = 0.0;
+                    if (mid_used(DIAG, a)) v[cc][u] = mid_get(pc + tid + 256 * u);
+                }
+                qv[cc] = 0.0;
+                if (DIAG && tid < MT) qv[cc] = mid_get(pc + MPART + tid);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const bool live = c0 + cc < nchunk;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const double t = sum[u] + v[cc][u]; sum[u] = live ? t : sum[u]; }
+                const double t = qs + qv[cc];
+                qs = live ? t : qs;
+            }
+        }
+        __syncthreads();                                           // (the tile overwrites the reduction slots)
+        MID_STAMP(4);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int a = (tid >> 6) + 4 * u;
+            if (!mid_used(DIAG, a)) continue;
+            int row, col;
+            mid_pos(lane, a, row, col);
+            sh[row * MPITCH + col] = sum[u];
+        }
+        if (DIAG && tid < MT) sh[MT * MPITCH + tid] = qs;
+    }
+    __syncthreads();
+    MID_STAMP(5);
+    if (PMT_MID_ABL != 4) mid_epilogue(g, sh, tid, jb, kb);
+    __builtin_amdgcn_s_waitcnt(0);
+    MID_STAMP(6);
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
+    __shared__ double sh[MSH];
+    const int tid = threadIdx.x;
+    int id = blockIdx.x;
+    const int noff = g.n_off * g.s_off;
+    if (id < noff) {
+        int t = id / g.s_off;
+        const int chunk = id - t * g.s_off;
+        const int tile = t;
+        int kb = 1;
+        while (t >= kb) { t -= kb; ++kb; }                         // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
+        mid_body<false, FAST>(g, sh, tid, t, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile);
+        return;
+    }
+    id -= noff;
+    if (id < g.nb * g.s_diag) {
+        const int jb = id / g.s_diag, chunk = id - jb * g.s_diag;
+        mid_body<true, FAST>(g, sh, tid, jb, jb, chunk, g.s_diag, g.gpc_diag, noff + jb * g.s_diag, g.counters + g.n_off + jb);
+        return;
+    }
+    mid_constant(g, sh, tid);
+}
+
+size_t gram_mid_workspace_bytes(int64_t rows, int64_t cols) {
+    if (cols <= 0) return 0;
+    const MidPlan p = mid_plan(rows, cols);
+    return sizeof(double) * (size_t)p.wgs * MSTRIDE;
+}
+int gram_mid_counters(int64_t cols) { const int nb = (int)cdiv(cols, MT); return nb * (nb + 1) / 2; }
+
+// the whole node in one launch; `counters`: gram_mid_counters(cols) zeroed words owned by the calling stream (gram.hip: SideStream)
+int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
+                    const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
+                    double *out_const, void *workspace, unsigned *counters, hipStream_t s) {
+    if (!workspace || !counters) return fail(PMT_INVALID_ARGUMENT, "quad_gram: workspace required");
+    const MidPlan p = mid_plan(rows, cols);
+    MidArgs g;
+    g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.b = (b && sign) ? b : nullptr; g.sign = g.b ? sign : 0;
+    g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = reinterpret_cast<QT *>(out_quad); g.out_csc = out_csc; g.alpha = alpha;
+    g.out_lin = reinterpret_cast<LT *>(out_lin); g.out_const = out_const;
+    g.nb = p.nb; g.n_off = p.n_off; g.s_off = p.s_off; g.s_diag = p.s_diag; g.gpc_off = p.gpc_off; g.gpc_diag = p.gpc_diag;
+    g.ws = reinterpret_cast<double *>(workspace); g.counters = counters;
+    const bool fast = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0 &&
+                      (uint64_t)lda * (uint64_t)cols * 8 < (1ull << 32);
+    if (fast) PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<true>), dim3((unsigned)p.wgs), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<false>), dim3((unsigned)p.wgs), dim3(256), 0, s, g);
+    return check_launch("gram_mid_kernel");
+}
+
+}  // namespace pmt
