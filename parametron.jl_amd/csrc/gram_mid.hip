@@ -30,7 +30,13 @@
 #define PMT_MID_G 256              // workgroups the tiles' row chunks are chosen for (one per CU)
 #endif
 #ifndef PMT_MID_D
-#define PMT_MID_D 2                // iterations (8-row groups) in flight per wave
+#define PMT_MID_D 3                // iterations (8-row groups) in flight per wave (2: 40.3 us at 4096 x 512, 3: 37.9)
+#endif
+#ifndef PMT_MID_FB
+#define PMT_MID_FB 4               // chunks whose partials the last arriver loads together (64 loads per thread: a wave may have 63 outstanding; 8, or 16-byte loads: no faster)
+#endif
+#ifndef PMT_MID_SCHED
+#define PMT_MID_SCHED 1            // scheduling barriers between the phases of an 8-row group (mid_compute)
 #endif
 #ifndef PMT_MID_ABL
 #define PMT_MID_ABL 0              // ablations (wrong results): 1 no MFMAs, 2 no loads after the first D groups, 3 no fold of the partials, 4 no epilogue
@@ -66,8 +72,10 @@ constexpr int MACC = 64;                     // accumulators per lane: (block ro
 constexpr int MPART = MACC * 64;             // doubles of a tile partial, [a][lane]
 constexpr int MSTRIDE = MPART + MT + 8;      // + q partial (diagonal tiles), padded to 64 bytes
 constexpr int MPITCH = MT + 1;
-constexpr int MRSLOT = MPART + MT;           // one wave's sums in LDS
-constexpr int MSH = 2 * MRSLOT + 8 + 2 * MT; // doubles of LDS per workgroup (67.6 KB): rotation pieces / two reduction slots / the finished tile; flag word; variable maps
+constexpr int MQBUF = 4 * 2048;              // LDS (doubles): [0, 8192) rotation pieces / the waves' exchange pieces / the finished tile + q + row descriptors;
+constexpr int MFLAG = MQBUF + 4 * MT;        // the waves' q (4 x 64); the count's old value; the tile's variable maps (2 x 64)
+constexpr int MMAPS = MFLAG + 8;
+constexpr int MSH = MMAPS + 2 * MT;          // 68.7 KB per workgroup
 
 struct MidArgs {
     const double *A; int64_t lda, rows, cols;
@@ -146,26 +154,56 @@ __device__ __forceinline__ void mid_compute(double *__restrict__ rot, const f64x
     constexpr int BO = DIAG ? 0 : 4;
     const int lm = lane & 15, lrow = lane & 48;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<f64x2 *>(rot + (t * 64 + lane) * 2) = buf[BO + t];
+    for (int t = 0; t < (PMT_MID_ABL == 5 || PMT_MID_ABL == 6 ? 0 : 4); ++t) *reinterpret_cast<f64x2 *>(rot + (t * 64 + lane) * 2) = buf[BO + t];
+    // ALL rotated operands are asked for up front, and the MFMAs that need none of them (rotation 0: the loaded values themselves) go
+    // first: the LDS round trip hides behind 32 MFMAs.  Read rotation by rotation in front of their first use, every wait for an LDS
+    // read stood in the wave's one issue stream (one wave per SIMD): ~10 exposed waits per 8-row group, the loop at 0.55 of the pipe.
+    f64x2 bv[4][4];
 #pragma unroll
-    for (int c = 0; c < (PMT_MID_ABL == 1 ? 0 : 4); ++c) {
-        f64x2 bv[4];
-        bv[0] = buf[BO + c];
+    for (int c = 0; c < 4; ++c) {
+        bv[c][0] = buf[BO + c];
 #pragma unroll
-        for (int r = 1; r < 4; ++r) bv[r] = *reinterpret_cast<const f64x2 *>(rot + (c * 64 + lrow + ((lm + 4 * r) & 15)) * 2);
+        for (int r = 1; r < 4; ++r) {
+            if (PMT_MID_ABL == 5 || PMT_MID_ABL == 6) { bv[c][r] = buf[BO + (PMT_MID_ABL == 6 ? 0 : c)]; continue; }      // (ablation: no rotations)
+            bv[c][r] = *reinterpret_cast<const f64x2 *>(rot + (c * 64 + lrow + ((lm + 4 * r) & 15)) * 2);
+        }
+    }
+#if PMT_MID_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    constexpr int NC = PMT_MID_ABL == 1 ? 0 : 4;
 #pragma unroll
-        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm) {
+            const int a = (tm * 4 + c) * 4;
+            acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].x, bv[c][0].x, acc[a], 0, 0, 0);
+        }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm) {
+            const int a = (tm * 4 + c) * 4;
+            acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].y, bv[c][0].y, acc[a], 0, 0, 0);
+        }
+#if PMT_MID_SCHED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+#pragma unroll
+            for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm) {
                 const int a = (tm * 4 + c) * 4 + r;
-                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].x, bv[r].x, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].x, bv[c][r].x, acc[a], 0, 0, 0);
             }
 #pragma unroll
-        for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm)
+        for (int r = 1; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm) {
                 const int a = (tm * 4 + c) * 4 + r;
-                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].y, bv[r].y, acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[tm].y, bv[c][r].y, acc[a], 0, 0, 0);
             }
     }
     if (DIAG) {
@@ -191,7 +229,7 @@ __device__ __forceinline__ void mid_pos(int lane, int a, int &row, int &col) {
 // the mapped variable indices of the tile's 64 columns / 64 rows, gathered at the TOP of the workgroup's life (two dependent loads that
 // would otherwise stand in the tail of the tile's last arriver); the barriers of the wave sums order them before the epilogue
 __device__ __forceinline__ void mid_maps(const MidArgs &g, double *sh, int tid, int jb, int kb) {
-    u64 *cmap = reinterpret_cast<u64 *>(sh + 2 * MRSLOT + 8);
+    u64 *cmap = reinterpret_cast<u64 *>(sh + MMAPS);
     if (tid >= 2 * MT || (!g.out_quad && jb != kb)) return;
     const int64_t i = (tid < MT ? (int64_t)kb * MT + tid : (int64_t)jb * MT + tid - MT);
     const int64_t v = i < g.cols ? g.xvar[i] : 1;
@@ -205,42 +243,52 @@ __device__ __forceinline__ void mid_epilogue(const MidArgs &g, double *sh, int t
     const int64_t n = g.cols, j0 = (int64_t)jb * MT, k0 = (int64_t)kb * MT;
     double *tile = sh;
     const double *qfin = sh + MT * MPITCH;
-    const u64 *cmap = reinterpret_cast<const u64 *>(sh + 2 * MRSLOT + 8);          // (mid_maps, at the top of the kernel)
+    const u64 *cmap = reinterpret_cast<const u64 *>(sh + MMAPS);          // (mid_maps, at the top of the kernel)
     const u64 *rmap = cmap + MT;
     if (g.out_csc) {
         const int64_t j = j0 + lane;
+#pragma unroll 4
         for (int col = wave; col < MT; col += 4) {
             const int64_t k = k0 + col;
-            if (k >= n) break;
-            if (j <= k) {
-                double c = tile[lane * MPITCH + col];
-                if (g.moi || j != k) c = 2 * c;
-                g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
-            }
+            double c = tile[lane * MPITCH + col];
+            if (g.moi || j != k) c = 2 * c;
+            if (k < n && j <= k) g.out_csc[k * (k + 1) / 2 + j] = g.alpha * c;
         }
     }
     if (g.out_quad) {
+        // One descriptor per tile row (first word of its segment in the term array, term count, first column, diagonal flag), then a
+        // wave per row, a lane per TERM: two unconditional LDS reads and three 8-byte stores (scalar row base + 24 * lane + immediate).
+        // The workgroup is alone with the tile (one wave per SIMD), so what counts is the instruction count: 16-byte chunks assembled
+        // word by word took 15 us per tile as a wave per row with conditional reads, 6.9 us as a flat chunk list, (tools/mid_trace.py).
         u64 *out = reinterpret_cast<u64 *>(g.out_quad);
-        for (int row = wave; row < MT; row += 4) {
-            const int64_t j = j0 + row;
-            if (j >= n) break;
+        u64 *desc = reinterpret_cast<u64 *>(sh + MT * MPITCH + MT);
+        if (tid < MT) {
+            const int64_t j = j0 + tid;
             const int64_t kstart = j > k0 ? j : k0;
             const int64_t kend = (k0 + MT < n) ? k0 + MT : n;
-            const int nterms = (int)(kend - kstart);
-            if (nterms <= 0) continue;
-            const int coff = (int)(kstart - k0);
-            const double *trow = tile + row * MPITCH + coff;
-            const u64 rv = rmap[row];
-            const bool dg = kstart == j;                 // the segment starts on the diagonal: its first term is not doubled in native mode
-            const int moi = g.moi;
-            wave_write_words<3>(out + (j * n - (j * (j - 1)) / 2 + (kstart - j)) * 3, nterms, lane, [&](int q) -> u64 {
-                const int t = q / 3, f = q - 3 * t;
-                if (f == 1) return rv;
-                if (f == 2) return cmap[coff + t];
-                double c = trow[t];
-                if (moi || !(dg && t == 0)) c = 2 * c;      // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
-                return (u64)__double_as_longlong(c);
-            });
+            const int64_t nterms = (j < n && kend > kstart) ? kend - kstart : 0;
+            desc[2 * tid] = (u64)(j * n - (j * (j - 1)) / 2 + (kstart - j)) * 3;
+            desc[2 * tid + 1] = (u64)nterms | (u64)(kstart - k0) << 16 | (u64)(kstart == j ? 1 : 0) << 24;
+        }
+        __syncthreads();
+        const bool moi = g.moi != 0;
+        const int uwave = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll 4
+        for (int i = 0; i < MT / 4; ++i) {
+            const int row = 4 * i + uwave;
+            const u64 w0 = desc[2 * row], info = desc[2 * row + 1];
+            const int nterms = (int)(info & 0xffff), coff = (int)((info >> 16) & 0xff);
+            const bool dg = ((info >> 24) & 1) != 0;          // the segment starts on the diagonal: its first term is not doubled in native mode
+            double c = tile[row * MPITCH + coff + lane];
+            const u64 m = cmap[(coff + lane) & (MT - 1)], rv = rmap[row];
+            // off-diagonal: (j,k)+(k,j) combined; diagonal: MOI doubling (moi_interop.jl:58)
+            if (moi || !(dg && lane == 0)) c = 2 * c;
+            if (lane < nterms) {
+                u64 *d = out + w0 + 3 * lane;
+                d[0] = (u64)__double_as_longlong(c);
+                d[1] = rv;
+                d[2] = m;
+            }
         }
     }
     if (jb == kb && tid < MT) {
@@ -290,6 +338,69 @@ __device__ __forceinline__ double mid_get(const double *p) {
 #endif
 }
 
+// Behind the main loop, as seen by wave W.  The four waves' sums, (0 + 2) + (1 + 3), by halving: wave W hands the half of its 64
+// accumulators that its partner W ^ 2 keeps to that partner through LDS and adds the partner's other half to its own; then the same
+// with quarters and the partner W ^ 1 — every wave ends up OWNING the finished sums of one block row (a = 16 W .. 16 W + 15), each
+// the same bits whichever side added (a + b = b + a).  Two waves summing everything for the others took 2.5 us of the workgroup's tail
+// (accumulator moves + adds in one issue stream, tools/mid_trace.py); here every wave moves 48 and adds 48.  The owned quarter then goes
+// to the workspace (a split tile) or into the finished tile in LDS; q of a diagonal tile is added by wave 0 (lane = column).
+template <bool DIAG, int W>
+__device__ __forceinline__ void mid_tail(const MidArgs &g, double *sh, int lane, double (&acc)[MACC], const double (&qacc)[4], int nchunk, double *w) {
+    constexpr int KEEP1 = (W >> 1) * 32, GIVE1 = 32 - KEEP1, KEEP2 = KEEP1 + (W & 1) * 16, GIVE2 = KEEP1 + 16 - (W & 1) * 16;
+    double *mine = sh + W * 2048;
+    const double *half = sh + (W ^ 2) * 2048, *quarter = sh + (W ^ 1) * 2048;
+    const bool qlane = (lane & 3) == 0;
+    const int qcol = 4 * ((lane >> 2) & 3) + (lane >> 4);          // q of column 16 t + qcol sits in qacc[t] of the lanes with lane & 3 == 0
+#pragma unroll
+    for (int a = 0; a < 32; a += 2)
+        if (mid_used(DIAG, GIVE1 + a)) { f64x2 v; v.x = acc[GIVE1 + a]; v.y = acc[GIVE1 + a + 1]; *reinterpret_cast<f64x2 *>(mine + (a * 32 + lane) * 2) = v; }
+    if (DIAG && qlane) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sh[MQBUF + W * MT + 16 * t + qcol] = qacc[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 32; a += 2)
+        if (mid_used(DIAG, KEEP1 + a)) {
+            const f64x2 v = *reinterpret_cast<const f64x2 *>(half + (a * 32 + lane) * 2);
+            acc[KEEP1 + a] = acc[KEEP1 + a] + v.x; acc[KEEP1 + a + 1] = acc[KEEP1 + a + 1] + v.y;
+        }
+    double qsum = 0.0;
+    if (DIAG && W == 0) qsum = (sh[MQBUF + lane] + sh[MQBUF + 2 * MT + lane]) + (sh[MQBUF + MT + lane] + sh[MQBUF + 3 * MT + lane]);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; a += 2)
+        if (mid_used(DIAG, GIVE2 + a)) { f64x2 v; v.x = acc[GIVE2 + a]; v.y = acc[GIVE2 + a + 1]; *reinterpret_cast<f64x2 *>(mine + (a * 32 + lane) * 2) = v; }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 16; a += 2)
+        if (mid_used(DIAG, KEEP2 + a)) {
+            const f64x2 v = *reinterpret_cast<const f64x2 *>(quarter + (a * 32 + lane) * 2);
+            acc[KEEP2 + a] = acc[KEEP2 + a] + v.x; acc[KEEP2 + a + 1] = acc[KEEP2 + a + 1] + v.y;
+        }
+    __syncthreads();                                               // (the finished tile overwrites the exchange pieces)
+    if (nchunk == 1) {
+#pragma unroll
+        for (int a = KEEP2; a < KEEP2 + 16; ++a) {
+            if (!mid_used(DIAG, a)) continue;
+            int row, col;
+            mid_pos(lane, a, row, col);
+            sh[row * MPITCH + col] = acc[a];
+        }
+        if (DIAG && W == 0) sh[MT * MPITCH + lane] = qsum;
+        return;
+    }
+#pragma unroll
+    for (int a = KEEP2; a < KEEP2 + 16; ++a) if (mid_used(DIAG, a)) mid_put(&w[a * 64 + lane], acc[a]);
+    if (DIAG && W == 0) mid_put(&w[MPART + lane], qsum);
+    // the partial is visible device-wide before the tile's count goes up (mid_body: a barrier, then the count)
+#if PMT_MID_FORMAL
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+}
+
 template <bool DIAG, bool FAST>
 __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, int jb, int kb, int chunk, int nchunk, int gpc, int first_wg, unsigned *counter) {
     constexpr int NG = DIAG ? 4 : 8;
@@ -333,69 +444,17 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
     }
 
     MID_STAMP(1);
-    // the four waves' sums: (0 + 2) + (1 + 3), through two slots of LDS
-    const bool qlane = (lane & 3) == 0;
-    const int qcol = 4 * ((lane >> 2) & 3) + (lane >> 4);          // q of column 16 t + qcol sits in qacc[t] of the lanes with lane & 3 == 0
-    auto put = [&](double *slot) {
-#pragma unroll
-        for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) slot[a * 64 + lane] = acc[a];
-        if (DIAG && qlane) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) slot[MPART + 16 * t + qcol] = qacc[t];
-        }
-    };
-    auto add = [&](const double *slot) {
-#pragma unroll
-        for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) acc[a] = acc[a] + slot[a * 64 + lane];
-        if (DIAG) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) qacc[t] = qacc[t] + slot[MPART + 16 * t + (qlane ? qcol : 0)];
-        }
-    };
+    unsigned *flag = reinterpret_cast<unsigned *>(sh + MFLAG);
+    double *w = g.ws + (int64_t)(first_wg + chunk) * MSTRIDE;
     __syncthreads();                                               // every wave is done with its rotation piece
-    if (wave >= 2) put(sh + (wave - 2) * MRSLOT);
-    __syncthreads();
-    if (wave < 2) add(sh + wave * MRSLOT);
-    __syncthreads();
-    if (wave == 1) put(sh);
-    __syncthreads();
-    if (wave == 0) add(sh);
-    __syncthreads();
-
-    unsigned *flag = reinterpret_cast<unsigned *>(sh + 2 * MRSLOT);
+    if (wave == 0) mid_tail<DIAG, 0>(g, sh, lane, acc, qacc, nchunk, w);
+    else if (wave == 1) mid_tail<DIAG, 1>(g, sh, lane, acc, qacc, nchunk, w);
+    else if (wave == 2) mid_tail<DIAG, 2>(g, sh, lane, acc, qacc, nchunk, w);
+    else mid_tail<DIAG, 3>(g, sh, lane, acc, qacc, nchunk, w);
     MID_STAMP(2);
-    if (nchunk == 1) {
-        // the whole tile in one workgroup: wave 0's registers -> the finished tile in LDS
-        if (wave == 0) {
-#pragma unroll
-            for (int a = 0; a < MACC; ++a) {
-                if (!mid_used(DIAG, a)) continue;
-                int row, col;
-                mid_pos(lane, a, row, col);
-                sh[row * MPITCH + col] = acc[a];
-            }
-            if (DIAG && qlane) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) sh[MT * MPITCH + 16 * t + qcol] = qacc[t];
-            }
-        }
-    } else {
-        double *w = g.ws + (int64_t)(first_wg + chunk) * MSTRIDE;
-        if (wave == 0) {
-#pragma unroll
-            for (int a = 0; a < MACC; ++a) if (mid_used(DIAG, a)) mid_put(&w[a * 64 + lane], acc[a]);
-            if (DIAG && qlane) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) mid_put(&w[MPART + 16 * t + qcol], qacc[t]);
-            }
-            // the partial is visible device-wide before the tile's count goes up
-#if PMT_MID_FORMAL
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#else
-            __builtin_amdgcn_s_waitcnt(0);
-#endif
-            if (lane == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if (nchunk > 1) {
+        __syncthreads();                                           // every wave's quarter of the partial has left (mid_tail waits for its stores)
+        if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         MID_STAMP(3);
         if (PMT_MID_ABL == 3 || *flag != (unsigned)(nchunk - 1)) return;               // (workgroup-uniform) not the last one of this tile
@@ -403,17 +462,17 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
         if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-        // the chunks' partials in ascending order, LOADED four chunks at a time (64 loads in flight per thread: the sum is not a chain of
-        // round trips to the fabric); thread tid: the elements e = tid + 256 u of the [a][lane] layout
+        // the chunks' partials in ascending order, LOADED PMT_MID_FB chunks at a time (the sum is not a chain of round trips to the fabric)
         const double *p = g.ws + (int64_t)first_wg * MSTRIDE;
+        double qs = 0.0;
+        // thread tid: the elements e = tid + 256 u of the [a][lane] layout
         double sum[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) sum[u] = 0.0;
-        double qs = 0.0;
-        for (int c0 = 0; c0 < nchunk; c0 += 4) {
-            double v[4][16], qv[4];
+        for (int c0 = 0; c0 < nchunk; c0 += PMT_MID_FB) {
+            double v[PMT_MID_FB][16], qv[PMT_MID_FB];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
+            for (int cc = 0; cc < PMT_MID_FB; ++cc) {
                 const double *pc = p + (int64_t)min(c0 + cc, nchunk - 1) * MSTRIDE;      // (beyond the last chunk: a repeated load that is not added)
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
@@ -425,7 +484,7 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
                 if (DIAG && tid < MT) qv[cc] = mid_get(pc + MPART + tid);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
+            for (int cc = 0; cc < PMT_MID_FB; ++cc) {
                 const bool live = c0 + cc < nchunk;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) { const double t = sum[u] + v[cc][u]; sum[u] = live ? t : sum[u]; }
@@ -433,7 +492,7 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
                 qs = live ? t : qs;
             }
         }
-        __syncthreads();                                           // (the tile overwrites the reduction slots)
+        __syncthreads();                                           // (the tile overwrites the exchange pieces)
         MID_STAMP(4);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -448,8 +507,10 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
     __syncthreads();
     MID_STAMP(5);
     if (PMT_MID_ABL != 4) mid_epilogue(g, sh, tid, jb, kb);
+#ifdef PMT_MID_TRACE
     __builtin_amdgcn_s_waitcnt(0);
     MID_STAMP(6);
+#endif
 }
 
 template <bool FAST>
