@@ -42,7 +42,7 @@ int launch_to_host_2d(const void *src, size_t src_pitch, void *dst_dev, size_t d
 void *host_device_pointer(void *host);
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0, const SKLin *lin = nullptr);
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict = 0);
 bool gram_tall_applies(int64_t rows, int64_t cols);
 bool gram_tiny(int64_t rows, int64_t cols);
 int launch_small_one(const SmallNode &nd, hipStream_t s);
@@ -135,15 +135,24 @@ static bool constant_chained(int64_t rows, int64_t cols) {
     return 0.07e-3 * (double)rows > 0.5 * contraction_ms;
 }
 
-// MID-SIZE wide shapes (129 .. 1024 columns, 32 .. 4096 rows, at most 2^21 elements): the sizes the reference is used at with a few hundred
-// variables.  Node us against the tall + strict form, same box (profiles/r06_gram_mid.txt): 300 x 300 35.7 -> 23.6, 100 x 1000 42.2 -> 29.9,
-// 1024 x 512 44.1 -> 33.1, 2048 x 512 47.6 -> 45.3, 4096 x 512 62.3 -> 54.8, 2048 x 1024 equal; beyond, the diagonal tiles' own kernel wins
-// (1024 x 2048 133 against 149, 128 x 2048 62 against 72) and one wave per column is too little for q (8192 x 256: 47 against 91).
+// WIDE shapes of up to 2048 columns that the one-launch form on 64 x 64 tiles takes (gram_mid.hip; round 6b): the sizes the reference is used
+// at with a few hundred variables, and most of what used to be the four launches tall + fix-up + strict stream-K + fix-up.  Same-box node
+// times in us, four launches -> one (profiles/r06_gram_mid.txt): 300 x 300 35.7 -> 19, 40 x 520 46 -> 10, 1024 x 512 44 -> 23, 4096 x 512
+// 62 -> 37.5, 4096 x 1024 128 -> 110, 8192 x 512 90 -> 59, 2048 x 1280 127 -> 81, 65536 x 512 411 -> 344, 65536 x 1024 1380 -> 1270,
+// 100000 x 129 188 -> 113.  Where it loses and the four launches stay: narrow panels of more than 256 MB (every 64-column panel is read
+// once per tile of its row and column: 524288 x 129 666 -> 809, 400000 x 160 557 -> 622, 262144 x 256 385 -> 403), more than 512 MB, and
+// beyond 1536 columns with more than 2048 rows (528 tiles: the rounds of 256 workgroups do not divide — 8192 x 2048 665 -> 692).
+#ifndef PMT_MID_MAXCOLS
+#define PMT_MID_MAXCOLS 2048
+#endif
 bool gram_mid_applies(int64_t rows, int64_t cols) {
 #ifdef PMT_NO_MID
     return false;
 #endif
-    return gram_tall_diag_applies(rows, cols) && cols <= 1024 && rows >= 32 && rows <= 4096 && rows * cols <= (int64_t)1 << 21;
+    if (!gram_tall_diag_applies(rows, cols) || cols > PMT_MID_MAXCOLS) return false;
+    if (cols > 1536) return rows <= 2048;
+    const int64_t el = rows * cols;
+    return el <= ((int64_t)1 << 25) || (cols >= 512 && el <= ((int64_t)1 << 26));
 }
 
 static int linear_splits(int64_t rows, int64_t cols) {
@@ -695,18 +704,12 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (side && !tall_form) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
             if (tall_form && gram_mid_applies(rows, cols)) {
-                // MID-SIZE wide shapes: every tile (diagonal ones included) in ONE stream-K launch with fine units, and one fix-up launch that
-                // also carries the affine part (gram_sk.hip: sk_lin_role) — two launches instead of four (tall + fix-up + strict stream-K + fix-up)
-                // round 6b: ONE launch on 64 x 64 tiles (gram_mid.hip) where the stream's counters are there; -DPMT_MID_SK keeps the two launches
-                const int64_t nt = cdiv(cols, GT);
-                const SKLin lin{(b && sign) ? b : nullptr, sign, reinterpret_cast<LT *>(out_lin), out_const};
-#ifndef PMT_MID_SK
-                if (side && side->counters && (size_t)gram_mid_counters(cols) * sizeof(unsigned) <= MID_COUNTER_BYTES)
-                    rc = launch_gram_mid(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace,
-                                         reinterpret_cast<unsigned *>(static_cast<char *>(side->counters) + MID_OFFSET), s);
-                else
-#endif
-                rc = launch_gram_sk(A, lda, rows, cols, xvar, varmap, moi, out_quad, out_csc, alpha, workspace, 0, 0, nt * (nt + 1) / 2, nullptr, 0, nullptr, s, 0, &lin);
+                // WIDE shapes of up to 2048 columns (gram_mid_applies): the whole node — every tile, q and c'c — in ONE launch on 64 x 64 tiles
+                // (gram_mid.hip); the per-tile arrival counts are this calling stream's
+                PMT_REQUIRE(side && side->counters && (size_t)gram_mid_counters(cols) * sizeof(unsigned) <= MID_COUNTER_BYTES, PMT_STATE_ERROR,
+                            "quad_gram: no auxiliary state for this stream");
+                rc = launch_gram_mid(A, lda, rows, cols, xvar, b, sign, moi, varmap, out_quad, out_csc, alpha, out_lin, out_const, workspace,
+                                     reinterpret_cast<unsigned *>(static_cast<char *>(side->counters) + MID_OFFSET), s);
                 if (!rc && side && side->in_replay) {          // side-lane entries behind this node may read its affine part (see below)
                     PMT_HIP_CHECK(hipEventRecord(side->fork, s));
                     PMT_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));

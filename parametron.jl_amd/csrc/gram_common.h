@@ -38,13 +38,7 @@ struct SKArgs {
     long long pair_timeout;                    // bound of the pair wait in 100 MHz ticks
     int strict;                                // ranged launches: the sequence enumerates the STRICTLY upper tiles (jb < kb) only — the diagonal
                                                // tiles of a wide tall matrix are computed by gram_tall.hip
-    // MID-SIZE wide shapes (gram.hip: gram_mid_applies): the node's affine part rides on the FIX-UP launch — `lin_blocks` extra workgroups
-    // (flat ids behind the `rsplit` split tiles' ones) compute q = 2 A'c (one wave per column) and c'c (the last of them) straight from A and b
-    const double *lin_b; int lin_sign; LT *out_lin; double *out_const; int lin_blocks; int rsplit;
 };
-
-// what launch_gram_sk needs to know about the affine part of a mid-size node (null: the node's caller computes it elsewhere)
-struct SKLin { const double *b; int sign; LT *out_lin; double *out_const; };
 
 // TN = 16-column MFMA tiles per wave along N (4: 64x64 wave tile, 4 waves; 2: 64x32 wave tile, 8 waves)
 template <int TN>

@@ -27,10 +27,16 @@
 #define PMT_MID_WPS 1              // waves per SIMD the register budget aims at
 #endif
 #ifndef PMT_MID_G
-#define PMT_MID_G 256              // workgroups the tiles' row chunks are chosen for (one per CU)
+#define PMT_MID_G 256              // workgroups per round (one per CU: 202 + 128 registers per lane)
+#endif
+#ifndef PMT_MID_MAXWG
+#define PMT_MID_MAXWG 2304         // workgroups at most (several rounds where the tiles alone are more than half of the CUs)
 #endif
 #ifndef PMT_MID_D
 #define PMT_MID_D 3                // iterations (8-row groups) in flight per wave (2: 40.3 us at 4096 x 512, 3: 37.9)
+#endif
+#ifndef PMT_MID_XCD
+#define PMT_MID_XCD 1              // 0: workgroup ids tile-major (id = tile * S + chunk) whatever the size
 #endif
 #ifndef PMT_MID_FB
 #define PMT_MID_FB 4               // chunks whose partials the last arriver loads together (64 loads per thread: a wave may have 63 outstanding; 8, or 16-byte loads: no faster)
@@ -87,11 +93,16 @@ struct MidArgs {
     int gpc_off, gpc_diag;                   // 8-row groups per chunk
     double *ws;                              // one MSTRIDE slot per workgroup
     unsigned *counters;                      // one per tile, zero between launches (the last arriver re-arms its tile's)
+    int xcd;                                 // workgroup ids in the XCD-aware order (gram_mid_kernel)
 };
 
 struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, wgs; };
 
-// row chunks per tile: as many as PMT_MID_G workgroups allow, a diagonal tile 5/8 of an off-diagonal one's, at least four groups per chunk
+// Row chunks per tile, from (rows, cols) alone (the summation order depends on them).  s chunks per off-diagonal tile and ceil(5 s / 8) per
+// diagonal one (88 against 128 MFMAs per 8-row group) make W workgroups that run one per CU in ceil(W / PMT_MID_G) rounds of
+// ceil(groups per chunk / 4) iterations of ~1.15 us each + ~5 us per workgroup (first loads, the waves' sums; + 1 for a partial); a
+// split tile's last arriver then reads s partials (~1.5 + 0.6 s us, measured 5.5 us at s = 7 .. 9: tools/mid_trace.py) — once in the
+// launch's tail and, summed over the tiles, as work of the CUs.  The s with the smallest estimate, at most PMT_MID_MAXWG workgroups (33 KB of workspace each).
 static MidPlan mid_plan(int64_t rows, int64_t cols) {
     MidPlan p;
     p.nb = (int)cdiv(cols, MT);
@@ -99,8 +110,18 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
     const int ngroups = (int)std::max<int64_t>(1, cdiv(rows, 8));
     const int maxs = std::max(1, ngroups / 4);
     auto sd = [&](int s) { return std::min(maxs, std::max(1, (5 * s + 7) / 8)); };
-    int s = 1;
-    while (s + 1 <= maxs && p.n_off * (s + 1) + p.nb * sd(s + 1) <= PMT_MID_G) ++s;
+    int best = 1;
+    double best_t = 1e300;
+    for (int s = 1; s <= std::min(maxs, 64); ++s) {
+        const int64_t wgs = (int64_t)p.n_off * s + (int64_t)p.nb * sd(s);
+        if (s > 1 && wgs > PMT_MID_MAXWG) break;
+        const double it_off = (double)cdiv(cdiv(ngroups, s), 4), it_diag = 0.69 * (double)cdiv(cdiv(ngroups, sd(s)), 4);
+        const double fold = s > 1 ? 1.5 + 0.6 * s : 0.0;
+        const double t = (double)cdiv(wgs, PMT_MID_G) * (1.15 * (p.n_off ? std::max(it_off, it_diag) : it_diag) + 5.0 + (s > 1 ? 1.0 : 0.0)) +
+                         fold * (1.0 + (double)(p.n_off + p.nb) / PMT_MID_G);
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    const int s = best;
     p.gpc_off = (int)cdiv(ngroups, s);
     p.s_off = (int)cdiv(ngroups, p.gpc_off);
     p.gpc_diag = (int)cdiv(ngroups, sd(s));
@@ -513,24 +534,42 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
 #endif
 }
 
+// position of workgroup `id` in the XCD-major order of the ids [base, base + n): the ids of XCD 0 (id % 8 == 0) first, in ascending order,
+// then XCD 1's, ..
+__device__ __forceinline__ int mid_xcd_rank(int id, int base, int n) {
+    const int x = id & 7, end = base + n;
+    int start = 0;
+    for (int y = 0; y < x; ++y) {
+        const int fy = base + ((y - base) & 7);                    // the first id of the range on XCD y
+        start += fy < end ? ((end - 1 - fy) >> 3) + 1 : 0;
+    }
+    return start + ((id - (base + ((x - base) & 7))) >> 3);
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
     __shared__ double sh[MSH];
     const int tid = threadIdx.x;
     int id = blockIdx.x;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own 4 MB L2.  The (chunk, tile) list is walked
+    // CHUNK-major and cut into 8 contiguous pieces, one per XCD: the 32 workgroups an XCD runs at a time work on the same rows of A and
+    // on neighbouring tiles (shared 64-column panels), so a matrix larger than one L2 is still read mostly out of L2 — numbered tile-major
+    // (id = tile * S + chunk) every XCD touched every row chunk of every panel and 4096 x 1024 ran out of the Infinity Cache at 1.76 us per
+    // 8-row group instead of 1.15 (profiles/r06_gram_mid.txt).
     const int noff = g.n_off * g.s_off;
     if (id < noff) {
-        int t = id / g.s_off;
-        const int chunk = id - t * g.s_off;
+        const int k = g.xcd ? mid_xcd_rank(id, 0, noff) : (id % g.s_off) * g.n_off + id / g.s_off;
+        const int chunk = k / g.n_off;
+        int t = k - chunk * g.n_off;
         const int tile = t;
         int kb = 1;
         while (t >= kb) { t -= kb; ++kb; }                         // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
         mid_body<false, FAST>(g, sh, tid, t, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile);
         return;
     }
-    id -= noff;
-    if (id < g.nb * g.s_diag) {
-        const int jb = id / g.s_diag, chunk = id - jb * g.s_diag;
+    if (id < noff + g.nb * g.s_diag) {
+        const int k = g.xcd ? mid_xcd_rank(id, noff, g.nb * g.s_diag) : ((id - noff) % g.s_diag) * g.nb + (id - noff) / g.s_diag;
+        const int chunk = k / g.nb, jb = k - chunk * g.nb;
         mid_body<true, FAST>(g, sh, tid, jb, jb, chunk, g.s_diag, g.gpc_diag, noff + jb * g.s_diag, g.counters + g.n_off + jb);
         return;
     }
@@ -556,6 +595,7 @@ int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, co
     g.out_lin = reinterpret_cast<LT *>(out_lin); g.out_const = out_const;
     g.nb = p.nb; g.n_off = p.n_off; g.s_off = p.s_off; g.s_diag = p.s_diag; g.gpc_off = p.gpc_off; g.gpc_diag = p.gpc_diag;
     g.ws = reinterpret_cast<double *>(workspace); g.counters = counters;
+    g.xcd = PMT_MID_XCD && rows * cols * 8 > ((int64_t)4 << 20);      // (a matrix that fits one L2 is all there on every XCD: 1024 x 512 23.0 against 25.6 us)
     const bool fast = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0 &&
                       (uint64_t)lda * (uint64_t)cols * 8 < (1ull << 32);
     if (fast) PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<true>), dim3((unsigned)p.wgs), dim3(256), 0, s, g);

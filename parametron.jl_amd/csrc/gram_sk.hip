@@ -631,59 +631,6 @@ __global__ __launch_bounds__(Cfg<TN>::NT, WPS) __attribute__((amdgpu_num_vgpr(10
 #ifndef PMT_SK_APB1_BELOW
 #define PMT_SK_APB1_BELOW 64       // fix-up: one accumulator per workgroup (NACC workgroups per tile) while tiles x NACC / 4 stays below this
 #endif
-#ifndef PMT_SK_MID_G
-#define PMT_SK_MID_G 256           // workgroups of a mid-size node's stream-K launch
-#endif
-// The affine part of a mid-size node inside the fix-up launch (SKArgs::lin_blocks workgroups of 512 threads, flat id L): workgroup L < the
-// last takes the columns 8 L .. 8 L + 7, one wave each — out_lin[j] = (2 sum_i c_i A[i, j], vm[xvar[j]]), c_i = 0.0 (+|-) b[i], lanes
-// striding the rows (coalesced), a shuffle tree at the end (gram.hip: gram_linear_kernel) —; the LAST one the constant c'c in the order
-// pmt_quad_gram_constant_order reports as 5: thread t of 512 adds rows t, t + 512, .. in order, a shuffle tree per wave (32, 16, .., 1),
-// the eight waves in order.  A is L2- / Infinity-Cache-hot: the contraction has just read it.
-__device__ __forceinline__ void sk_lin_role(const SKArgs &g, int L, int tid) {
-    const int wave = tid >> 6, lane = tid & 63;
-    if (L + 1 < g.lin_blocks) {
-        const int64_t col = (int64_t)L * 8 + wave;
-        if (col >= g.cols) return;
-        const double *a = g.A + col * g.lda;
-        double acc = 0.0;
-        if (g.lin_b && g.lin_sign) {
-            int64_t i = lane;
-            for (; i + 7 * 64 < g.rows; i += 8 * 64) {                       // eight loads of A and b in flight per lane; the additions keep their order
-                double av[8], bv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { av[u] = a[i + 64 * u]; bv[u] = g.lin_b[i + 64 * u]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += signed_const(bv[u], g.lin_sign) * av[u];
-            }
-            for (; i < g.rows; i += 64) acc += signed_const(g.lin_b[i], g.lin_sign) * a[i];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) {
-            LT t;
-            t.coeff = 2 * acc;
-            const int64_t v = g.xvar[col];
-            t.var = g.moi ? map_var(g.varmap, v) : v;
-            g.out_lin[col] = t;
-        }
-        return;
-    }
-    __shared__ double wsum[8];
-    double s = 0.0;
-    if (g.lin_b && g.lin_sign)
-        for (int64_t i = tid; i < g.rows; i += 512) { const double c = signed_const(g.lin_b[i], g.lin_sign); s = s + c * c; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s = s + __shfl_down(s, off, 64);
-    if (lane == 0) wsum[wave] = s;
-    __syncthreads();
-    if (tid == 0) {
-        double v = wsum[0];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) v = v + wsum[w];
-        *g.out_const = v;
-    }
-}
-
 // one workgroup per tile: if the tile was split, add its partials in ascending workgroup order and write the terms
 // APB = accumulators per thread handled by one workgroup: 4 normally; 1 when only a few tiles are split (tall matrices: one tile summed
 // over up to 256 partials) so that the sum is spread over NACC instead of NACC/4 workgroups per tile
@@ -693,11 +640,6 @@ __global__ __launch_bounds__(Cfg<TN>::NT) void gram_sk_fixup_kernel(SKArgs g) {
     const int rtile = blockIdx.x;                                              // index among the remainder (split) tiles
     const int tile = g.tfull * g.G + rtile;
     const int tid = threadIdx.x;
-    if (g.lin_blocks && rtile >= g.rsplit) {                                   // (mid-size nodes: the affine part's workgroups)
-        const int L = ((rtile - g.rsplit) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.z + (int)blockIdx.z;
-        if (L < g.lin_blocks) sk_lin_role(g, L, tid);
-        return;
-    }
     const int64_t ub = (int64_t)rtile * g.nchunk, ue = ub + g.nchunk - 1;      // first / last remainder unit of this tile
     auto owner = [&](int64_t u) {
         int b = (int)((u * g.G) / g.U);
@@ -763,11 +705,6 @@ __global__ __launch_bounds__(512) void gram_sk_fixup_sliced_kernel(SKArgs g) {
     __shared__ double part[NSL][64];
     const int rtile = blockIdx.x;
     const int tile = g.tfull * g.G + rtile;
-    if (g.lin_blocks && rtile >= g.rsplit) {                                   // (mid-size nodes: the affine part's workgroups)
-        const int L = ((rtile - g.rsplit) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.z + (int)blockIdx.z;
-        if (L < g.lin_blocks) sk_lin_role(g, L, (int)threadIdx.x);
-        return;
-    }
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = (int)blockIdx.z * 64 + el;                                  // the thread of the contraction whose accumulator this is
     const int r0 = (int)blockIdx.y;
@@ -828,9 +765,8 @@ static int env_int(const char *name, int dflt) {
 // anything but `epoch`): tiles split exactly in two are summed inside the launch (see the kernel) instead of by the fix-up pass.
 int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const int64_t *varmap, int moi,
                    pmt_quadratic_term *out_quad, double *out_csc, double alpha, void *workspace, int order_w, int64_t seq_begin, int64_t seq_count,
-                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict, const SKLin *lin) {
+                   unsigned *pair_flags, unsigned epoch, int *error_word, hipStream_t s, int strict) {
     SKArgs g;
-    g.lin_b = nullptr; g.lin_sign = 0; g.out_lin = nullptr; g.out_const = nullptr; g.lin_blocks = 0; g.rsplit = 0;
     g.strict = (strict && seq_count >= 0) ? 1 : 0;
     g.A = A; g.lda = lda; g.rows = rows; g.cols = cols; g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = out_quad;
     g.out_csc = out_csc; g.alpha = alpha;
@@ -842,12 +778,6 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
     g.skc = SKC;
     if (seq_count < 0 || g.strict)
         while (g.skc > 64 && T * cdiv(rows, g.skc) < 256) g.skc >>= 1;
-    // mid-size nodes (all tiles in one launch, the affine part on the fix-up launch): units down to 64 rows until there are two per CU
-    // (4096 x 512: 54 us against 63 with 256 units), and at least two chunks, so that every tile is split and the fix-up launch exists
-    if (lin) {
-        while (g.skc > 64 && T * cdiv(rows, g.skc) < 512) g.skc >>= 1;
-        while (g.skc > 16 && cdiv(rows, g.skc) < 2) g.skc >>= 1;
-    }
     g.nchunk = (int)std::max<int64_t>(1, cdiv(rows, g.skc));
     g.seq_begin = (int)seq_begin; g.seq_step = 1;
     if (order_w < 0) {                                // walked from the end: position p of the walk is tile T_all - 1 - p of the sequence
@@ -869,7 +799,7 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #else
     constexpr int variant = 1, gdef = 0;
 #endif
-    const int gwant = gdef > 0 ? gdef : (lin ? PMT_SK_MID_G : (variant == 0 ? 512 : 256));
+    const int gwant = gdef > 0 ? gdef : (variant == 0 ? 512 : 256);
     g.G = (int)std::min<int64_t>(T * g.nchunk, std::min(gwant, MAXG));
     // strict launches of tall matrices (few tiles, each split over many workgroups): a grid that is a MULTIPLE of the tile count gives every
     // tile the same row ranges, so that the workgroups of different tiles that share a column panel read the same rows of it at the same
@@ -916,13 +846,6 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
 #endif
     int rc = check_launch("gram_sk_kernel");
     if (rc) return rc;
-    if (lin) {
-        if (!(g.nchunk > 1 && g.tfull == 0 && R == T)) return fail(PMT_STATE_ERROR, "quad_gram: a mid-size node needs every tile split (internal)");
-        g.lin_b = lin->b; g.lin_sign = lin->b ? lin->sign : 0; g.out_lin = lin->out_lin; g.out_const = lin->out_const;
-        g.lin_blocks = (int)cdiv(cols, 8) + 1; g.rsplit = (int)R;
-    }
-    // extra x-slices of the fix-up grid that hold the affine part's workgroups (gy x gz workgroups per slice)
-    auto lin_slices = [&](int64_t gy, int64_t gz) { return (unsigned)(g.lin_blocks ? cdiv(g.lin_blocks, gy * gz) : 0); };
     if (g.nchunk > 1 && R > 0 && !fold) {
         // The split tiles are summed by a second launch.  (Round 3 measured the alternative — the workgroup that arrives last at a split tile
         // adds its partials inside the contraction: +55 us at n = r = 4096, one CU pulling 2 MB of partials, against 15 us of fix-up kernel
@@ -933,9 +856,9 @@ int launch_gram_sk(const double *A, int64_t lda, int64_t rows, int64_t cols, con
         constexpr int apb = 0;
 #endif
         // (tiles split more than 32 ways each — few tiles, many rows: the sliced form)
-        if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_sliced_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC, Cfg<2>::NT / 64), Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
-        else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < PMT_SK_APB1_BELOW)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC, 1), Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
-        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R + lin_slices(Cfg<2>::NACC / 4, 1), Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
+        if (apb == 0 && (int64_t)g.G >= 32 * R) PMT_LAUNCH_NAMED("gram_sk_fixup_sliced_kernel", (gram_sk_fixup_sliced_kernel<2>), dim3((unsigned)R, Cfg<2>::NACC, Cfg<2>::NT / 64), dim3(512), 0, s, g);
+        else if (apb == 1 || (apb == 0 && R * (Cfg<2>::NACC / 4) < PMT_SK_APB1_BELOW)) PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 1>), dim3((unsigned)R, Cfg<2>::NACC), dim3(Cfg<2>::NT), 0, s, g);
+        else PMT_LAUNCH_NAMED("gram_sk_fixup_kernel", (gram_sk_fixup_kernel<2, 4>), dim3((unsigned)R, Cfg<2>::NACC / 4), dim3(Cfg<2>::NT), 0, s, g);
         rc = check_launch("gram_sk_fixup_kernel");
     }
     return rc;

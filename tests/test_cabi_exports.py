@@ -266,13 +266,14 @@ def test_constant_order_is_host_arithmetic(lib):
     assert order(16384, 17)[0] == 2 and order(32768, 17) == (4, 256, 32) and order(77777, 50) == (4, 512, 16) and order(33001, 9)[0] == 4
     assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
     assert order(1 << 20, 48) == (4, 512, 32) and order(40000, 40) == (4, 313, 32) and order(20000, 40)[0] == 2      # 33 .. 48 columns: three column groups (stream form only)
-    # .. or several: the diagonal tiles take the tall kernel, tile 0's workgroups the constant
-    assert order(16384, 1024)[0] == 2 and order(131072, 256)[0] == 2 and order(17, 130)[0] == 2 and order(31, 300)[0] == 2
-    assert order(8192, 1024)[0] == 2 and order(65536, 2048) == (2, 64, 32) and order(4090, 1000)[0] == 2
-    # mid-size wide shapes (129 .. 1024 columns, 32 .. 4096 rows, <= 2^21 elements): one stream-K launch over all tiles, the constant by the last
-    # workgroup of the fix-up launch (order 5: 512 strided chains)
-    assert order(300, 300) == (5, 1, 512) and order(4096, 512) == (5, 1, 512) and order(1024, 2048)[0] == 2 and order(100, 1000)[0] == 5 and order(8192, 256)[0] == 2
-    assert order(4096, 256)[0] == 5 and order(70, 130)[0] == 5 and order(4097, 512)[0] == 2
+    # .. or several.  Most of them take the one-launch form on 64 x 64 tiles (gram_mid.hip; the constant by one more workgroup of that launch, order 5:
+    # 512 strided chains): up to 1536 columns and 256 MB (512 MB from 512 columns), up to 2048 columns with at most 2048 rows
+    assert order(300, 300) == (5, 1, 512) and order(4096, 512) == (5, 1, 512) and order(100, 1000)[0] == 5 and order(8192, 256)[0] == 5
+    assert order(4096, 256)[0] == 5 and order(70, 130)[0] == 5 and order(4097, 512)[0] == 5 and order(17, 130)[0] == 5 and order(31, 300)[0] == 5
+    assert order(16384, 1024)[0] == 5 and order(131072, 256)[0] == 5 and order(65536, 1024)[0] == 5 and order(1024, 2048)[0] == 5 and order(2048, 1537)[0] == 5
+    # .. the rest the diagonal tiles' kernel + the strict stream-K launch (tile 0's workgroups the constant, order 2)
+    assert order(262144, 256)[0] == 2 and order(524288, 129)[0] == 2 and order(262144, 512)[0] == 2 and order(65536, 2048) == (2, 64, 32)
+    assert order(2049, 1537)[0] == 2 and order(8192, 2048)[0] == 2 and order(1 << 20, 192)[0] == 2
     with pytest.raises(lib.ArgumentError):
         lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
 
