@@ -141,7 +141,8 @@ static bool constant_chained(int64_t rows, int64_t cols) {
 // 62 -> 37.5, 4096 x 1024 128 -> 110, 8192 x 512 90 -> 59, 2048 x 1280 127 -> 81, 65536 x 512 411 -> 344, 65536 x 1024 1380 -> 1270,
 // 100000 x 129 188 -> 113.  Where it loses and the four launches stay: narrow panels of more than 256 MB (every 64-column panel is read
 // once per tile of its row and column: 524288 x 129 666 -> 809, 400000 x 160 557 -> 622, 262144 x 256 385 -> 403), more than 512 MB, and
-// beyond 1536 columns with more than 2048 rows (528 tiles: the rounds of 256 workgroups do not divide — 8192 x 2048 665 -> 692).
+// beyond 1536 columns with more than 2048 rows (528 tiles: the rounds of 256 workgroups do not divide — 8192 x 2048 665 -> 692).  Up to 128
+// columns the one-tile kernel of gram_tall.hip stays (three 64 x 64 tiles split 80 ways fold too much: 8192 x 128 18 -> 40 us).
 #ifndef PMT_MID_MAXCOLS
 #define PMT_MID_MAXCOLS 2048
 #endif
@@ -191,7 +192,7 @@ constexpr size_t PROGRESS_OFFSET = 0;
 constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
 constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
 constexpr size_t MID_OFFSET = DONE_OFFSET + 2 * sizeof(unsigned);                  // per-tile arrival counts of the one-launch mid-size node (gram_mid.hip)
-constexpr size_t MID_COUNTER_BYTES = 4096;
+constexpr size_t MID_COUNTER_BYTES = 36864;          // 16 words per tile, 528 tiles at 2048 columns
 constexpr size_t COUNTER_BYTES = MID_OFFSET + MID_COUNTER_BYTES;
 static std::mutex g_side_mu;
 static std::unordered_map<hipStream_t, SideStream> g_side;

@@ -78,6 +78,8 @@ constexpr int MACC = 64;                     // accumulators per lane: (block ro
 constexpr int MPART = MACC * 64;             // doubles of a tile partial, [a][lane]
 constexpr int MSTRIDE = MPART + MT + 8;      // + q partial (diagonal tiles), padded to 64 bytes
 constexpr int MPITCH = MT + 1;
+constexpr int MFG = 8;                       // chunks per group of a two-level fold (mid_body)
+constexpr int MCNT = 16;                     // counter words per tile: [0] the tile's, [1 + group] the groups' (at most 64 chunks)
 constexpr int MQBUF = 4 * 2048;              // LDS (doubles): [0, 8192) rotation pieces / the waves' exchange pieces / the finished tile + q + row descriptors;
 constexpr int MFLAG = MQBUF + 4 * MT;        // the waves' q (4 x 64); the count's old value; the tile's variable maps (2 x 64)
 constexpr int MMAPS = MFLAG + 8;
@@ -116,7 +118,7 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
         const int64_t wgs = (int64_t)p.n_off * s + (int64_t)p.nb * sd(s);
         if (s > 1 && wgs > PMT_MID_MAXWG) break;
         const double it_off = (double)cdiv(cdiv(ngroups, s), 4), it_diag = 0.69 * (double)cdiv(cdiv(ngroups, sd(s)), 4);
-        const double fold = s > 1 ? 1.5 + 0.6 * s : 0.0;
+        const double fold = s <= 1 ? 0.0 : s <= MFG ? 1.5 + 0.6 * s : (1.5 + 0.6 * MFG) + 1.5 + (1.5 + 0.6 * (double)cdiv(s, MFG));
         const double t = (double)cdiv(wgs, PMT_MID_G) * (1.15 * (p.n_off ? std::max(it_off, it_diag) : it_diag) + 5.0 + (s > 1 ? 1.0 : 0.0)) +
                          fold * (1.0 + (double)(p.n_off + p.nb) / PMT_MID_G);
         if (t < best_t) { best_t = t; best = s; }
@@ -422,6 +424,38 @@ __device__ __forceinline__ void mid_tail(const MidArgs &g, double *sh, int lane,
 #endif
 }
 
+// sum (in ascending order) of `count` partials `stride` doubles apart, LOADED PMT_MID_FB at a time (the sum is not a chain of round trips to
+// the fabric); thread tid: the elements e = tid + 256 u of the [a][lane] layout, and q of column tid of a diagonal tile
+template <bool DIAG>
+__device__ __forceinline__ void mid_fold(const double *p, int count, int64_t stride, int tid, double (&sum)[16], double &qs) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) sum[u] = 0.0;
+    qs = 0.0;
+    for (int c0 = 0; c0 < count; c0 += PMT_MID_FB) {
+        double v[PMT_MID_FB][16], qv[PMT_MID_FB];
+#pragma unroll
+        for (int cc = 0; cc < PMT_MID_FB; ++cc) {
+            const double *pc = p + (int64_t)min(c0 + cc, count - 1) * stride;          // (beyond the last one: a repeated load that is not added)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int a = (tid >> 6) + 4 * u;
+                v[cc][u] = 0.0;
+                if (mid_used(DIAG, a)) v[cc][u] = mid_get(pc + tid + 256 * u);
+            }
+            qv[cc] = 0.0;
+            if (DIAG && tid < MT) qv[cc] = mid_get(pc + MPART + tid);
+        }
+#pragma unroll
+        for (int cc = 0; cc < PMT_MID_FB; ++cc) {
+            const bool live = c0 + cc < count;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const double t = sum[u] + v[cc][u]; sum[u] = live ? t : sum[u]; }
+            const double t = qs + qv[cc];
+            qs = live ? t : qs;
+        }
+    }
+}
+
 template <bool DIAG, bool FAST>
 __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, int jb, int kb, int chunk, int nchunk, int gpc, int first_wg, unsigned *counter) {
     constexpr int NG = DIAG ? 4 : 8;
@@ -474,44 +508,45 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
     else mid_tail<DIAG, 3>(g, sh, lane, acc, qacc, nchunk, w);
     MID_STAMP(2);
     if (nchunk > 1) {
+        // One level up to MFG chunks: the tile's last arriver adds them all.  Beyond (few tiles, tall: 65536 x 256 is 10 tiles of 29 chunks —
+        // one CU reading 29 x 32 KB took 20 us of the node's 113), two levels: the last arriver of every GROUP of MFG consecutive chunks adds
+        // its group and publishes the sum in the slot of the group's first chunk, the last of THOSE adds the groups' sums.  The order stays
+        // fixed: chunks in order within a group, groups in order.
+        const bool two = nchunk > MFG;
+        const int gfirst = two ? (chunk / MFG) * MFG : 0;
+        const int n1 = two ? min(MFG, nchunk - gfirst) : nchunk;
+        unsigned *c1 = two ? counter + 1 + chunk / MFG : counter;
         __syncthreads();                                           // every wave's quarter of the partial has left (mid_tail waits for its stores)
-        if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         MID_STAMP(3);
-        if (PMT_MID_ABL == 3 || *flag != (unsigned)(nchunk - 1)) return;               // (workgroup-uniform) not the last one of this tile
+        if (PMT_MID_ABL == 3 || *flag != (unsigned)(n1 - 1)) return;                   // (workgroup-uniform) not the last one of this tile / group
 #if PMT_MID_FORMAL
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
-        if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-        // the chunks' partials in ascending order, LOADED PMT_MID_FB chunks at a time (the sum is not a chain of round trips to the fabric)
-        const double *p = g.ws + (int64_t)first_wg * MSTRIDE;
-        double qs = 0.0;
-        // thread tid: the elements e = tid + 256 u of the [a][lane] layout
-        double sum[16];
+        if (tid == 0) __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-armed for the next launch
+        double sum[16], qs;
+        double *p = g.ws + (int64_t)(first_wg + gfirst) * MSTRIDE;
+        mid_fold<DIAG>(p, n1, MSTRIDE, tid, sum, qs);
+        if (two) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sum[u] = 0.0;
-        for (int c0 = 0; c0 < nchunk; c0 += PMT_MID_FB) {
-            double v[PMT_MID_FB][16], qv[PMT_MID_FB];
-#pragma unroll
-            for (int cc = 0; cc < PMT_MID_FB; ++cc) {
-                const double *pc = p + (int64_t)min(c0 + cc, nchunk - 1) * MSTRIDE;      // (beyond the last chunk: a repeated load that is not added)
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int a = (tid >> 6) + 4 * u;
-                    v[cc][u] = 0.0;
-                    if (mid_used(DIAG, a)) v[cc][u] = mid_get(pc + tid + 256 * u);
-                }
-                qv[cc] = 0.0;
-                if (DIAG && tid < MT) qv[cc] = mid_get(pc + MPART + tid);
-            }
-#pragma unroll
-            for (int cc = 0; cc < PMT_MID_FB; ++cc) {
-                const bool live = c0 + cc < nchunk;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) { const double t = sum[u] + v[cc][u]; sum[u] = live ? t : sum[u]; }
-                const double t = qs + qv[cc];
-                qs = live ? t : qs;
-            }
+            for (int u = 0; u < 16; ++u) if (mid_used(DIAG, (tid >> 6) + 4 * u)) mid_put(p + tid + 256 * u, sum[u]);
+            if (DIAG && tid < MT) mid_put(p + MPART + tid, qs);
+#if PMT_MID_FORMAL
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            __syncthreads();                                       // (also: everyone has read the first count's old value)
+            if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int ng = (nchunk + MFG - 1) / MFG;
+            if (*flag != (unsigned)(ng - 1)) return;
+#if PMT_MID_FORMAL
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+            if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mid_fold<DIAG>(g.ws + (int64_t)first_wg * MSTRIDE, ng, (int64_t)MFG * MSTRIDE, tid, sum, qs);
         }
         __syncthreads();                                           // (the tile overwrites the exchange pieces)
         MID_STAMP(4);
@@ -564,13 +599,13 @@ __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
         const int tile = t;
         int kb = 1;
         while (t >= kb) { t -= kb; ++kb; }                         // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
-        mid_body<false, FAST>(g, sh, tid, t, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile);
+        mid_body<false, FAST>(g, sh, tid, t, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile * MCNT);
         return;
     }
     if (id < noff + g.nb * g.s_diag) {
         const int k = g.xcd ? mid_xcd_rank(id, noff, g.nb * g.s_diag) : ((id - noff) % g.s_diag) * g.nb + (id - noff) / g.s_diag;
         const int chunk = k / g.nb, jb = k - chunk * g.nb;
-        mid_body<true, FAST>(g, sh, tid, jb, jb, chunk, g.s_diag, g.gpc_diag, noff + jb * g.s_diag, g.counters + g.n_off + jb);
+        mid_body<true, FAST>(g, sh, tid, jb, jb, chunk, g.s_diag, g.gpc_diag, noff + jb * g.s_diag, g.counters + (g.n_off + jb) * MCNT);
         return;
     }
     mid_constant(g, sh, tid);
@@ -581,7 +616,7 @@ size_t gram_mid_workspace_bytes(int64_t rows, int64_t cols) {
     const MidPlan p = mid_plan(rows, cols);
     return sizeof(double) * (size_t)p.wgs * MSTRIDE;
 }
-int gram_mid_counters(int64_t cols) { const int nb = (int)cdiv(cols, MT); return nb * (nb + 1) / 2; }
+int gram_mid_counters(int64_t cols) { const int nb = (int)cdiv(cols, MT); return MCNT * (nb * (nb + 1) / 2); }
 
 // the whole node in one launch; `counters`: gram_mid_counters(cols) zeroed words owned by the calling stream (gram.hip: SideStream)
 int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,

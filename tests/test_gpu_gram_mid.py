@@ -27,7 +27,7 @@ SHAPES = [
     (300, 300, 0, 0), (517, 391, 0, 1), (1024, 512, 0, 0), (1027, 515, 3, 0),                # split tiles, one round; ragged rows / columns
     (4096, 512, 0, 0), (4099, 448, 0, 0), (5000, 129, 1, 0),                               # the masked last 8-row group beside unmasked ones
     (2048, 1024, 0, 0), (4096, 1024, 0, 0), (2048, 1536, 0, 0), (1000, 2048, 2, 0),         # several rounds of workgroups; > 4 MB: XCD-aware order
-    (128, 2048, 0, 0), (20000, 200, 0, 0), (8192, 512, 0, 1),
+    (128, 2048, 0, 0), (20000, 200, 0, 0), (8192, 512, 0, 1), (65536, 256, 0, 0), (30001, 130, 1, 0),          # many chunks per tile: the two-level fold
 ]
 
 
@@ -38,14 +38,14 @@ def test_one_launch_wide_node_against_numpy_on_every_load_path(rows, n, pad, shi
     _check_gram_node(rows, n, rows + pad, shift, np.random.default_rng(rows * 13 + n))
 
 
-def _node(g, dA, lda, rows, n, xvar, db, sign, ws, stream):
+def _node(g, dA, lda, rows, n, xvar, db, sign, ws, stream, out=None):
     nq = n * (n + 1) // 2
-    oq, ol, oc = g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)
+    oq, ol, oc = out or (g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1))
     g.call("pmt_quad_gram_f64", g.ptr(dA), lda, rows, n, g.ptr(xvar), g.ptr(db), sign, 1, None, g.ptr(oq), g.ptr(ol), g.ptr(oc), g.ptr(ws), stream)
     return oq, ol, oc
 
 
-@pytest.mark.parametrize("rows,n", [(300, 300), (4096, 512), (4096, 1024)])
+@pytest.mark.parametrize("rows,n", [(300, 300), (4096, 512), (4096, 1024), (20000, 200)])      # (the last: groups of 8 chunks folded first, then the groups)
 def test_repeated_launches_give_the_same_bits(rows, n):
     """the sums of a split tile are added in chunk order by whichever workgroup arrives last, and that workgroup re-arms the tile's count:
     thirty launches in a row, every one bit-identical to the first"""
@@ -83,11 +83,13 @@ def test_two_streams_run_the_node_at_once_without_sharing_counts():
         alone.append((g.terms_to_host(oq, nq, g.QT).tobytes(), g.terms_to_host(ol, n, g.LT).tobytes(), g.f64_to_host(oc, 1).tobytes()))
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs = [[], []]
-    for _ in range(12):
+    # (the poisoned output buffers are filled on torch's current stream: all of them exist, and the fills are done, before the two streams start)
+    outs = [[(g.empty_terms(nq, g.QT), g.empty_terms(n, g.LT), g.empty_f64(1)) for _ in range(12)] for k in range(2)]
+    torch.cuda.synchronize()
+    for i in range(12):
         for k in range(2):
             dA, db, xvar, ws = data[k]
-            outs[k].append(_node(g, dA, rows, rows, n, xvar, db, -1, ws, C.c_void_p(streams[k].cuda_stream)))
+            _node(g, dA, rows, rows, n, xvar, db, -1, ws, C.c_void_p(streams[k].cuda_stream), outs[k][i])
     torch.cuda.synchronize()
     for k in range(2):
         for oq, ol, oc in outs[k]:

@@ -21,7 +21,7 @@ pmc() {  # pmc <name> <cmd...>
   done
 }
 pmc c2_step python bench.py --steps 5 --warmup 1 --timed-loop-only
-for shape in 1048576x16 1048576x32 1048576x64 1048576x128 262144x512 65536x1024 4096x512 300x300; do pmc gram_$shape python tools/shape_once.py $shape 5; done
+for shape in 1048576x16 1048576x32 1048576x64 1048576x128 262144x512 65536x1024 4096x512 300x300 8192x512 4096x1024 65536x512; do pmc gram_$shape python tools/shape_once.py $shape 5; done
 pmc c4_batch python bench.py --workload batch --steps 5 --warmup 2
 pmc c5_sparse python tools/c5_once.py 5
 python - "$OUT" <<'PY'
