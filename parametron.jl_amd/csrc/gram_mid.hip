@@ -103,8 +103,11 @@ struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, wgs; };
 // Row chunks per tile, from (rows, cols) alone (the summation order depends on them).  s chunks per off-diagonal tile and ceil(5 s / 8) per
 // diagonal one (88 against 128 MFMAs per 8-row group) make W workgroups that run one per CU in ceil(W / PMT_MID_G) rounds of
 // ceil(groups per chunk / 4) iterations of ~1.15 us each + ~5 us per workgroup (first loads, the waves' sums; + 1 for a partial); a
-// split tile's last arriver then reads s partials (~1.5 + 0.6 s us, measured 5.5 us at s = 7 .. 9: tools/mid_trace.py) — once in the
+// split tile's last arriver then reads s partials (mid_fold_us: 5.5 us measured at s = 7 .. 9, tools/mid_trace.py) — once in the
 // launch's tail and, summed over the tiles, as work of the CUs.  The s with the smallest estimate, at most PMT_MID_MAXWG workgroups (33 KB of workspace each).
+// what adding `count` partials costs the last arriver: one round of loads per PMT_MID_FB partials (~2.6 us each, tools/mid_trace.py)
+static double mid_fold_us(int count) { return 0.5 + 2.6 * (double)cdiv(count, PMT_MID_FB); }
+
 static MidPlan mid_plan(int64_t rows, int64_t cols) {
     MidPlan p;
     p.nb = (int)cdiv(cols, MT);
@@ -118,7 +121,7 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
         const int64_t wgs = (int64_t)p.n_off * s + (int64_t)p.nb * sd(s);
         if (s > 1 && wgs > PMT_MID_MAXWG) break;
         const double it_off = (double)cdiv(cdiv(ngroups, s), 4), it_diag = 0.69 * (double)cdiv(cdiv(ngroups, sd(s)), 4);
-        const double fold = s <= 1 ? 0.0 : s <= MFG ? 1.5 + 0.6 * s : (1.5 + 0.6 * MFG) + 1.5 + (1.5 + 0.6 * (double)cdiv(s, MFG));
+        const double fold = s <= 1 ? 0.0 : s <= MFG ? mid_fold_us(s) : mid_fold_us(MFG) + 1.5 + mid_fold_us((int)cdiv(s, MFG));
         const double t = (double)cdiv(wgs, PMT_MID_G) * (1.15 * (p.n_off ? std::max(it_off, it_diag) : it_diag) + 5.0 + (s > 1 ? 1.0 : 0.0)) +
                          fold * (1.0 + (double)(p.n_off + p.nb) / PMT_MID_G);
         if (t < best_t) { best_t = t; best = s; }
