@@ -33,7 +33,10 @@
 #define PMT_MID_MAXWG 2304         // workgroups at most (several rounds where the tiles alone are more than half of the CUs)
 #endif
 #ifndef PMT_MID_D
-#define PMT_MID_D 3                // iterations (8-row groups) in flight per wave (2: 40.3 us at 4096 x 512, 3: 37.9)
+#define PMT_MID_D 2                // iterations (8-row groups) in flight per wave (pinned stream, PMT_MID_SCHED 2: 2 33.6 us at 4096 x 512, 3 34.0, 4 35.4; 4096 x 1024 97.7 / 100.3 / 103.7 — with mid_compute + mid_load it was 3)
+#endif
+#ifndef PMT_MID_GROUP_US
+#define PMT_MID_GROUP_US 1.15      // the cost model's time of one 8-row group per wave (mid_plan)
 #endif
 #ifndef PMT_MID_XCD
 #define PMT_MID_XCD 1              // 0: workgroup ids tile-major (id = tile * S + chunk) whatever the size
@@ -42,7 +45,7 @@
 #define PMT_MID_FB 4               // chunks whose partials the last arriver loads together (64 loads per thread: a wave may have 63 outstanding; 8, or 16-byte loads: no faster)
 #endif
 #ifndef PMT_MID_SCHED
-#define PMT_MID_SCHED 1            // scheduling barriers between the phases of an 8-row group (mid_compute)
+#define PMT_MID_SCHED 2            // 2: an 8-row group and the loads of the group D further on as one pinned instruction stream (mid_step); 1: mid_compute + mid_load with scheduling barriers between the phases (37.3 -> 34.3 us at 4096 x 512, 1250 -> 1189 at 65536 x 1024)
 #endif
 #ifndef PMT_MID_ABL
 #define PMT_MID_ABL 0              // ablations (wrong results): 1 no MFMAs, 2 no loads after the first D groups, 3 no fold of the partials, 4 no epilogue
@@ -122,7 +125,7 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
         if (s > 1 && wgs > PMT_MID_MAXWG) break;
         const double it_off = (double)cdiv(cdiv(ngroups, s), 4), it_diag = 0.69 * (double)cdiv(cdiv(ngroups, sd(s)), 4);
         const double fold = s <= 1 ? 0.0 : s <= MFG ? mid_fold_us(s) : mid_fold_us(MFG) + 1.5 + mid_fold_us((int)cdiv(s, MFG));
-        const double t = (double)cdiv(wgs, PMT_MID_G) * (1.15 * (p.n_off ? std::max(it_off, it_diag) : it_diag) + 5.0 + (s > 1 ? 1.0 : 0.0)) +
+        const double t = (double)cdiv(wgs, PMT_MID_G) * (PMT_MID_GROUP_US * (p.n_off ? std::max(it_off, it_diag) : it_diag) + 5.0 + (s > 1 ? 1.0 : 0.0)) +
                          fold * (1.0 + (double)(p.n_off + p.nb) / PMT_MID_G);
         if (t < best_t) { best_t = t; best = s; }
     }
@@ -240,6 +243,83 @@ __device__ __forceinline__ void mid_compute(double *__restrict__ rot, const f64x
         for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].x, c0, qacc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].y, c1, qacc[t], 0, 0, 0);
+    }
+}
+
+// One 8-row group AND the loads of the group D further on, as ONE pinned instruction stream (PMT_MID_SCHED 2, the FAST load path).  The
+// workgroup has one wave per SIMD: whatever is not an MFMA stands in the wave's only issue stream.  mid_compute + mid_load put the 16 LDS
+// operations of a group in one run in front of the MFMAs and its 8 loads (with a 64-bit vector add each: the compiler hoists the zero
+// extension of the lane offsets out of the loop and loses the scalar-base form) in runs behind them: ~18.5 clocks per MFMA against 16.6 for
+// bare MFMAs.  Here every LDS operation and every load stands alone behind an MFMA (the matrix pipe is busy for 16 clocks after an issue):
+//   * the 32 (20 + 8 of q on a diagonal tile) MFMAs that need no rotation first, one LDS operation behind each of the first 16;
+//   * the rotated MFMAs block ROW by block row: an A operand's registers are free after its row — its reload is issued there, the B
+//     operands' reloads (free after the first phase) behind the first MFMAs of the second;
+//   * loads in the scalar-base form (the lane offset passes through an empty asm: nothing to hoist).
+// Every accumulator sees the same operations in the same order as in mid_compute (x before y of each group): the same bits.
+#define MID_SB() __builtin_amdgcn_sched_barrier(0)
+template <bool DIAG>
+__device__ __forceinline__ void mid_step(const MidArgs &g, double *__restrict__ rot, int64_t next_row0, unsigned (&voff)[DIAG ? 4 : 8],
+                                         f64x2 (&buf)[DIAG ? 4 : 8], f64x2 &cb, int sign, int lane, double (&acc)[MACC], double (&qacc)[4]) {
+    constexpr int BO = DIAG ? 0 : 4;
+    const int lm = lane & 15, lrow = lane & 48, lk = lane >> 4;
+    const char *base = reinterpret_cast<const char *>(g.A + next_row0);
+    auto reload = [&](int t) {
+        asm volatile("" : "+v"(voff[t]));
+        buf[t] = *reinterpret_cast<const f64x2 *>(base + voff[t]);
+    };
+    f64x2 bv[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bv[c][0] = buf[BO + c];
+    auto lds_op = [&](int i) {                       // 0..3: the B groups out; 4..15: the rotated reads
+        if (i < 4) *reinterpret_cast<f64x2 *>(rot + (i * 64 + lane) * 2) = buf[BO + i];
+        else {
+            const int c = (i - 4) / 3, r = 1 + (i - 4) % 3;
+            bv[c][r] = *reinterpret_cast<const f64x2 *>(rot + (c * 64 + lrow + ((lm + 4 * r) & 15)) * 2);
+        }
+    };
+    MID_SB();
+    // phase 0: rotation 0 (operands as loaded), x then y; an LDS operation behind each of the first 16
+    int k = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int tm = 0; tm < (DIAG ? c + 1 : 4); ++tm) {
+                const int a = (tm * 4 + c) * 4;
+                acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(pass ? buf[tm].y : buf[tm].x, pass ? bv[c][0].y : bv[c][0].x, acc[a], 0, 0, 0);
+                if (k < 16) { MID_SB(); lds_op(k); MID_SB(); }
+                ++k;
+            }
+    if (DIAG) {
+        // q = A'c on the matrix pipe (mid_compute)
+        const double c0 = signed_const(cb.x, sign), c1 = signed_const(cb.y, sign);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].x, c0, qacc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t].y, c1, qacc[t], 0, 0, 0);
+        MID_SB();
+        // (no b: sign is 0 and signed_const ignores what is loaded — any valid address keeps the block free of branches)
+        cb = *reinterpret_cast<const f64x2 *>((g.b ? g.b : g.A) + next_row0 + 2 * lk);
+    }
+    MID_SB();
+    // phase 1: the rotated blocks, block row by block row
+    int nb = 0;                                      // B reloads issued (off-diagonal tiles: buf[4..7])
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int c = (DIAG ? tm : 0); c < 4; ++c)
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    const int a = (tm * 4 + c) * 4 + r;
+                    acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(pass ? buf[tm].y : buf[tm].x, pass ? bv[c][r].y : bv[c][r].x, acc[a], 0, 0, 0);
+                    if (!DIAG && nb < 4) { MID_SB(); reload(4 + nb); MID_SB(); ++nb; }
+                }
+        MID_SB();
+        reload(tm);
+        MID_SB();
     }
 }
 
@@ -488,11 +568,24 @@ __device__ __forceinline__ void mid_body(const MidArgs &g, double *sh, int tid, 
     if (nfast > 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) mid_load<DIAG, FAST>(g, row_of(d), lane, cj0, ck0, voff, buf[d], cb[d]);
-        for (int s0 = 0; s0 < nfast; s0 += D) {
+        if (PMT_MID_SCHED == 2 && FAST && PMT_MID_ABL == 0) {
+            // whole rounds of D groups as one branch-free block (a branch inside it and the compiler's vmcnt waits fall back to "all
+            // loads": the number of loads in flight must not depend on the path); the loads beyond the last group repeat the last group
+            int s0 = 0;
+            for (; s0 + D <= nfast; s0 += D) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
+                for (int d = 0; d < D; ++d) mid_step<DIAG>(g, rot, row_of(s0 + d + D), voff, buf[d], cb[d], g.sign, lane, acc, qacc);
+            }
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d)
                 if (s0 + d < nfast) mid_compute<DIAG>(rot, buf[d], cb[d], g.sign, lane, acc, qacc);
-                if (PMT_MID_ABL != 2) mid_load<DIAG, FAST>(g, row_of(s0 + d + D), lane, cj0, ck0, voff, buf[d], cb[d]);
+        } else {
+            for (int s0 = 0; s0 < nfast; s0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (s0 + d < nfast) mid_compute<DIAG>(rot, buf[d], cb[d], g.sign, lane, acc, qacc);
+                    if (PMT_MID_ABL != 2) mid_load<DIAG, FAST>(g, row_of(s0 + d + D), lane, cj0, ck0, voff, buf[d], cb[d]);
+                }
             }
         }
     }
