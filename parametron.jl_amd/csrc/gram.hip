@@ -135,14 +135,12 @@ static bool constant_chained(int64_t rows, int64_t cols) {
     return 0.07e-3 * (double)rows > 0.5 * contraction_ms;
 }
 
-// WIDE shapes of up to 2048 columns that the one-launch form on 64 x 64 tiles takes (gram_mid.hip; round 6b): the sizes the reference is used
-// at with a few hundred variables, and most of what used to be the four launches tall + fix-up + strict stream-K + fix-up.  Same-box node
-// times in us, four launches -> one (profiles/r06_gram_mid.txt): 300 x 300 35.7 -> 19, 40 x 520 46 -> 10, 1024 x 512 44 -> 23, 4096 x 512
-// 62 -> 37.5, 4096 x 1024 128 -> 110, 8192 x 512 90 -> 59, 2048 x 1280 127 -> 81, 65536 x 512 411 -> 344, 65536 x 1024 1380 -> 1270,
-// 100000 x 129 188 -> 113.  Where it loses and the four launches stay: narrow panels of more than 256 MB (every 64-column panel is read
-// once per tile of its row and column: 524288 x 129 666 -> 809, 400000 x 160 557 -> 622, 262144 x 256 385 -> 403), more than 512 MB, and
-// beyond 1536 columns with more than 2048 rows (528 tiles: the rounds of 256 workgroups do not divide — 8192 x 2048 665 -> 692).  Up to 128
-// columns the one-tile kernel of gram_tall.hip stays (three 64 x 64 tiles split 80 ways fold too much: 8192 x 128 18 -> 40 us).
+// WIDE shapes of up to 2048 columns that the one-launch form on 64 x 64 tiles takes (gram_mid.hip; round 6b/6c): the sizes the reference is
+// used at with a few hundred variables, and most of what used to be the four launches tall + fix-up + strict stream-K + fix-up.  Same-box node
+// times in us, four launches -> one (profiles/r06_gram_mid.txt): 300 x 300 35.7 -> 16, 40 x 520 46 -> 10, 1024 x 512 44 -> 21, 4096 x 512
+// 62 -> 33.6, 4096 x 1024 128 -> 98, 8192 x 512 90 -> 50.5, 2048 x 1280 127 -> 71, 65536 x 512 411 -> 304, 65536 x 1024 1380 -> 1189,
+// 262144 x 512 1387 -> 1282, 100000 x 129 188 -> 103.  Up to 128 columns the one-tile kernel of gram_tall.hip stays (three 64 x 64 tiles
+// split 80 ways fold too much: 8192 x 128 18 -> 40 us).
 #ifndef PMT_MID_MAXCOLS
 #define PMT_MID_MAXCOLS 2048
 #endif
@@ -151,9 +149,21 @@ bool gram_mid_applies(int64_t rows, int64_t cols) {
     return false;
 #endif
     if (!gram_tall_diag_applies(rows, cols) || cols > PMT_MID_MAXCOLS) return false;
-    if (cols > 1536) return rows <= 2048;
+#ifdef PMT_MID_ALWAYS
+    return true;                                                    // (A/B builds: every wide shape of up to PMT_MID_MAXCOLS columns)
+#endif
+    // Measured with the pinned instruction stream of round 6c (gram_mid.hip: mid_step), one launch against four, us (profiles/r06_gram_mid.txt):
+    //   wins   200000 x 224 287 (330), 230000 x 256 354 (381), 150000 x 288 304 (459), 160000 x 320 326 (498), 131072 x 384 358 (460),
+    //          100000 x 448 375 (554), 262144 x 512 1282 (1387), 524288 x 512 2527 (2680), 2^20 x 384 2991 (3188), 4096 x 2048 359 (381),
+    //          16384 x 2048 1190 (1338), 131072 x 1024 2453 (2640), 262144 x 1024 4980 (5240)
+    //   loses  380000 x 129 578 (505), 300000 x 160 462 (422), 250000 x 192 389 (366), 262144 x 256 407 (386), 786432 x 320 2317 (2224)
+    // (every 64-column panel is read once per tile of its row and column: few, narrow panels out of HBM are the four launches' shapes).  The
+    // fast load path needs the matrix within 4 GiB: below 2^29 elements.
     const int64_t el = rows * cols;
-    return el <= ((int64_t)1 << 25) || (cols >= 512 && el <= ((int64_t)1 << 26));
+    if (cols <= 192) return el <= ((int64_t)1 << 25);
+    if (cols < 320) return el < ((int64_t)1 << 26);
+    if (cols < 384) return el <= ((int64_t)1 << 27);
+    return el < ((int64_t)1 << 29);
 }
 
 static int linear_splits(int64_t rows, int64_t cols) {

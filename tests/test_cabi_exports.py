@@ -267,13 +267,16 @@ def test_constant_order_is_host_arithmetic(lib):
     assert order(1 << 20, 64) == (4, 512, 16) and order(1 << 20, 16) == (4, 256, 32) and order(1 << 20, 32) == (4, 256, 32)
     assert order(1 << 20, 48) == (4, 512, 32) and order(40000, 40) == (4, 313, 32) and order(20000, 40)[0] == 2      # 33 .. 48 columns: three column groups (stream form only)
     # .. or several.  Most of them take the one-launch form on 64 x 64 tiles (gram_mid.hip; the constant by one more workgroup of that launch, order 5:
-    # 512 strided chains): up to 1536 columns and 256 MB (512 MB from 512 columns), up to 2048 columns with at most 2048 rows
+    # 512 strided chains) — gram.hip: gram_mid_applies, by measured times: up to 192 columns 2^25 elements, below 320 columns 2^26, below 384
+    # columns 2^27, from 384 columns everything the fast load path reaches (below 2^29 elements)
     assert order(300, 300) == (5, 1, 512) and order(4096, 512) == (5, 1, 512) and order(100, 1000)[0] == 5 and order(8192, 256)[0] == 5
     assert order(4096, 256)[0] == 5 and order(70, 130)[0] == 5 and order(4097, 512)[0] == 5 and order(17, 130)[0] == 5 and order(31, 300)[0] == 5
     assert order(16384, 1024)[0] == 5 and order(131072, 256)[0] == 5 and order(65536, 1024)[0] == 5 and order(1024, 2048)[0] == 5 and order(2048, 1537)[0] == 5
-    # .. the rest the diagonal tiles' kernel + the strict stream-K launch (tile 0's workgroups the constant, order 2)
-    assert order(262144, 256)[0] == 2 and order(524288, 129)[0] == 2 and order(262144, 512)[0] == 2 and order(65536, 2048) == (2, 64, 32)
-    assert order(2049, 1537)[0] == 2 and order(8192, 2048)[0] == 2 and order(1 << 20, 192)[0] == 2
+    assert order(262144, 512)[0] == 5 and order(524288, 512)[0] == 5 and order(65536, 2048)[0] == 5 and order(8192, 2048)[0] == 5 and order(2049, 1537)[0] == 5
+    assert order(230000, 256)[0] == 5 and order(160000, 320)[0] == 5 and order(1 << 20, 384)[0] == 5 and order(100000, 129)[0] == 5
+    # .. the rest the diagonal tiles' kernel + the strict stream-K launch (tile 0's workgroups the constant, order 2): few, narrow panels out of HBM
+    assert order(262144, 256)[0] == 2 and order(524288, 129)[0] == 2 and order(1 << 20, 192)[0] == 2 and order(786432, 320)[0] == 2
+    assert order(1 << 20, 512)[0] == 2 and order(380000, 129)[0] == 2 and order(300000, 160)[0] == 2
     with pytest.raises(lib.ArgumentError):
         lib.call("pmt_quad_gram_constant_order", -1, 4, None, None, None)
 
