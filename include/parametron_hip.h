@@ -194,8 +194,8 @@ size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
  *   order 4  narrow panels, cols <= 64, from 32768 rows (gram_stream_kernel): iterations of `stage_rows` rows dealt out to the 4 * `groups` WAVES (wave
  *            4 g + w: iterations 4 g + w, + 4 * groups, ..); contraction slot k of a wave adds rows 8 i + 2 k, + 1 of its iterations in order;
  *            slots (0 + 2) + (1 + 3); the four waves of a workgroup in order; workgroups in 16 interleaved slices, then the slices
- *   order 5  wide shapes in one launch (gram_mid.hip: 129 .. 1536 columns up to 2^25 elements — 2^26 from 512 columns —, 1537 .. 2048 columns up to
- *            2048 rows): `stage_rows` = 512 strided chains (thread
+ *   order 5  wide shapes in one launch (gram_mid.hip: 129 .. 2048 columns — from 384 columns everything below 2^29 elements, below 384 / 320 / 193
+ *            columns up to 2^27 / 2^26 / 2^25; gram.hip: gram_mid_applies): `stage_rows` = 512 strided chains (thread
  *            t adds rows t, t + 512, ..), a shuffle tree (32, 16, .., 1) per 64 threads, the eight results in order
  * (tests/gpu_util.py restates every order bit for bit.)
  * Every order is within (rows / 2048 + 2048) * eps / 2 relative of the exact sum for same-signed terms: far inside the 1e-12 parity bar. */

@@ -1,5 +1,5 @@
-// Canonical least-squares objective for MID-SIZE wide shapes (129 .. 1024 columns, a few thousand rows at most: the sizes the reference
-// is used at with a few hundred variables) in ONE launch: upper triangle of A'A, q = 2 A'c and c'c.
+// Canonical least-squares objective for WIDE shapes of 129 .. 2048 columns (from the sizes the reference is used at with a few hundred
+// variables up to what the fast load path reaches: gram.hip, gram_mid_applies) in ONE launch: upper triangle of A'A, q = 2 A'c and c'c.
 //
 // Reference semantics replaced: _vecdot!/muladd! literal expansion (src/functions.jl:702-709,548-576) + canonicalize!
 // (src/functions.jl:381-386, src/util.jl:9-26) + update!(::MOI.ScalarQuadraticFunction) (src/moi_interop.jl:45-62): SURVEY Appendix A.3.
@@ -9,9 +9,9 @@
 // 54.8 us for 13.7 us of flops.  Here
 //   * tiles are 64 x 64 (a partial is 32 KB); a workgroup takes one (tile, row chunk); its four waves split the chunk's 8-row groups among
 //     themselves (a split of the contraction index: each wave holds the WHOLE tile, 16 blocks x 4 rotations = 64 accumulators, so a
-//     k-step's 4 + 4 operand loads feed 64 MFMAs) and stream their rows straight from global memory (L2 / Infinity Cache: the matrix is
-//     <= 16 MB) in the MFMA operand layout — no barrier, no shared panel; the rotated B operands come out of the wave's private piece of LDS
-//     (gram_tall.hip: gram_stream_kernel);
+//     k-step's 4 + 4 operand loads feed 64 MFMAs) and stream their rows straight from global memory (L2 / Infinity Cache) in the MFMA
+//     operand layout — no barrier, no shared panel; the rotated B operands come out of the wave's private piece of LDS (gram_tall.hip:
+//     gram_stream_kernel); an 8-row group and the loads of the group D further on are one pinned instruction stream (mid_step);
 //   * diagonal tiles compute their 10 upper blocks and carry q = A'c on the matrix pipe (B operand = c in every lane of the slot); they are
 //     split into fewer chunks than the off-diagonal ones (40 against 64 MFMAs per k-step);
 //   * the waves' sums are added through LDS in a fixed order; a split tile's partials go to the workspace and the LAST workgroup of the tile
