@@ -129,7 +129,10 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
                          fold * (1.0 + (double)(p.n_off + p.nb) / PMT_MID_G);
         if (t < best_t) { best_t = t; best = s; }
     }
-    const int s = best;
+    int s = best;
+#ifdef PMT_MID_ENV_S
+    if (const char *e = getenv("PMT_MID_S")) { const int v = atoi(e); if (v > 0) s = std::min(v, maxs); }      // (measurement builds only)
+#endif
     p.gpc_off = (int)cdiv(ngroups, s);
     p.s_off = (int)cdiv(ngroups, p.gpc_off);
     p.gpc_diag = (int)cdiv(ngroups, sd(s));
