@@ -752,6 +752,9 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 #ifndef PMT_STREAM_WPS
 #define PMT_STREAM_WPS 2
 #endif
+#ifndef PMT_STREAM_WPS12
+#define PMT_STREAM_WPS12 1         // 16 / 32 columns run one workgroup per CU (PMT_STREAM_MAXG): the whole register file for a round of D iterations as one block (256 registers: 20 spilled at 32 columns)
+#endif
 #ifndef PMT_STREAM_WPS4
 #define PMT_STREAM_WPS4 2          // workgroups per CU the 64-column kernel's registers are budgeted for
 #endif
@@ -766,6 +769,9 @@ __global__ __launch_bounds__(256, PMT_NARROW_WPS) void gram_narrow_kernel(TallAr
 #endif
 #ifndef PMT_STREAM_ABL
 #define PMT_STREAM_ABL 0           // ablations (wrong results): 1 no MFMAs / rotations, 2 no loads after the first D iterations
+#endif
+#ifndef PMT_STREAM_SADDR
+#define PMT_STREAM_SADDR 1         // scalar-base loads, no branch around b's load, whole rounds of D iterations as one branch-free block
 #endif
 #ifndef PMT_STREAM_DPP
 #define PMT_STREAM_DPP 1           // 0: the rotated operands are loaded again from global memory (L1 hits) instead of DPP rotations
@@ -787,17 +793,30 @@ template <int NB> struct Stream {
 // one ragged iteration at the end of the matrix, 8-byte loads from clamped addresses, what lies outside replaced by 0.0 (no branch around a
 // load either: s_waitcnt vmcnt counts loads in order, a merge would drain the pipeline).
 template <int NB, bool FAST>
-__device__ __forceinline__ void stream_load(const TallArgs &g, int64_t row0, int lane, const unsigned (&voff)[NB], f64x2 (&buf)[NB][Stream<NB>::IT], f64x2 &cb) {
+__device__ __forceinline__ void stream_load(const TallArgs &g, int64_t row0, int lane, unsigned (&voff)[NB], f64x2 (&buf)[NB][Stream<NB>::IT], f64x2 &cb) {
     using S = Stream<NB>;
     const int lm = lane & 15, lk = lane >> 4, bp = lane & (4 * S::IT - 1);
     if (FAST) {
         const char *base = reinterpret_cast<const char *>(g.A + row0);
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
+        for (int t = 0; t < NB; ++t) {
+#if PMT_STREAM_SADDR
+            // the lane offset passes through an empty asm: the compiler cannot hoist its zero extension out of the loop (it did, and
+            // then paid a 64-bit vector add per load instead of the scalar-base form; gram_mid.hip: mid_step)
+            asm volatile("" : "+v"(voff[t]));
+#endif
 #pragma unroll
             for (int i = 0; i < S::IT; ++i) buf[t][i] = *reinterpret_cast<const f64x2 *>(base + voff[t] + 64 * i);
+        }
+#if PMT_STREAM_SADDR
+        // no b: sign is 0 and signed_const ignores what is loaded — any valid address keeps the loop free of branches
+        unsigned bo = 16u * (unsigned)bp;
+        asm volatile("" : "+v"(bo));
+        cb = *reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>((g.b ? g.b : g.A) + row0) + bo);
+#else
         cb.x = 0.0; cb.y = 0.0;
         if (g.b) cb = *reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(g.b + row0) + 16u * (unsigned)bp);
+#endif
         return;
     }
 #pragma unroll
@@ -837,8 +856,13 @@ __device__ __forceinline__ void stream_compute(double *__restrict__ rot, const f
                                                int lane, double (&acc)[Narrow<NB>::NACC], double (&qacc)[NB], double &cacc) {
     using S = Stream<NB>;
     const int lm = lane & 15, lrow = lane & 48, lk = lane >> 4;
-    double *__restrict__ rotb = rot + NB * S::IT * 128;              // b's row pairs: lane l < 4 IT holds pair l
-    *reinterpret_cast<f64x2 *>(rotb + lane * 2) = cb;
+    double *__restrict__ rotb = rot + NB * S::IT * 128;              // c's row pairs: lane l < 4 IT holds pair l
+    // c = 0.0 (+|-) b ONCE per loaded value, before the pairs go to LDS (round 6c): done behind the read-back, every contraction slot
+    // recomputed it for its pair — 12 vector ALU instructions per pair of k-steps in the wave's one issue stream (48 of the 64 beside
+    // 32 MFMAs per iteration at 16 columns), and vector ALU work does not hide behind the wave's own f64 MFMAs.  Same values, same bits.
+    f64x2 cs;
+    cs.x = signed_const(cb.x, sign); cs.y = signed_const(cb.y, sign);
+    *reinterpret_cast<f64x2 *>(rotb + lane * 2) = cs;
 #if PMT_STREAM_ABL != 4
 #pragma unroll
     for (int t = 0; t < NB; ++t)
@@ -868,8 +892,8 @@ __device__ __forceinline__ void stream_compute(double *__restrict__ rot, const f
                 }
         }
         if (PMT_STREAM_ABL == 5) continue;                                                // (ablation: no q / c'c)
-        const f64x2 bi = *reinterpret_cast<const f64x2 *>(rotb + (4 * i + lk) * 2);        // rows 8 i + 2 lk, + 1 of b
-        const double c0 = signed_const(bi.x, sign), c1 = signed_const(bi.y, sign);
+        const f64x2 bi = *reinterpret_cast<const f64x2 *>(rotb + (4 * i + lk) * 2);        // rows 8 i + 2 lk, + 1 of c
+        const double c0 = bi.x, c1 = bi.y;
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
             qacc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(buf[t][i].x, c0, qacc[t], 0, 0, 0);
@@ -881,7 +905,7 @@ __device__ __forceinline__ void stream_compute(double *__restrict__ rot, const f
 }
 
 template <int NB, bool FAST>
-__global__ __launch_bounds__(256, NB == 4 ? PMT_STREAM_WPS4 : PMT_STREAM_WPS) void gram_stream_kernel(TallArgs g) {
+__global__ __launch_bounds__(256, NB == 4 ? PMT_STREAM_WPS4 : NB <= 2 ? PMT_STREAM_WPS12 : PMT_STREAM_WPS) void gram_stream_kernel(TallArgs g) {
     using S = Stream<NB>;
     using N = Narrow<NB>;
     // per wave: the rotation buffer of one iteration (NB IT KB) during the loop; afterwards the same memory carries the waves' sums
@@ -914,11 +938,27 @@ __global__ __launch_bounds__(256, NB == 4 ? PMT_STREAM_WPS4 : PMT_STREAM_WPS) vo
     if (my > 0) {
 #pragma unroll
         for (int d = 0; d < S::D; ++d) stream_load<NB, FAST>(g, row_of(d), lane, voff, buf[d], cb[d]);
-        for (int s0 = 0; s0 < my; s0 += S::D) {
+        if (PMT_STREAM_SADDR && FAST && PMT_STREAM_ABL == 0) {
+            // whole rounds of D iterations: one block without a branch (the number of loads in flight does not depend on the path, the
+            // compiler's vmcnt waits stay counted ones); the loads beyond the wave's last iteration repeat the last one
+            int s0 = 0;
+            for (; s0 + S::D <= my; s0 += S::D) {
 #pragma unroll
-            for (int d = 0; d < S::D; ++d) {
+                for (int d = 0; d < S::D; ++d) {
+                    stream_compute<NB>(rot, buf[d], cb[d], g.sign, lane, acc, qacc, cacc);
+                    stream_load<NB, FAST>(g, row_of(s0 + d + S::D), lane, voff, buf[d], cb[d]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < S::D - 1; ++d)
                 if (s0 + d < my) stream_compute<NB>(rot, buf[d], cb[d], g.sign, lane, acc, qacc, cacc);
-                if (PMT_STREAM_ABL != 2 && PMT_STREAM_ABL != 4 && PMT_STREAM_ABL != 5) stream_load<NB, FAST>(g, row_of(s0 + d + S::D), lane, voff, buf[d], cb[d]);
+        } else {
+            for (int s0 = 0; s0 < my; s0 += S::D) {
+#pragma unroll
+                for (int d = 0; d < S::D; ++d) {
+                    if (s0 + d < my) stream_compute<NB>(rot, buf[d], cb[d], g.sign, lane, acc, qacc, cacc);
+                    if (PMT_STREAM_ABL != 2 && PMT_STREAM_ABL != 4 && PMT_STREAM_ABL != 5) stream_load<NB, FAST>(g, row_of(s0 + d + S::D), lane, voff, buf[d], cb[d]);
+                }
             }
         }
     }
