@@ -43,6 +43,9 @@
 #define PMT_BS_FENCE 1     // operand reads are hoisted at most one k-step ahead of their MFMAs (unfenced the scheduler hoists several k-steps and spills)
 #endif
 
+#ifndef PMT_BS_PIN
+#define PMT_BS_PIN 0       // (measured round 6c: 0.450 against 0.416 ms per step — SLOWER here, profiles/r06_batch_small_pin.txt; not shipped) 1: the matrix waves' k-step as one pinned instruction stream: one operand read behind every second MFMA (0: the reads of k-step ks + 1 in one run in front of the MFMAs of ks)
+#endif
 #ifndef PMT_BS_GLDS
 #define PMT_BS_GLDS 0      // 1: the FAST path's A chunks go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write)
 #endif
@@ -192,6 +195,55 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
                     for (int r = 0; r < 4; ++r) { bA[s_][r] = pan[bA0 + rc[r] + ks * 4]; bB[s_][r] = pan[bB0 + rc[r] + ks * 4]; }
                 };
                 read_operands(0, 0);
+#if PMT_BS_PIN
+                // Round 6c: the k-step as ONE pinned instruction stream (gram_mid.hip: mid_step).  The matrix wave is alone with its SIMD's
+                // matrix pipe: the KA + 8 operand reads of k-step ks + 1 stood in one run in front of the 34-36 MFMAs of k-step ks, and a
+                // run of LDS instructions is issue time the pipe waits for.  Here ONE read stands behind every second MFMA, in the order
+                // the next k-step needs them (the A operands, then the B operands rotation by rotation); same MFMAs in the same order.
+                auto read_one = [&](int s_, int ks, int idx) {
+                    if (PMT_BS_SKIP & 32) { read_operands(s_, ks); return; }
+                    const int hi = (ks >> 1) * 8;
+                    if (idx < KA) {
+                        a[s_][idx] = GL ? pan[((ks & 1) ? gaO : gaE) + idx * 4 * GLG + hi] : pan[a0 + idx * 16 * SGP + ks * 4];
+                    } else {
+                        const int r = (idx - KA) >> 1;
+                        const bool isB = ((idx - KA) & 1) != 0;
+                        if (GL) {
+                            const int b0 = (ks & 1) ? gbO[r] : gbE[r];
+                            if (isB) bB[s_][r] = pan[b0 + TNB * 4 * GLG + hi]; else bA[s_][r] = pan[b0 + TNA * 4 * GLG + hi];
+                        } else {
+                            if (isB) bB[s_][r] = pan[bB0 + rc[r] + ks * 4]; else bA[s_][r] = pan[bA0 + rc[r] + ks * 4];
+                        }
+                    }
+                };
+#pragma unroll
+                for (int ks = 0; ks < CK / 4; ++ks) {
+                    const int s_ = ks & 1;
+                    const bool more = ks + 1 < CK / 4;
+                    int m = 0, nread = 0;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int i = 0; i < KA + KB; ++i) {
+                            const bool isA = i < KA;
+                            const int ii = isA ? i : i - KA;
+                            if (PMT_BS_DIAG3 && r == 3 && ii == (isA ? KA : KB) - 1) continue;
+                            if (isA) accA[ii][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][ii], bA[s_][r], accA[ii][r], 0, 0, 0);
+                            else accB[ii][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s_][ii], bB[s_][r], accB[ii][r], 0, 0, 0);
+                            if (more && (m & 1) == 0 && nread < KA + 8 && !(PMT_BS_SKIP & 32)) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                read_one(s_ ^ 1, ks + 1, nread);
+                                __builtin_amdgcn_sched_barrier(0);
+                                ++nread;
+                            }
+                            ++m;
+                        }
+                    }
+                    if (more && (PMT_BS_SKIP & 32)) read_operands(s_ ^ 1, ks + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
 #pragma unroll
                 for (int ks = 0; ks < CK / 4; ++ks) {
                     const int s_ = ks & 1;
@@ -211,6 +263,7 @@ __device__ __forceinline__ void matrix_wave(const SmallArgs &p, const Shared &sh
                     }
                     if (PMT_BS_FENCE) asm volatile("" ::: "memory");
                 }
+#endif
             }
             if (PMT_BS_TRACE && W == 0 && lane == 0) BS_STAMP(0, 4 * tphase + 1);
             if (ch == nchunk - 1) {
