@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 # measures 75.6 TFLOP/s with two MFMA waves per SIMD on the box (profiles/r02_fp64_coissue.txt).
 F64_MFMA_PEAK_TFLOPS = 78.6
 LINE_LIMIT = 4096              # bytes of the stdout line (the driver stopped parsing a 20.8 KB line in round 5)
-DOMINANT = "gram_sk_kernel"
+DOMINANT = "gram_mid_kernel"
 
 
 def parse_args():
@@ -413,7 +413,7 @@ def sections(out, args, torch, P, _lib, wl, BC):
     if out["roofline"] is not None:
         measured = "not run (--no-pmc)" if args.no_pmc else guarded(pmc_children)
         out["pmc_traffic"] = measured
-        attach_traffic(out["roofline"], measured, "pmt::gram_sk_kernel<2, 16, 2, 0, false>")
+        attach_traffic(out["roofline"], measured, "pmt::gram_mid_kernel<true>")
         us = _get(measured, "affine_tile_kernel<VAT>", "rocprofv3_us")
         if us:      # the constraint pack INSIDE the step (cold input behind the contraction) by the profiler's own clock, this run
             out["pack_in_step_rocprofv3"] = hbm_roofline("affine_tile_kernel<VAT>", us * 1e-3, 32.0 * wl.m * wl.n, source="rocprofv3 --kernel-trace child of this run (no counters), 20 timed steps")
@@ -563,7 +563,7 @@ def main():
     else:
         wl.close()
         if rank == 0 and out["roofline"] is not None:
-            attach_traffic(out["roofline"], "not run (N > 1 or --graph)", "pmt::gram_sk_kernel<2, 16, 2, 0, false>")
+            attach_traffic(out["roofline"], "not run (N > 1 or --graph)", "pmt::gram_mid_kernel<true>")
     if not args.no_configs:
         # every rank: BASELINE config 4 sharded by instance over the N ranks (N = 1: the same code path, single-rank communicator)
         from parametron_jl_amd import batch

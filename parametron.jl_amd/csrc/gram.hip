@@ -56,6 +56,7 @@ int gram_mid_counters(int64_t cols);
 int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
                     const int64_t *varmap, pmt_quadratic_term *out_quad, double *out_csc, double alpha, pmt_linear_term *out_lin,
                     double *out_const, void *workspace, unsigned *counters, hipStream_t s);
+int launch_gram_mid_constant(const double *b, int sign, int64_t rows, double *out_const, hipStream_t s);
 constexpr int GT = 128;          // output tile edge of the contraction (gram_sk.hip)
 constexpr size_t PAIR_FLAG_BYTES = 4096;      // 4 bytes per tile of a stage (at most 512 workgroups / 2 tiles)
 // a CSC delivery computes the tiles column band by column band (super-columns of ONE tile column: a band's completion is never held back by
@@ -144,10 +145,29 @@ static bool constant_chained(int64_t rows, int64_t cols) {
 #ifndef PMT_MID_MAXCOLS
 #define PMT_MID_MAXCOLS 2048
 #endif
+#ifndef PMT_MID_BIGCOLS
+#define PMT_MID_BIGCOLS 4096
+#endif
+#ifndef PMT_MID_BIGROWS
+#define PMT_MID_BIGROWS 8192
+#endif
+// 2049 .. 4096 columns (config 2), round 6c: with the pinned instruction stream the one launch beats the stream-K node (contraction + fix-up,
+// q and the constant on a side stream) up to 8192 rows — 4096 x 4096 1205 -> 1096-1126 us (0.73 -> 0.78-0.80 of the f64 matrix peak), 2048 x
+// 4096 661 -> 599, 4096 x 3072 718 -> 644, 4096 x 2304 461 -> 384, 8192 x 2560 1065 -> 910, 1000 x 3000 246 -> 191, 8192 x 4096 2340 -> 2309;
+// beyond, the unsplit tiles' rounds of 256 workgroups cost more than they gain (16384 x 4096 4600 -> 4884, 32768 x 3072 5324 -> 5681).  A
+// STAGED host delivery of such a shape (config 2's host_csc hand-off: column bands leave while the contraction runs) keeps the stream-K
+// kernel — run_quad_gram — with the constant in this form's order, so that pmt_quad_gram_constant_order holds for every call form.
+bool gram_mid_big(int64_t rows, int64_t cols) {
+#ifdef PMT_NO_MID
+    return false;
+#endif
+    return cols > 16 * 128 && cols <= PMT_MID_BIGCOLS && rows >= 1 && rows <= PMT_MID_BIGROWS;
+}
 bool gram_mid_applies(int64_t rows, int64_t cols) {
 #ifdef PMT_NO_MID
     return false;
 #endif
+    if (gram_mid_big(rows, cols)) return true;
     if (!gram_tall_diag_applies(rows, cols) || cols > PMT_MID_MAXCOLS) return false;
 #ifdef PMT_MID_ALWAYS
     return true;                                                    // (A/B builds: every wide shape of up to PMT_MID_MAXCOLS columns)
@@ -202,7 +222,7 @@ constexpr size_t PROGRESS_OFFSET = 0;
 constexpr size_t FLAGS_OFFSET = PROGRESS_OFFSET + MAXGROUPS * sizeof(unsigned long long);
 constexpr size_t DONE_OFFSET = FLAGS_OFFSET + MAXGROUPS * sizeof(long long);
 constexpr size_t MID_OFFSET = DONE_OFFSET + 2 * sizeof(unsigned);                  // per-tile arrival counts of the one-launch mid-size node (gram_mid.hip)
-constexpr size_t MID_COUNTER_BYTES = 36864;          // 16 words per tile, 528 tiles at 2048 columns
+constexpr size_t MID_COUNTER_BYTES = 135168;         // 16 words per tile, 2080 tiles at 4096 columns
 constexpr size_t COUNTER_BYTES = MID_OFFSET + MID_COUNTER_BYTES;
 static std::mutex g_side_mu;
 static std::unordered_map<hipStream_t, SideStream> g_side;
@@ -631,7 +651,9 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
     // upper tiles in ONE ranged launch of the stream-K kernel (SKArgs::strict: its tile sequence leaves the diagonal out; the partials of both
     // forms share the workspace in stream order).  A host delivery of such a node is ONE transfer of the whole array behind it: the staged
     // contraction pays for hundreds of megabytes (config 2), not for the <= 50 MB of these shapes.
-    const bool tall_form = cols > 0 && workspace && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols));
+    // (2049 .. 4096 columns: the one-launch form unless a staged delivery is asked for — gram_mid_big)
+    const bool mid_big = cols > 0 && workspace && !deliver_host && gram_mid_big(rows, cols);
+    const bool tall_form = cols > 0 && workspace && (gram_tall_applies(rows, cols) || gram_tall_diag_applies(rows, cols) || mid_big);
     if (deliver_host && cols > 0) {
         if (tall_form) {
             dplan.host = deliver_host;
@@ -702,7 +724,8 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         double *chains = scratch ? scratch + (size_t)linear_splits(rows, cols) * (size_t)cols : nullptr;
         auto const_part = [=]() -> int {
             int rc2 = PMT_OK;
-            if (b && sign && rows > 0) rc2 = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2, constant_chained(rows, cols) ? 1 : 0);
+            if (gram_mid_big(rows, cols)) rc2 = launch_gram_mid_constant(b, sign, rows, out_const, s2);      // (a staged delivery: the one-launch form's order)
+            else if (b && sign && rows > 0) rc2 = launch_blocked_dot(b, sign, b, sign, rows, chains, out_const, s2, constant_chained(rows, cols) ? 1 : 0);
             else if (hipMemsetAsync(out_const, 0, sizeof(double), s2) != hipSuccess) rc2 = fail(PMT_HIP_ERROR, "hipMemsetAsync(out_const)");
             if (side) {
                 PMT_HIP_CHECK(hipEventRecord(side->join2, side->stream));
@@ -714,7 +737,7 @@ static int gram_node(const double *A, int64_t lda, int64_t rows, int64_t cols, c
         if (!rc && defer_const) side->deferred.push_back(const_part);
         if (side && !tall_form) PMT_HIP_CHECK(hipEventRecord(side->join, side->stream));          // the affine part: `s` joins it behind the contraction's launch
         if (!rc && cols > 0) {
-            if (tall_form && gram_mid_applies(rows, cols)) {
+            if (tall_form && (mid_big || (gram_mid_applies(rows, cols) && !gram_mid_big(rows, cols)))) {
                 // WIDE shapes of up to 2048 columns (gram_mid_applies): the whole node — every tile, q and c'c — in ONE launch on 64 x 64 tiles
                 // (gram_mid.hip); the per-tile arrival counts are this calling stream's
                 PMT_REQUIRE(side && side->counters && (size_t)gram_mid_counters(cols) * sizeof(unsigned) <= MID_COUNTER_BYTES, PMT_STATE_ERROR,

@@ -41,6 +41,9 @@
 #ifndef PMT_MID_XCD
 #define PMT_MID_XCD 1              // 0: workgroup ids tile-major (id = tile * S + chunk) whatever the size
 #endif
+#ifndef PMT_MID_SUPER
+#define PMT_MID_SUPER 1            // XCD-aware order: the tiles of a chunk in 8 x 8 super-tiles (mid_tile_of)
+#endif
 #ifndef PMT_MID_FB
 #define PMT_MID_FB 4               // chunks whose partials the last arriver loads together (64 loads per thread: a wave may have 63 outstanding; 8, or 16-byte loads: no faster)
 #endif
@@ -130,7 +133,7 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
         if (t < best_t) { best_t = t; best = s; }
     }
     int s = best;
-#ifdef PMT_MID_ENV_S
+#ifdef PMT_TUNING
     if (const char *e = getenv("PMT_MID_S")) { const int v = atoi(e); if (v > 0) s = std::min(v, maxs); }      // (measurement builds only)
 #endif
     p.gpc_off = (int)cdiv(ngroups, s);
@@ -680,6 +683,26 @@ __device__ __forceinline__ int mid_xcd_rank(int id, int base, int n) {
     return start + ((id - (base + ((x - base) & 7))) >> 3);
 }
 
+// Strictly upper tile number t -> (jb, kb) in SUPER-TILE order (round 6c): 8 x 8 blocks of tiles, column by column; inside a block row by
+// row (on the diagonal: column by column).  32 consecutive tiles — what an XCD runs at a time — are then 4 row panels x 8 column panels
+// (12 panels through its L2) instead of one column panel with 32 row panels (33): config 2 moved 4.39 GB per launch over the fabric.
+__device__ __forceinline__ void mid_tile_of(int t, int nb, int &jb, int &kb) {
+    const int nsb = (nb + 7) >> 3;
+    for (int K = 0; K < nsb; ++K) {
+        const int wK = min(8, nb - 8 * K);
+        for (int J = 0; J <= K; ++J) {
+            const int cnt = J < K ? 8 * wK : wK * (wK - 1) / 2;
+            if (t >= cnt) { t -= cnt; continue; }
+            if (J < K) { jb = 8 * J + t / wK; kb = 8 * K + t % wK; return; }
+            int kk = 1;
+            while (t >= kk) { t -= kk; ++kk; }
+            jb = 8 * K + t; kb = 8 * K + kk;
+            return;
+        }
+    }
+    jb = 0; kb = 1;
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
     __shared__ double sh[MSH];
@@ -695,10 +718,15 @@ __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
         const int k = g.xcd ? mid_xcd_rank(id, 0, noff) : (id % g.s_off) * g.n_off + id / g.s_off;
         const int chunk = k / g.n_off;
         int t = k - chunk * g.n_off;
-        const int tile = t;
-        int kb = 1;
-        while (t >= kb) { t -= kb; ++kb; }                         // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
-        mid_body<false, FAST>(g, sh, tid, t, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile * MCNT);
+        int jb, kb;
+        if (PMT_MID_SUPER && g.xcd) mid_tile_of(t, g.nb, jb, kb);
+        else {
+            kb = 1;
+            while (t >= kb) { t -= kb; ++kb; }                     // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
+            jb = t;
+        }
+        const int tile = kb * (kb - 1) / 2 + jb;                   // (workspace slots and counters: the column-by-column number)
+        mid_body<false, FAST>(g, sh, tid, jb, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile * MCNT);
         return;
     }
     if (id < noff + g.nb * g.s_diag) {
@@ -708,6 +736,18 @@ __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
         return;
     }
     mid_constant(g, sh, tid);
+}
+
+// c'c alone, in the same order 5 (the staged host delivery of a shape the one-launch form otherwise takes: gram.hip)
+__global__ __launch_bounds__(256) void gram_mid_constant_kernel(MidArgs g) {
+    __shared__ double sh[8];
+    mid_constant(g, sh, threadIdx.x);
+}
+int launch_gram_mid_constant(const double *b, int sign, int64_t rows, double *out_const, hipStream_t s) {
+    MidArgs g = {};
+    g.rows = rows; g.b = (b && sign) ? b : nullptr; g.sign = g.b ? sign : 0; g.out_const = out_const;
+    PMT_LAUNCH_NAMED("gram_mid_constant_kernel", gram_mid_constant_kernel, dim3(1), dim3(256), 0, s, g);
+    return check_launch("gram_mid_constant_kernel");
 }
 
 size_t gram_mid_workspace_bytes(int64_t rows, int64_t cols) {

@@ -1085,6 +1085,9 @@ bool gram_tall_applies(int64_t rows, int64_t cols) { return cols >= 1 && cols <=
 // side-stream fork for q and c'c.  Measured (profiles/r05_gram_tall.txt) against the stream-K node: better at every row count from 100 to
 // 2^20 (300 x 300: 64 -> 37 us; 4096 x 512: 112 -> 69 us; 262144 x 512: 1.76 -> 1.44 ms; 65536 x 2048: 5.69 -> 5.37 ms), equal at
 // 8192 x 1024 and 4096 x 2048.  Config 2 (4096 columns) keeps the plain stream-K node.
+#ifndef PMT_WIDE_MAXCOLS
+#define PMT_WIDE_MAXCOLS (16 * TCOLS)
+#endif
 bool gram_tall_diag_applies(int64_t rows, int64_t cols) {
 #ifdef PMT_TUNING
     static const int64_t minrows = [] { const char *e = getenv("PMT_TALL_DIAG_MINROWS"); return e ? atoll(e) : 1LL; }();
@@ -1092,7 +1095,7 @@ bool gram_tall_diag_applies(int64_t rows, int64_t cols) {
     static const int64_t maxcols = [] { const char *e = getenv("PMT_TALL_DIAG_MAXCOLS"); return e ? atoll(e) : 16LL * TCOLS; }();
     return cols > TCOLS && cols <= maxcols && rows >= minrows && rows >= ratio * cols;
 #else
-    return cols > TCOLS && cols <= 16 * TCOLS && rows >= 1;
+    return cols > TCOLS && cols <= PMT_WIDE_MAXCOLS && rows >= 1;
 #endif
 }
 

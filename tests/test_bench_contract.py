@@ -21,7 +21,7 @@ def test_roofline_helpers_follow_the_contract():
     r = bench.hbm_roofline("k", 0.05, 402653184.0)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] == pytest.approx(402653184.0 / 0.05e-3 / 1e9) and r["frac"] == pytest.approx(r["achieved"] / r["peak"])
-    m = bench.mfma_roofline("gram_sk_kernel", 1.18, 4096.0 * 4096 * 4097)
+    m = bench.mfma_roofline("gram_mid_kernel", 1.18, 4096.0 * 4096 * 4097)
     assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and 0.7 < m["frac"] < 0.8 and m["traffic"] is None
     json.dumps(r), json.dumps(m)
 
@@ -65,8 +65,8 @@ def _full_size_out():
     """an `out` of the size the default run builds: every section with its prose, per-kernel tables, error strings"""
     kern = {"kernel_%d<with, template, arguments, %d>" % (i, i): {"launches": 20, "avg_ms": 1.2007552499999998, "min_ms": 1.1, "max_ms": 1.3, "measured": "x" * 90}
             for i in range(25)}
-    roof = bench.mfma_roofline("gram_sk_kernel", 1.2007552499999998, 4096.0 * 4096 * 4097, launches=20, algorithmic_bytes=335.6e6)
-    bench.attach_traffic(roof, {"gram_sk_kernel": {"read": 870123456.789, "write": 184123456.789}, "source": "s"}, "pmt::gram_sk_kernel<")
+    roof = bench.mfma_roofline("gram_mid_kernel", 1.2007552499999998, 4096.0 * 4096 * 4097, launches=20, algorithmic_bytes=335.6e6)
+    bench.attach_traffic(roof, {"gram_mid_kernel": {"read": 870123456.789, "write": 184123456.789}, "source": "s"}, "pmt::gram_mid_kernel<")
     shapes = {"%dx%d" % (r, n): {"node_ms": 0.0617123456, "frac": 0.2212345678, "mfma_frac": 0.22, "hbm_frac": 0.1, "binding": "mfma", "kernels_ms": kern}
               for r, n in ((1 << 20, 16), (1 << 20, 64), (1 << 20, 128), (4096, 512), (262144, 512), (300, 300))}
     return {"metric": "QP re-evaluations/sec (Q,q,C,d rebuild) at n=4096", "value": 805.1812345678, "unit": "re-evaluations/s", "n_gpus": 1, "steps": 20,
@@ -77,7 +77,7 @@ def _full_size_out():
             "ranks_seen": 1, "kernels": kern, "roofline": roof, "value_200_steps": {"value": 798.5123456, "what": "w" * 200},
             "roofline_affine": {"frac": 0.838825149931128, "cold": {"frac": 0.6634979288064853, "what": "c" * 300}, "note": "n" * 500},
             "roofline_constraint_pack": {"frac": 0.5429215189654949, "warm": {"frac": 0.57}, "note": "n" * 500},
-            "pmc_traffic": {"gram_sk_kernel": {"read": 8.7e8, "write": 1.84e8}, "source": "s" * 200},
+            "pmc_traffic": {"gram_mid_kernel": {"read": 8.7e8, "write": 1.84e8}, "source": "s" * 200},
             "configs": {"C1": {"update_us": 9.123456789, "solve_us_python_host_mock_optimizer": 26.87654321, "model_update_us_c_entry": 12.3456789, "workload": "y" * 300, "kernel_us": kern},
                         "C3": {"ms_per_step": 1.2712345678, "workload": "y" * 3000, "kernels": kern},
                         "C4": {"ms_per_step": 0.4412345678, "roofline": {"frac": 0.5412345678}, "kernels": kern},
@@ -129,11 +129,11 @@ def test_the_line_survives_missing_and_failing_sections():
 
 
 def test_traffic_is_labelled_measured_or_replayed():
-    roof = bench.mfma_roofline("gram_sk_kernel", 1.2, 6.87e10)
+    roof = bench.mfma_roofline("gram_mid_kernel", 1.2, 6.87e10)
     bench.attach_traffic(roof, None, "pmt::no_such_kernel")                  # no rocprofv3, nothing on file
     assert roof["measured_in_this_run"] is False and roof["traffic"] is None and "rocprofv3 not on PATH" in roof["traffic_source"]
-    roof = bench.mfma_roofline("gram_sk_kernel", 1.2, 6.87e10)
-    bench.attach_traffic(roof, {"error": "rocprofv3 --pmc FETCH_SIZE child: rc 1"}, "pmt::gram_sk_kernel<2, 16, 2, 0, false>")
+    roof = bench.mfma_roofline("gram_mid_kernel", 1.2, 6.87e10)
+    bench.attach_traffic(roof, {"error": "rocprofv3 --pmc FETCH_SIZE child: rc 1"}, "pmt::gram_mid_kernel<true>")
     assert roof["measured_in_this_run"] is False and "rc 1" in roof["traffic_source"]
     if roof["traffic"] is not None:                                          # the committed replay, labelled as such
         assert roof["traffic"] == pytest.approx(roof["traffic_read"] + roof["traffic_write"]) and "replay" in roof["traffic_source"]
@@ -144,12 +144,12 @@ def test_counter_csv_reduction(tmp_path):
     p = tmp_path / "x_counter_collection.csv"
     rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
     for i, v in enumerate([999.0, 100.0, 102.0, 104.0]):
-        rows.append('%d,"void pmt::gram_sk_kernel<2, 16, 2, 0, false>(pmt::SKArgs)",FETCH_SIZE,%r' % (i, v))
+        rows.append('%d,"void pmt::gram_mid_kernel<true>(pmt::MidArgs)",FETCH_SIZE,%r' % (i, v))
     rows.append('9,"void pmt::affine_tile_kernel<1>(pmt::AffArgs)",FETCH_SIZE,50.0')
     rows.append('10,"void pmt::fill_uniform_kernel(double*)",FETCH_SIZE,7.0')
     p.write_text("\n".join(rows) + "\n")
     got = bench.reduce_counter_csv(str(p), 3)
-    assert got == {"gram_sk_kernel": pytest.approx(102.0), "affine_tile_kernel<VAT>": pytest.approx(50.0)}
+    assert got == {"gram_mid_kernel": pytest.approx(102.0), "affine_tile_kernel<VAT>": pytest.approx(50.0)}
 
 
 def test_stdout_carries_the_json_line_only(tmp_path):

@@ -122,9 +122,9 @@ def config_c3(torch, P, _lib, steps):
     _lib.call("pmt_profile_enable", 0)
     out["ms_per_step"] = out["staged_upload"]["ms_per_step"]
     out["kernels"] = kern
-    g = kern.get("gram_sk_kernel")
+    g = kern.get("gram_mid_kernel") or kern.get("gram_sk_kernel")
     if g:
-        out["roofline"] = mfma_roofline("gram_sk_kernel", g["avg_ms"], 4096.0 * 4096 * 4097)
+        out["roofline"] = mfma_roofline("gram_mid_kernel" if kern.get("gram_mid_kernel") else "gram_sk_kernel", g["avg_ms"], 4096.0 * 4096 * 4097)
     v = kern.get("affine_tile_kernel<VAT>")
     if v:
         out["roofline_inequality_pack"] = hbm_roofline("affine_tile_kernel<VAT>", v["avg_ms"], 32.0 * 512 * 4096)

@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
-DOMINANT = "gram_sk_kernel"
+DOMINANT = "gram_mid_kernel"
 
 
 def pmc_replay(prefix):
@@ -25,7 +25,7 @@ def pmc_replay(prefix):
 
 
 
-PMC_KERNELS = {"gram_sk_kernel": "gram_sk_kernel<", "gram_sk_fixup_kernel": "gram_sk_fixup_kernel", "gram_linear_kernel": "gram_linear_kernel",
+PMC_KERNELS = {"gram_mid_kernel": "gram_mid_kernel<", "gram_sk_kernel": "gram_sk_kernel<", "gram_sk_fixup_kernel": "gram_sk_fixup_kernel", "gram_linear_kernel": "gram_linear_kernel",
                "affine_tile_kernel<VAT>": "affine_tile_kernel<1"}
 
 

@@ -59,7 +59,7 @@ det = json.load(open(out + "/bench_under_rocprof_detail.json"))
 first = det["config_detail"]["setup_spinup_steps"] + bu["warmup"]
 lines = ["rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-pmc`, per-launch durations of the TIMED REGION (launches %d..%d of each kernel):"
          % (first, first + bu["steps"] - 1)]
-for name in ("gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
+for name in ("gram_mid_kernel", "gram_sk_kernel", "gram_sk_fixup_kernel", "affine_tile_kernel<1"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in tr if name in r["Kernel_Name"]]
     reg = d[first:first + bu["steps"]]
     if reg:
