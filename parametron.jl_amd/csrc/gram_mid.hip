@@ -136,9 +136,25 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
 #ifdef PMT_TUNING
     if (const char *e = getenv("PMT_MID_S")) { const int v = atoi(e); if (v > 0) s = std::min(v, maxs); }      // (measurement builds only)
 #endif
+    // UNSPLIT off-diagonal tiles in several rounds (config 2: 2016 of them + 64 diagonal ones = 8.1 rounds of 256): the diagonal tiles come
+    // last in the workgroup order — split, their chunks fill the CUs the last off-diagonal round leaves free and what remains is short
+    // rounds, instead of a ninth round of 0.69 tile times for 32 workgroups.  The chunk count with the shortest estimated tail.
+    int sdiag = sd(s);
+    if (s == 1 && p.n_off + p.nb > PMT_MID_G) {
+        const double t_off = PMT_MID_GROUP_US * (double)cdiv(ngroups, 4) + 5.0;
+        const int rem = p.n_off % PMT_MID_G, free_cus = rem ? PMT_MID_G - rem : 0;
+        double best_tail = 1e300;
+        for (int c = 1; c <= std::min(maxs, MFG); ++c) {
+            const double t_d = PMT_MID_GROUP_US * 0.69 * (double)cdiv(cdiv(ngroups, c), 4) + 5.0 + (c > 1 ? 1.0 : 0.0);
+            const int64_t inside = (int64_t)free_cus * (int64_t)(t_off / t_d);       // chunks done beside the last off-diagonal round
+            const int64_t left = std::max<int64_t>(0, (int64_t)p.nb * c - inside);
+            const double tail = (double)cdiv(left, PMT_MID_G) * t_d + (c > 1 ? mid_fold_us(c) : 0.0);
+            if (tail < best_tail) { best_tail = tail; sdiag = c; }
+        }
+    }
     p.gpc_off = (int)cdiv(ngroups, s);
     p.s_off = (int)cdiv(ngroups, p.gpc_off);
-    p.gpc_diag = (int)cdiv(ngroups, sd(s));
+    p.gpc_diag = (int)cdiv(ngroups, sdiag);
     p.s_diag = (int)cdiv(ngroups, p.gpc_diag);
     p.wgs = p.n_off * p.s_off + p.nb * p.s_diag + 1;
     return p;
