@@ -148,20 +148,21 @@ static bool constant_chained(int64_t rows, int64_t cols) {
 #ifndef PMT_MID_BIGCOLS
 #define PMT_MID_BIGCOLS 4096
 #endif
-#ifndef PMT_MID_BIGROWS
-#define PMT_MID_BIGROWS 8192
+#ifndef PMT_MID_BIGEL
+#define PMT_MID_BIGEL ((int64_t)1 << 29)      // (the fast load path needs the matrix within 4 GiB)
 #endif
-// 2049 .. 4096 columns (config 2), round 6c: with the pinned instruction stream the one launch beats the stream-K node (contraction + fix-up,
-// q and the constant on a side stream) up to 8192 rows — 4096 x 4096 1205 -> 1096-1126 us (0.73 -> 0.78-0.80 of the f64 matrix peak), 2048 x
-// 4096 661 -> 599, 4096 x 3072 718 -> 644, 4096 x 2304 461 -> 384, 8192 x 2560 1065 -> 910, 1000 x 3000 246 -> 191, 8192 x 4096 2340 -> 2309;
-// beyond, the unsplit tiles' rounds of 256 workgroups cost more than they gain (16384 x 4096 4600 -> 4884, 32768 x 3072 5324 -> 5681).  A
+// 2049 .. 4096 columns (config 2), round 6c: with the pinned instruction stream, the tiles in super-tile order and the partial round / the
+// diagonal tiles split (gram_mid.hip: mid_plan) the one launch beats the stream-K node (contraction + fix-up, q and the constant on a side
+// stream) at every row count measured — 4096 x 4096 1205 -> 1069-1092 us (0.73 -> 0.80-0.82 of the f64 matrix peak), 2048 x 4096 661 -> 573,
+// 4096 x 3072 718 -> 630, 4096 x 2304 461 -> 373, 8192 x 2560 1065 -> 839, 1000 x 3000 246 -> 191, 8192 x 4096 2340 -> 2062, 16384 x 4096
+// 4616 -> 4405, 32768 x 3072 5338 -> 4863, 131072 x 2560 17877 -> 15256, 20000 x 3500 4878 -> 3859; 65536 x 4096 18287 -> 18444 is a tie.  A
 // STAGED host delivery of such a shape (config 2's host_csc hand-off: column bands leave while the contraction runs) keeps the stream-K
 // kernel — run_quad_gram — with the constant in this form's order, so that pmt_quad_gram_constant_order holds for every call form.
 bool gram_mid_big(int64_t rows, int64_t cols) {
 #ifdef PMT_NO_MID
     return false;
 #endif
-    return cols > 16 * 128 && cols <= PMT_MID_BIGCOLS && rows >= 1 && rows <= PMT_MID_BIGROWS;
+    return cols > 16 * 128 && cols <= PMT_MID_BIGCOLS && rows >= 1 && rows * cols < PMT_MID_BIGEL;
 }
 bool gram_mid_applies(int64_t rows, int64_t cols) {
 #ifdef PMT_NO_MID

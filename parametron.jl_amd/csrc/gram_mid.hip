@@ -99,12 +99,13 @@ struct MidArgs {
     int nb;                                  // 64-column panels
     int n_off, s_off, s_diag;                // strictly upper tiles, row chunks of one, row chunks of a diagonal tile
     int gpc_off, gpc_diag;                   // 8-row groups per chunk
+    int n_tail, s_tail, gpc_tail;            // the LAST n_tail strictly upper tiles (in the order they are walked) in s_tail chunks instead (mid_plan)
     double *ws;                              // one MSTRIDE slot per workgroup
     unsigned *counters;                      // one per tile, zero between launches (the last arriver re-arms its tile's)
     int xcd;                                 // workgroup ids in the XCD-aware order (gram_mid_kernel)
 };
 
-struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, wgs; };
+struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, n_tail, s_tail, gpc_tail, wgs; };
 
 // Row chunks per tile, from (rows, cols) alone (the summation order depends on them).  s chunks per off-diagonal tile and ceil(5 s / 8) per
 // diagonal one (88 against 128 MFMAs per 8-row group) make W workgroups that run one per CU in ceil(W / PMT_MID_G) rounds of
@@ -136,27 +137,52 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
 #ifdef PMT_TUNING
     if (const char *e = getenv("PMT_MID_S")) { const int v = atoi(e); if (v > 0) s = std::min(v, maxs); }      // (measurement builds only)
 #endif
-    // UNSPLIT off-diagonal tiles in several rounds (config 2: 2016 of them + 64 diagonal ones = 8.1 rounds of 256): the diagonal tiles come
-    // last in the workgroup order — split, their chunks fill the CUs the last off-diagonal round leaves free and what remains is short
-    // rounds, instead of a ninth round of 0.69 tile times for 32 workgroups.  The chunk count with the shortest estimated tail.
-    int sdiag = sd(s);
-    if (s == 1 && p.n_off + p.nb > PMT_MID_G) {
-        const double t_off = PMT_MID_GROUP_US * (double)cdiv(ngroups, 4) + 5.0;
-        const int rem = p.n_off % PMT_MID_G, free_cus = rem ? PMT_MID_G - rem : 0;
-        double best_tail = 1e300;
-        for (int c = 1; c <= std::min(maxs, MFG); ++c) {
-            const double t_d = PMT_MID_GROUP_US * 0.69 * (double)cdiv(cdiv(ngroups, c), 4) + 5.0 + (c > 1 ? 1.0 : 0.0);
-            const int64_t inside = (int64_t)free_cus * (int64_t)(t_off / t_d);       // chunks done beside the last off-diagonal round
-            const int64_t left = std::max<int64_t>(0, (int64_t)p.nb * c - inside);
-            const double tail = (double)cdiv(left, PMT_MID_G) * t_d + (c > 1 ? mid_fold_us(c) : 0.0);
-            if (tail < best_tail) { best_tail = tail; sdiag = c; }
+    // UNSPLIT off-diagonal tiles in several rounds of PMT_MID_G workgroups (config 2: 2016 of them + 64 diagonal ones = 8.1 rounds): what the
+    // rounds do not divide is split instead of costing a whole tile time on a few CUs —
+    //   * the LAST n_off % G off-diagonal tiles (the partial round) in s_tail chunks each (4096 x 3072: 1128 tiles = 4 rounds + 104 tiles,
+    //     152 CUs idle for a tile time; in two chunks they are one round of half the length);
+    //   * the diagonal tiles (last in the workgroup order) in chunks that fill the CUs the last round leaves free, the rest short rounds
+    //     (config 2: instead of a ninth round of 0.69 tile times for 32 workgroups).
+    // Both counts by the shortest estimated tail; compared with the best uniform split above.
+    int sdiag = sd(s), ntail = 0, stail = 1;
+    if (p.n_off + p.nb > PMT_MID_G) {
+        auto wg_us = [&](int c, double w) { return PMT_MID_GROUP_US * w * (double)cdiv(cdiv(ngroups, c), 4) + 5.0 + (c > 1 ? 1.0 : 0.0); };
+        const int rem = p.n_off % PMT_MID_G;
+        int ct = 1;
+        double tail_off = 0.0;
+        if (rem) {
+            tail_off = 1e300;
+            for (int c = 1; c <= std::min(maxs, MFG); ++c) {
+                const double t = (double)cdiv((int64_t)rem * c, PMT_MID_G) * wg_us(c, 1.0) + (c > 1 ? mid_fold_us(c) : 0.0);
+                if (t < tail_off) { tail_off = t; ct = c; }
+            }
         }
+        const int last = rem ? (int)(((int64_t)rem * ct) % PMT_MID_G) : 0, free_cus = last ? PMT_MID_G - last : 0;
+        const double t_last = rem ? wg_us(ct, 1.0) : wg_us(1, 1.0);
+        int cd = 1;
+        double tail_diag = 1e300;
+        for (int c = 1; c <= std::min(maxs, MFG); ++c) {
+            const double t_d = wg_us(c, 0.69);
+            const int64_t inside = (int64_t)free_cus * (int64_t)(t_last / t_d);       // chunks done beside the last off-diagonal round
+            const int64_t left = std::max<int64_t>(0, (int64_t)p.nb * c - inside);
+            const double t = (double)cdiv(left, PMT_MID_G) * t_d + (c > 1 ? mid_fold_us(c) : 0.0);
+            if (t < tail_diag) { tail_diag = t; cd = c; }
+        }
+        const double t1 = (double)(p.n_off / PMT_MID_G) * wg_us(1, 1.0) + tail_off + tail_diag;
+        if (s == 1 || t1 < best_t) { s = 1; sdiag = cd; ntail = ct > 1 ? rem : 0; stail = ct > 1 ? ct : 1; }
     }
+#ifdef PMT_TUNING
+    if (const char *e = getenv("PMT_MID_TAIL")) { if (atoi(e) == 0) { ntail = 0; stail = 1; } }          // (measurement builds only)
+#endif
     p.gpc_off = (int)cdiv(ngroups, s);
     p.s_off = (int)cdiv(ngroups, p.gpc_off);
     p.gpc_diag = (int)cdiv(ngroups, sdiag);
     p.s_diag = (int)cdiv(ngroups, p.gpc_diag);
-    p.wgs = p.n_off * p.s_off + p.nb * p.s_diag + 1;
+    p.n_tail = ntail;
+    p.gpc_tail = (int)cdiv(ngroups, stail);
+    p.s_tail = ntail ? (int)cdiv(ngroups, p.gpc_tail) : 1;
+    if (p.s_tail <= 1) { p.n_tail = 0; p.s_tail = 1; p.gpc_tail = ngroups; }
+    p.wgs = (p.n_off - p.n_tail) * p.s_off + p.n_tail * p.s_tail + p.nb * p.s_diag + 1;
     return p;
 }
 
@@ -729,20 +755,23 @@ __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
     // on neighbouring tiles (shared 64-column panels), so a matrix larger than one L2 is still read mostly out of L2 — numbered tile-major
     // (id = tile * S + chunk) every XCD touched every row chunk of every panel and 4096 x 1024 ran out of the Infinity Cache at 1.76 us per
     // 8-row group instead of 1.15 (profiles/r06_gram_mid.txt).
-    const int noff = g.n_off * g.s_off;
+    const int nbody = g.n_off - g.n_tail, wbody = nbody * g.s_off, noff = wbody + g.n_tail * g.s_tail;
     if (id < noff) {
-        const int k = g.xcd ? mid_xcd_rank(id, 0, noff) : (id % g.s_off) * g.n_off + id / g.s_off;
-        const int chunk = k / g.n_off;
-        int t = k - chunk * g.n_off;
-        int jb, kb;
+        // body tiles (ranks 0 .. nbody - 1 of the walk) in s_off chunks, then the tail tiles in s_tail chunks: chunk-major inside each part
+        const bool tail = id >= wbody;
+        const int base = tail ? wbody : 0, ntile = tail ? g.n_tail : nbody, nch = tail ? g.s_tail : g.s_off;
+        const int k = g.xcd ? mid_xcd_rank(id, base, ntile * nch) : ((id - base) % nch) * ntile + (id - base) / nch;
+        const int chunk = k / ntile;
+        const int rank = (tail ? nbody : 0) + (k - chunk * ntile);          // the tile's place in the walk: its workspace slots and its counters
+        int t = rank, jb, kb;
         if (PMT_MID_SUPER && g.xcd) mid_tile_of(t, g.nb, jb, kb);
         else {
             kb = 1;
             while (t >= kb) { t -= kb; ++kb; }                     // strictly upper tiles, column by column: (0,1), (0,2), (1,2), (0,3), ..
             jb = t;
         }
-        const int tile = kb * (kb - 1) / 2 + jb;                   // (workspace slots and counters: the column-by-column number)
-        mid_body<false, FAST>(g, sh, tid, jb, kb, chunk, g.s_off, g.gpc_off, tile * g.s_off, g.counters + tile * MCNT);
+        const int first = tail ? wbody + (rank - nbody) * g.s_tail : rank * g.s_off;
+        mid_body<false, FAST>(g, sh, tid, jb, kb, chunk, nch, tail ? g.gpc_tail : g.gpc_off, first, g.counters + rank * MCNT);
         return;
     }
     if (id < noff + g.nb * g.s_diag) {
@@ -784,6 +813,7 @@ int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, co
     g.xvar = xvar; g.varmap = varmap; g.moi = moi; g.out_quad = reinterpret_cast<QT *>(out_quad); g.out_csc = out_csc; g.alpha = alpha;
     g.out_lin = reinterpret_cast<LT *>(out_lin); g.out_const = out_const;
     g.nb = p.nb; g.n_off = p.n_off; g.s_off = p.s_off; g.s_diag = p.s_diag; g.gpc_off = p.gpc_off; g.gpc_diag = p.gpc_diag;
+    g.n_tail = p.n_tail; g.s_tail = p.s_tail; g.gpc_tail = p.gpc_tail;
     g.ws = reinterpret_cast<double *>(workspace); g.counters = counters;
     g.xcd = PMT_MID_XCD && rows * cols * 8 > ((int64_t)4 << 20);      // (a matrix that fits one L2 is all there on every XCD: 1024 x 512 23.0 against 25.6 us)
     const bool fast = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0 &&

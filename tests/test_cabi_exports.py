@@ -251,11 +251,12 @@ def test_constant_order_is_host_arithmetic(lib):
         o, g, s = C.c_int(), C.c_int(), C.c_int()
         lib.call("pmt_quad_gram_constant_order", r, n, C.byref(o), C.byref(g), C.byref(s))
         return o.value, g.value, s.value
-    # config 2 and its neighbours (2049 .. 4096 columns, at most 8192 rows): the one-launch form on 64 x 64 tiles (round 6c: gram_mid_big), order 5
+    # config 2 and its neighbours (2049 .. 4096 columns, below 2^29 elements): the one-launch form on 64 x 64 tiles (round 6c: gram_mid_big), order 5
     assert order(4096, 4096) == (5, 1, 512) and order(1000, 2049)[0] == 5 and order(8192, 4096)[0] == 5 and order(4096, 2304)[0] == 5
+    assert order(8193, 4096)[0] == 5 and order(65536, 4096)[0] == 5 and order(131072, 2560)[0] == 5
     assert order(8, 8) == (0, 1, 0) and order(64, 1)[0] == 0 and order(256, 1)[0] == 3   # tiny shapes (the small-plan node, at most 64 rows): sequential
     # beyond (more rows, more columns): the stream-K node, the constant by the cost model (sequential where the contraction hides its chain)
-    assert order(8193, 4096) == (1, 2048, 0) and order(4096, 4097)[0] == 0 and order(1000, 5000)[0] == 0 and order(16384, 4096)[0] == 1
+    assert order(131072, 4096) == (1, 2048, 0) and order(4096, 4097)[0] == 0 and order(1000, 5000)[0] == 0 and order(16384, 4100)[0] == 1
     # up to 2048 columns the fused tall forms, whatever the row count: one tile (order 2; 3 = sixteen row-pair lanes, <= 16 columns) ..
     assert order(80, 96) == (2, 3, 32) and order(1000, 128) == (2, 32, 32) and order(4096, 128) == (2, 64, 32)
     o, g, s = order(1 << 20, 128)

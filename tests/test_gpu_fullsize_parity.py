@@ -43,7 +43,7 @@ def _sample_pairs(rng, n, count):
 # expect_order: 0 sequential constant (hidden behind the contraction: the stream-K node beyond 4096 columns / 8192 rows), 1 chained (long vectors, or few columns: the cost model of
 # gram.hip), 2 the fused tall form (gram_tall.hip: n <= 128, r >= 1024 — one pass over A for Q, q and the constant — or the diagonal tiles of
 # a wide tall matrix beyond what the one-launch form takes), 5 the one-launch form of wide shapes on 64 x 64 tiles (gram_mid.hip: 129 .. 2048 columns; gram.hip: gram_mid_applies)
-@pytest.mark.parametrize("r,n,count,expect_order", [(4096, 4096, 10000, 5), (16384, 1024, 6000, 5), (4090, 1000, 4000, 5), (3000, 2304, 3000, 5), (9000, 2100, 2500, 1), (5000, 4100, 2500, 0), (300, 300, 2000, 5), (100, 1000, 3000, 5), (4096, 512, 3000, 5), (1024, 512, 3000, 5), (1000, 2048, 3000, 5), (33, 129, 600, 5), (2000, 1000, 3000, 5), (517, 391, 2000, 5), (131072, 256, 3000, 5), (262144, 512, 3000, 5), (100000, 384, 2500, 5), (70000, 640, 2500, 5), (300000, 256, 2000, 2), (8192, 512, 3000, 5), (65536, 1024, 3000, 5), (2048, 1536, 3000, 5), (40, 520, 2000, 5), (4096, 2048, 3000, 5), (380000, 129, 1500, 2),
+@pytest.mark.parametrize("r,n,count,expect_order", [(4096, 4096, 10000, 5), (16384, 1024, 6000, 5), (4090, 1000, 4000, 5), (3000, 2304, 3000, 5), (9000, 2100, 2500, 5), (5000, 4100, 2500, 0), (9000, 4100, 2500, 1), (300, 300, 2000, 5), (100, 1000, 3000, 5), (4096, 512, 3000, 5), (1024, 512, 3000, 5), (1000, 2048, 3000, 5), (33, 129, 600, 5), (2000, 1000, 3000, 5), (517, 391, 2000, 5), (131072, 256, 3000, 5), (262144, 512, 3000, 5), (100000, 384, 2500, 5), (70000, 640, 2500, 5), (300000, 256, 2000, 2), (8192, 512, 3000, 5), (65536, 1024, 3000, 5), (2048, 1536, 3000, 5), (40, 520, 2000, 5), (4096, 2048, 3000, 5), (380000, 129, 1500, 2),
                                                      (1 << 20, 128, 1500, 2), (8192, 128, 3000, 2), (100003, 100, 2000, 2), (5000, 17, 150, 2), (50016, 72, 1500, 2), (60000, 96, 2000, 2), (40001, 112, 2000, 2), (33000, 65, 1500, 2), (2048, 81, 1500, 2), (333, 97, 1500, 2),
                                                      (1000, 128, 2000, 2), (100, 100, 800, 2), (500, 100, 800, 2), (200, 50, 400, 2), (700, 7, 28, 3),
                                                      # narrow tall shapes (gram_stream_kernel<1 | 2 | 4>, order 4): whole panels and ragged ones
