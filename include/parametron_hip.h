@@ -172,8 +172,9 @@ int pmt_quad_expand_f64(int64_t rows,
  *                        forms' per-workgroup order — every one within (rows / 2048 + 2048) * eps / 2 of the exact sum.
  * Shapes of up to 2048 columns take the fused forms of csrc/gram_tall.hip whatever the row count (the triangle of every diagonal
  * 128-column tile, out_lin and out_const from ONE pass over A; the strictly upper tiles from one stream-K launch); tiny shapes recorded
- * into a plan are nodes of its one-launch interpreter (csrc/small.hip); wider shapes (config 2) the stream-K node with the two
- * reductions on a side stream.
+ * into a plan are nodes of its one-launch interpreter (csrc/small.hip); 2049 .. 4096 columns below 2^29 elements (config 2) the one-launch
+ * form of csrc/gram_mid.hip (round 6c; the staged `_deliver_` entry points keep the stream-K kernel there, with out_lin within 1e-13 of the
+ * plain call's and out_const in the same order); wider or larger shapes the stream-K node with the two reductions on a side stream.
  * A is read as lda x cols doubles: a kernel may read (and ignore) the padding rows rows .. lda - 1 of a column, the last one included.
  * Requires xvar strictly increasing (distinct variables in sorted order — what Variable(model) yields);
  * moi == 0 keeps native indices (no varmap) but the same coefficients as the MOI form are NOT produced:
@@ -182,10 +183,10 @@ int pmt_quad_expand_f64(int64_t rows,
 size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
 /* The summation order of the node's constant c'c for an r x n problem — fixed by (rows, cols) alone, reported so that a caller (and the
  * parity tests) can restate it:
- *   order 0  sequential, the reference's left-to-right sum (src/functions.jl:574), bit for bit: tiny shapes, and beyond 2048 columns
- *            where the contraction hides the one-wave chain (config 2)
- *   order 1  `groups` = 2048 interleaved chains (chain t adds rows t, t + 2048, .. in order), chain totals added left to right: beyond 2048
- *            columns with rows > 8192, or a sequential chain that would take half as long as the contraction beside it or longer
+ *   order 0  sequential, the reference's left-to-right sum (src/functions.jl:574), bit for bit: tiny shapes, and the stream-K node (beyond
+ *            4096 columns or from 2^29 elements) where the contraction hides the one-wave chain
+ *   order 1  `groups` = 2048 interleaved chains (chain t adds rows t, t + 2048, .. in order), chain totals added left to right: the stream-K
+ *            node with rows > 8192, or a sequential chain that would take half as long as the contraction beside it or longer
  *   order 2  the fused forms (cols <= 2048; csrc/gram_tall.hip): `groups` workgroups, workgroup g takes the stages g, g + groups, .. of
  *            `stage_rows` rows; per stage eight row-pair lanes (rows 16 j + 2 p, + 1) add their squares in row order, an 8-lane tree
  *            ((0+4)+(2+6))+((1+5)+(3+7)) closes a workgroup, the workgroups are added in 16 interleaved slices, then the slices
@@ -194,8 +195,8 @@ size_t pmt_quad_gram_workspace_bytes(int64_t rows, int64_t cols);
  *   order 4  narrow panels, cols <= 64, from 32768 rows (gram_stream_kernel): iterations of `stage_rows` rows dealt out to the 4 * `groups` WAVES (wave
  *            4 g + w: iterations 4 g + w, + 4 * groups, ..); contraction slot k of a wave adds rows 8 i + 2 k, + 1 of its iterations in order;
  *            slots (0 + 2) + (1 + 3); the four waves of a workgroup in order; workgroups in 16 interleaved slices, then the slices
- *   order 5  wide shapes in one launch (gram_mid.hip: 129 .. 2048 columns — from 384 columns everything below 2^29 elements, below 384 / 320 / 193
- *            columns up to 2^27 / 2^26 / 2^25; gram.hip: gram_mid_applies): `stage_rows` = 512 strided chains (thread
+ *   order 5  wide shapes in one launch (gram_mid.hip: 129 .. 4096 columns — from 384 columns everything below 2^29 elements, below 384 / 320 / 193
+ *            columns up to 2^27 / 2^26 / 2^25; gram.hip: gram_mid_applies — config 2 since round 6c): `stage_rows` = 512 strided chains (thread
  *            t adds rows t, t + 512, ..), a shuffle tree (32, 16, .., 1) per 64 threads, the eight results in order
  * (tests/gpu_util.py restates every order bit for bit.)
  * Every order is within (rows / 2048 + 2048) * eps / 2 relative of the exact sum for same-signed terms: far inside the 1e-12 parity bar. */
