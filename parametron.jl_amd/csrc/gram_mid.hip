@@ -44,6 +44,9 @@
 #ifndef PMT_MID_SUPER
 #define PMT_MID_SUPER 1            // XCD-aware order: the tiles of a chunk in 8 x 8 super-tiles (mid_tile_of)
 #endif
+#ifndef PMT_MID_SB
+#define PMT_MID_SB 8               // edge of a super-tile in tiles
+#endif
 #ifndef PMT_MID_FB
 #define PMT_MID_FB 4               // chunks whose partials the last arriver loads together (64 loads per thread: a wave may have 63 outstanding; 8, or 16-byte loads: no faster)
 #endif
@@ -729,16 +732,17 @@ __device__ __forceinline__ int mid_xcd_rank(int id, int base, int n) {
 // row (on the diagonal: column by column).  32 consecutive tiles — what an XCD runs at a time — are then 4 row panels x 8 column panels
 // (12 panels through its L2) instead of one column panel with 32 row panels (33): config 2 moved 4.39 GB per launch over the fabric.
 __device__ __forceinline__ void mid_tile_of(int t, int nb, int &jb, int &kb) {
-    const int nsb = (nb + 7) >> 3;
+    constexpr int SB = PMT_MID_SB;
+    const int nsb = (nb + SB - 1) / SB;
     for (int K = 0; K < nsb; ++K) {
-        const int wK = min(8, nb - 8 * K);
+        const int wK = min(SB, nb - SB * K);
         for (int J = 0; J <= K; ++J) {
-            const int cnt = J < K ? 8 * wK : wK * (wK - 1) / 2;
+            const int cnt = J < K ? SB * wK : wK * (wK - 1) / 2;
             if (t >= cnt) { t -= cnt; continue; }
-            if (J < K) { jb = 8 * J + t / wK; kb = 8 * K + t % wK; return; }
+            if (J < K) { jb = SB * J + t / wK; kb = SB * K + t % wK; return; }
             int kk = 1;
             while (t >= kk) { t -= kk; ++kk; }
-            jb = 8 * K + t; kb = 8 * K + kk;
+            jb = SB * K + t; kb = SB * K + kk;
             return;
         }
     }
