@@ -53,3 +53,8 @@ for a, bq, nm in ((2, 3, "partial out + count"), (3, 4, "fold"), (4, 5, "tile ->
     dd = us[la, bq] - us[la, a]
     if len(dd):
         print("last arrivers: %-20s median %.2f max %.2f us" % (nm, np.nanmedian(dd), np.nanmax(dd)))
+# dispatch gap: the i-th workgroup to START beyond the first 256 takes the CU the i-th workgroup to END has left
+st, en = np.sort(us[:, 0]), np.sort(np.nanmax(us, axis=1))
+if len(st) > 256:
+    gap = st[256:] - en[:len(st) - 256]
+    print("workgroup end -> next workgroup's start on the freed CU: median %.2f us, min %.2f, max %.2f (n = %d)" % (np.median(gap), gap.min(), gap.max(), len(gap)))
