@@ -44,6 +44,9 @@
 #ifndef PMT_MID_SUPER
 #define PMT_MID_SUPER 1            // XCD-aware order: the tiles of a chunk in 8 x 8 super-tiles (mid_tile_of)
 #endif
+#ifndef PMT_MID_PERSIST
+#define PMT_MID_PERSIST 1          // launches of at least two rounds of work items run as PMT_MID_G persistent workgroups (gram_mid_kernel)
+#endif
 #ifndef PMT_MID_SB
 #define PMT_MID_SB 8               // edge of a super-tile in tiles
 #endif
@@ -106,6 +109,8 @@ struct MidArgs {
     double *ws;                              // one MSTRIDE slot per workgroup
     unsigned *counters;                      // one per tile, zero between launches (the last arriver re-arms its tile's)
     int xcd;                                 // workgroup ids in the XCD-aware order (gram_mid_kernel)
+    int persist, total;                      // PMT_MID_G persistent workgroups walk the `total` work items (gram_mid_kernel)
+    unsigned *tickets;                       // 8 per-XCD tickets + the count of workgroups that have left; zero between launches
 };
 
 struct MidPlan { int nb, n_off, s_off, s_diag, gpc_off, gpc_diag, n_tail, s_tail, gpc_tail, wgs; };
@@ -749,11 +754,9 @@ __device__ __forceinline__ void mid_tile_of(int t, int nb, int &jb, int &kb) {
     jb = 0; kb = 1;
 }
 
+// one work item of the launch: (tile, chunk) number `id`, or the constant's (the last one)
 template <bool FAST>
-__global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
-    __shared__ double sh[MSH];
-    const int tid = threadIdx.x;
-    int id = blockIdx.x;
+__device__ __forceinline__ void mid_item(const MidArgs &g, double *sh, int tid, int id) {
     // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own 4 MB L2.  The (chunk, tile) list is walked
     // CHUNK-major and cut into 8 contiguous pieces, one per XCD: the 32 workgroups an XCD runs at a time work on the same rows of A and
     // on neighbouring tiles (shared 64-column panels), so a matrix larger than one L2 is still read mostly out of L2 — numbered tile-major
@@ -787,6 +790,37 @@ __global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
     mid_constant(g, sh, tid);
 }
 
+// A launch of more than PMT_MID_G work items runs PERSISTENT (round 6c): PMT_MID_G workgroups, each walking items until none is left,
+// instead of one workgroup per item — between two workgroups on a CU lay 2.5 us (the first one's stores drain, the dispatcher starts the
+// next: tools/mid_trace.py, 8 times per CU at config 2); in a loop the next item's loads go out while the stores of the last drain.  The
+// items keep their XCD: a workgroup with blockIdx % 8 = x takes the ids x, x + 8, x + 16, .. in order through ticket word x (what the
+// hardware's round-robin over the XCDs gives a launch of one workgroup per item).  Nobody waits for anybody; the last workgroup to leave
+// re-arms the tickets.
+template <bool FAST>
+__global__ __launch_bounds__(256, PMT_MID_WPS) void gram_mid_kernel(MidArgs g) {
+    __shared__ double sh[MSH];
+    __shared__ int next_id;
+    const int tid = threadIdx.x;
+    const int x = blockIdx.x & 7, per = gridDim.x >> 3;
+    int id = blockIdx.x;
+    for (;;) {
+        mid_item<FAST>(g, sh, tid, id);
+        if (!g.persist) return;                                    // (one workgroup per item)
+        __syncthreads();                                           // the item's last LDS reads, and next_id's last readers
+        if (tid == 0) next_id = x + 8 * (per + (int)__hip_atomic_fetch_add(g.tickets + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        id = next_id;
+        if (id >= g.total) break;
+    }
+    if (tid == 0) {
+        const unsigned gone = __hip_atomic_fetch_add(g.tickets + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(g.tickets + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // c'c alone, in the same order 5 (the staged host delivery of a shape the one-launch form otherwise takes: gram.hip)
 __global__ __launch_bounds__(256) void gram_mid_constant_kernel(MidArgs g) {
     __shared__ double sh[8];
@@ -804,7 +838,7 @@ size_t gram_mid_workspace_bytes(int64_t rows, int64_t cols) {
     const MidPlan p = mid_plan(rows, cols);
     return sizeof(double) * (size_t)p.wgs * MSTRIDE;
 }
-int gram_mid_counters(int64_t cols) { const int nb = (int)cdiv(cols, MT); return MCNT * (nb * (nb + 1) / 2); }
+int gram_mid_counters(int64_t cols) { const int nb = (int)cdiv(cols, MT); return MCNT * (nb * (nb + 1) / 2) + 16; }      // (+ the tickets)
 
 // the whole node in one launch; `counters`: gram_mid_counters(cols) zeroed words owned by the calling stream (gram.hip: SideStream)
 int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, const int64_t *xvar, const double *b, int sign, int moi,
@@ -822,8 +856,12 @@ int launch_gram_mid(const double *A, int64_t lda, int64_t rows, int64_t cols, co
     g.xcd = PMT_MID_XCD && rows * cols * 8 > ((int64_t)4 << 20);      // (a matrix that fits one L2 is all there on every XCD: 1024 x 512 23.0 against 25.6 us)
     const bool fast = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0 &&
                       (uint64_t)lda * (uint64_t)cols * 8 < (1ull << 32);
-    if (fast) PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<true>), dim3((unsigned)p.wgs), dim3(256), 0, s, g);
-    else PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<false>), dim3((unsigned)p.wgs), dim3(256), 0, s, g);
+    g.total = p.wgs;
+    g.persist = PMT_MID_PERSIST && p.wgs >= 2 * PMT_MID_G;
+    g.tickets = counters + gram_mid_counters(cols) - 16;
+    const unsigned grid = g.persist ? (unsigned)PMT_MID_G : (unsigned)p.wgs;
+    if (fast) PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<true>), dim3(grid), dim3(256), 0, s, g);
+    else PMT_LAUNCH_NAMED("gram_mid_kernel", (gram_mid_kernel<false>), dim3(grid), dim3(256), 0, s, g);
     return check_launch("gram_mid_kernel");
 }
 
