@@ -38,6 +38,9 @@
 #ifndef PMT_MID_GROUP_US
 #define PMT_MID_GROUP_US 1.15      // the cost model's time of one 8-row group per wave (mid_plan)
 #endif
+#ifndef PMT_MID_TAIL_US
+#define PMT_MID_TAIL_US 0.95       // the same in the plan of unsplit tiles with split tails (mid_plan)
+#endif
 #ifndef PMT_MID_XCD
 #define PMT_MID_XCD 1              // 0: workgroup ids tile-major (id = tile * S + chunk) whatever the size
 #endif
@@ -154,7 +157,9 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
     // Both counts by the shortest estimated tail; compared with the best uniform split above.
     int sdiag = sd(s), ntail = 0, stail = 1;
     if (p.n_off + p.nb > PMT_MID_G) {
-        auto wg_us = [&](int c, double w) { return PMT_MID_GROUP_US * w * (double)cdiv(cdiv(ngroups, c), 4) + 5.0 + (c > 1 ? 1.0 : 0.0); };
+        // (0.95 us per 8-row group and wave: the pinned loop's time in these long workgroups, tools/mid_trace.py — config 2 1101 -> 1085 us
+        // against the uniform model's 1.15, which stays where it decides the summation order of the single-round shapes)
+        auto wg_us = [&](int c, double w) { return PMT_MID_TAIL_US * w * (double)cdiv(cdiv(ngroups, c), 4) + 5.0 + (c > 1 ? 1.0 : 0.0); };
         const int rem = p.n_off % PMT_MID_G;
         int ct = 1;
         double tail_off = 0.0;
@@ -177,7 +182,8 @@ static MidPlan mid_plan(int64_t rows, int64_t cols) {
             if (t < tail_diag) { tail_diag = t; cd = c; }
         }
         const double t1 = (double)(p.n_off / PMT_MID_G) * wg_us(1, 1.0) + tail_off + tail_diag;
-        if (s == 1 || t1 < best_t) { s = 1; sdiag = cd; ntail = ct > 1 ? rem : 0; stail = ct > 1 ? ct : 1; }
+        // (the uniform model counts PMT_MID_GROUP_US per group)
+        if (s == 1 || t1 * (PMT_MID_GROUP_US / PMT_MID_TAIL_US) < best_t) { s = 1; sdiag = cd; ntail = ct > 1 ? rem : 0; stail = ct > 1 ? ct : 1; }
     }
 #ifdef PMT_TUNING
     if (const char *e = getenv("PMT_MID_TAIL")) { if (atoi(e) == 0) { ntail = 0; stail = 1; } }          // (measurement builds only)
