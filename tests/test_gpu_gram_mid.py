@@ -1,4 +1,4 @@
-"""-m gpu: the one-launch form of the canonical objective node for wide shapes of up to 2048 columns (csrc/gram_mid.hip: 64 x 64 tiles, the
+"""-m gpu: the one-launch form of the canonical objective node for wide shapes of up to 4096 columns (csrc/gram_mid.hip: 64 x 64 tiles, the
 contraction index split among the waves and over row chunks, last-arriver fold in chunk order, c'c as one more workgroup) — every plan
 regime (one chunk per tile, split tiles in one round, several rounds, the XCD-aware order beyond 4 MB, fewer than 32 rows), every load path,
 both outputs; repeated and concurrent launches give the same BITS (the fold's order does not depend on who arrives last; the per-tile
@@ -28,6 +28,10 @@ SHAPES = [
     (4096, 512, 0, 0), (4099, 448, 0, 0), (5000, 129, 1, 0),                               # the masked last 8-row group beside unmasked ones
     (2048, 1024, 0, 0), (4096, 1024, 0, 0), (2048, 1536, 0, 0), (1000, 2048, 2, 0),         # several rounds of workgroups; > 4 MB: XCD-aware order
     (128, 2048, 0, 0), (20000, 200, 0, 0), (8192, 512, 0, 1), (65536, 256, 0, 0), (30001, 130, 1, 0),          # many chunks per tile: the two-level fold
+    # 2049 .. 4096 columns (round 6c, config 2's regime): unsplit tiles in several rounds walked by persistent workgroups in super-tile order,
+    # the diagonal tiles and the partial round split; few rows, ragged rows / columns, odd pitch, shifted base (the masked load path)
+    (5, 2100, 0, 0), (100, 2500, 1, 0), (31, 4096, 0, 1), (1000, 3000, 0, 0), (2048, 2304, 0, 0), (1029, 2049, 3, 1), (1500, 4095, 0, 0),
+    (3000, 2100, 1, 0), (2000, 2560, 0, 0),
 ]
 
 
@@ -45,7 +49,7 @@ def _node(g, dA, lda, rows, n, xvar, db, sign, ws, stream, out=None):
     return oq, ol, oc
 
 
-@pytest.mark.parametrize("rows,n", [(300, 300), (4096, 512), (4096, 1024), (20000, 200)])      # (the last: groups of 8 chunks folded first, then the groups)
+@pytest.mark.parametrize("rows,n", [(300, 300), (4096, 512), (4096, 1024), (20000, 200), (1024, 2560)])      # (20000 x 200: groups of 8 chunks folded first, then the groups; the last: persistent workgroups, split tails)
 def test_repeated_launches_give_the_same_bits(rows, n):
     """the sums of a split tile are added in chunk order by whichever workgroup arrives last, and that workgroup re-arms the tile's count:
     thirty launches in a row, every one bit-identical to the first"""
@@ -65,11 +69,11 @@ def test_repeated_launches_give_the_same_bits(rows, n):
         assert got == first
 
 
-def test_two_streams_run_the_node_at_once_without_sharing_counts():
-    """the per-tile arrival counts belong to the CALLING STREAM (gram.hip: SideStream): two streams launching the node back to back, each
-    on its own matrix and workspace, get what each gets alone"""
+@pytest.mark.parametrize("rows,n", [(2048, 512), (1024, 2304)])      # (the second: two sets of 256 persistent workgroups share the CUs; tickets per stream)
+def test_two_streams_run_the_node_at_once_without_sharing_counts(rows, n):
+    """the per-tile arrival counts (and the persistent form's tickets) belong to the CALLING STREAM (gram.hip: SideStream): two streams
+    launching the node back to back, each on its own matrix and workspace, get what each gets alone"""
     import gpu_util as g
-    rows, n = 2048, 512
     assert _order(rows, n) == 5
     rng = np.random.default_rng(5)
     nq = n * (n + 1) // 2
@@ -101,7 +105,7 @@ def test_workspace_covers_every_workgroups_partial():
     """pmt_quad_gram_workspace_bytes is what the node may write: a guard band behind it stays untouched"""
     import gpu_util as g
     rng = np.random.default_rng(9)
-    for rows, n in ((4096, 1024), (1024, 512), (128, 2048)):
+    for rows, n in ((4096, 1024), (1024, 512), (128, 2048), (1024, 2304)):
         nbytes = g.lib().pmt_quad_gram_workspace_bytes(rows, n)
         guard = 4096
         buf = torch.full((nbytes // 8 + guard,), 7.25, dtype=torch.float64, device="cuda")
