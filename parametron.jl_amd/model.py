@@ -382,6 +382,11 @@ class Model:
                     def is_gram(r):
                         return getattr(r, "mode", "").startswith("canonical") and r.kind == "quad" and getattr(r.expr, "gram_candidate", None) is not None
                     emit_order = [re for re in emit_order if not is_gram(re[0])] + [re for re in emit_order if is_gram(re[0])]
+                elif use_lane:
+                    # round 6c: the side lane's records go in FRONT of the objective — its one-launch node (gram_mid.hip) holds every CU
+                    # with persistent workgroups and lane entries recorded behind it wait for it; recorded first they take CUs first and
+                    # the node's workgroups start as CUs come free (config 3, staged uploads: 1.244 -> 1.222 ms per step)
+                    emit_order = [re for re in emit_order if any(re[0] is x for x in eligible)] + [re for re in emit_order if not any(re[0] is x for x in eligible)]
                 for r, e in emit_order:
                     side = use_lane and any(r is x for x in eligible)
                     if side:
